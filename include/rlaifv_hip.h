@@ -1,0 +1,132 @@
+/* rlaifv_hip.h - C ABI of librlaifv_hip.so, the MI355X (gfx950) kernels behind the RLAIF-V LLaVA-1.5
+ * DPO training step.
+ *
+ * Boundary: the reference has no FFI/plugin layer - its hot path is Python
+ * calling HuggingFace/torch modules.  Each entry point below replaces the third-party / reference
+ * arithmetic named in its comment (paths relative to the reference checkout).  The Python host
+ * (rlaif_v_amd.hip) binds these with ctypes; INTEGRATION.md shows the stub a reference maintainer adds.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller and borrowed for the call;
+ *    bf16 tensors are raw uint16 bit patterns (`void*`), statistics are fp32, indices are int32;
+ *  - `ld*` are row strides in ELEMENTS; bf16 rows must be 16-byte aligned;
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises;
+ *  - return 0 = ok, 1 = argument error, 2 = launch error; text via rv_last_error() (thread local);
+ *  - no exceptions cross the ABI, no internal threads, no allocation.
+ */
+#ifndef RLAIFV_HIP_H
+#define RLAIFV_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RV_ABI_VERSION 1
+
+const char* rv_last_error(void);
+int rv_abi_version(void);
+/* 0 = register-staged GEMM tiles, 1 = global_load_lds (LDS-DMA) tiles (default). */
+int rv_set_gemm_variant(int variant);
+
+/* ---- dense contractions (replace torch.nn.Linear inside HF LlamaForCausalLM / CLIPVisionModel /
+ *      mm_projector: llava/model/language_model/llava_llama.py:91-102,
+ *      llava/model/multimodal_encoder/clip_encoder.py:55, llava/model/multimodal_projector/builder.py:39-46)
+ *   C[m][n] = act(alpha * sum_k A[m][k] * B[n][k] + bias[n]) + R[m][n]        (bf16 in, fp32 accumulate)
+ *   act: 0 none, 1 quick_gelu (CLIP MLP), 2 gelu(erf) (projector).  K % 64 == 0, N % 4 == 0.
+ *   variant: -1 = process default, 0 / 1 as rv_set_gemm_variant. */
+int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                    const void* bias, const void* residual, long ldr, int act, float alpha, int variant,
+                    void* stream);
+int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                           int variant, void* stream);
+
+/* ---- fused LM head + log-softmax + label gather (replaces lm_head + get_batch_logps,
+ *      muffin/eval/muffin_inference_logp.py:82-115; logits [rows, V] never reach HBM).
+ *   fwd : per selected row m and 64-column block j:  pmax[m][j], psum[m][j] = max / sum exp(x - max);
+ *         tgt_logit[m] = logit of tgt[m].   V % 64 == 0.
+ *   finish: lse[m], logp[m] = tgt_logit[m] - lse[m].
+ *   bwd : dlogits[m][n] = coef[m] * ((n == tgt[m]) - exp(logit - lse[m]))  (bf16, recomputed logits). */
+int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, int M, int V, int K,
+                       float* pmax, float* psum, float* tgt_logit, int variant, void* stream);
+int rv_logp_finish(const float* pmax, const float* psum, const float* tgt_logit, int nblk, int M, float* lse,
+                   float* logp, void* stream);
+int rv_lmhead_logp_bwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, const float* lse,
+                       const float* coef, void* dlogits, long ldd, int M, int V, int K, int variant, void* stream);
+/* (per_token_logps * loss_mask).sum(-1) and loss_mask.sum(-1) of get_batch_logps (:103-104); rows of
+ * sequence s are seq_off[s] .. seq_off[s+1]; optional per-row weight (compute_weighted_logp,
+ * muffin/train/trainers.py:128-137). Fixed summation order. */
+int rv_seq_sum(const float* logp, const float* weight, const int* seq_off, int n_seq, float* out_sum, float* out_cnt,
+               void* stream);
+/* dpo_loss + loss mix + metrics (muffin/train/trainers.py:91-126, :292-309) and its closed-form gradient.
+ *   per_pair[5][B] = losses, chosen_rewards, rejected_rewards, policy_win_logp, policy_rej_logp
+ *   scalars[8]     = loss, mean chosen reward, mean rejected reward, accuracy, margin, mean win logp, mean rej logp, 0
+ *   coef[2B]       = d loss / d (sequence log-prob sum) */
+int rv_dpo_loss(const float* seq_sum, const float* seq_cnt, const float* ref_win, const float* ref_rej, int B,
+                float beta, int use_average, float sft_weight, float dpo_weight, float* per_pair, float* scalars,
+                float* coef, void* stream);
+int rv_row_coef(const float* coef, const int* seq_of_row, const float* weight, float* out, int n, void* stream);
+
+/* ---- attention (replaces HF LlamaAttention eager/SDPA math and CLIPAttention).
+ *   qkv: [S*L][ld] with q heads at q_col0 + h*hd, k heads at k_col0 + h*hd; vt = rv_head_transpose of V.
+ *   out: [S*L][ldo] (head h at column h*hd); lse: [S][H][L] natural-log of sum exp(scale * q.k).
+ *   causal=1: pure causal mask, no padding mask (muffin/train/trainers.py:199). hd in {64,128}. */
+int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, const void* vt, void* out, long ldo, float* lse,
+                int S, int L, int H, int hd, int causal, float scale, void* stream);
+/* backward (hd = 128): qt/kt/dOt are rv_head_transpose copies of Q, K, dO; delta = rv_attn_delta.
+ * Writes dQ, dK, dV into dqkv at the same column offsets as qkv. */
+int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* qt, const void* kt,
+                const void* dO, long lddo, const void* dOt, const float* lse, const float* delta, void* dqkv,
+                long lddq, int S, int L, int H, int hd, int causal, float scale, void* stream);
+int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
+                  void* stream);
+/* X[(s*L+l)][col0 + h*hd + e] -> XT[s][h][e][Lp], Lp = roundup(L,64), zero padded; positions inside every
+ * aligned group of 16 stored with 4-element chunks 1 and 2 swapped (MFMA accumulator order). */
+int rv_head_transpose(const void* x, long ld, int col0, void* xt, int S, int L, int H, int hd, void* stream);
+
+/* ---- norms / rotary / activations (replace HF LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP, CLIP LayerNorm) */
+int rv_rmsnorm_fwd(const void* x, long ldx, const int* row_idx, const void* w, void* y, long ldy, float* rstd,
+                   int rows, int d, float eps, void* stream);
+int rv_rmsnorm_bwd_nblocks(int rows);   /* rows of the fp32 dw_partial scratch [nblocks][d] */
+int rv_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const int* row_idx, const void* w,
+                   const float* rstd, const void* dres, long lddres, void* dx, long lddx, float* dw_partial,
+                   void* dw, int dw_accumulate, int rows, int d, void* stream);
+int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int d,
+                     float eps, void* stream);
+/* in-place half-split RoPE over n_heads_total adjacent heads (q then k), position = token % L
+ * (position_ids are dropped: llava/model/language_model/llava_llama.py:94); backward = inverse rotation. */
+int rv_rope_inplace(void* x, long ld, const float* cos_tab, const float* sin_tab, long n_tok, int L,
+                    int n_heads_total, int hd, int backward, void* stream);
+int rv_swiglu_fwd(const void* gu, long ldgu, void* act, long lda, long rows, int f, void* stream);
+int rv_swiglu_bwd(const void* dact, long ldd, const void* gu, long ldgu, void* dgu, long lddgu, long rows, int f,
+                  void* stream);
+int rv_gelu_fwd(const void* x, void* y, long n, void* stream);
+int rv_gelu_bwd(const void* dy, const void* x, void* dx, long n, void* stream);
+
+/* ---- data movement */
+int rv_transpose(const void* in, long ld_in, void* out, long ldo, int R, int C, void* stream);
+/* prepare_inputs_labels_for_multimodal (llava/model/llava_arch.py:237-315): out row n = embed[src[n]] if
+ * src[n] >= 0, zero if -1, image feature row (-2 - src[n]) otherwise. */
+int rv_splice_fwd(const int* src, const void* embed, const void* feats, void* out, long n_rows, int d, void* stream);
+int rv_embed_bwd(const int* uniq_ids, const int* seg_off, const int* pos_sorted, int n_uniq, const void* dx, void* dW,
+                 int d, void* stream);
+int rv_feat_grad(const int* src_a, const int* src_b, const void* dx, void* dfeat, long n_rows, int d, void* stream);
+int rv_gather_rows(const void* in, long ld_in, const int* idx, void* out, long ld_out, long n_rows, int d, int scatter,
+                   void* stream);
+int rv_colsum(const void* dy, long ld, void* db, int M, int N, void* stream);
+/* CLIPVisionEmbeddings (patch conv as GEMM): fp32 pixels -> bf16 patch rows [B*P][Kp], then CLS + pos-emb */
+int rv_im2col_patches(const float* pixels, void* out, int B, int image_size, int patch, int Kp, void* stream);
+int rv_clip_assemble(const void* patch, const void* cls, const void* pos, void* x, int B, int P, int d, void* stream);
+int rv_cast_f32_to_bf16(const float* in, void* out, long n, void* stream);
+int rv_cast_bf16_to_f32(const void* in, float* out, long n, void* stream);
+
+/* ---- optimizer (replaces torch.optim.AdamW + clip_grad_norm_ selected by optim="adamw_torch",
+ *      muffin/train/train_llava15.py:75).  out2[0] = ||g||, out2[1] = min(1, max_norm/(||g||+1e-6)). */
+int rv_sumsq_nblocks(void);
+int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float* out2, void* stream);
+int rv_adamw_step(void* p, float* master, float* m, float* v, const void* g, long n, float lr, float beta1, float beta2,
+                  float eps, float wd, int step, const float* clip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLAIFV_HIP_H */

@@ -1,0 +1,913 @@
+// HBM-bound kernels of the DPO step (norms, RoPE, SwiGLU, GELU, transposes, splice, optimizer).
+// All bf16 traffic is 16 bytes per lane (8 x bf16); accumulation in fp32.
+#include "common.hpp"
+#include "rlaifv_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = bf2f((bf16_t)(v.x & 0xffff)); f[1] = bf2f((bf16_t)(v.x >> 16));
+  f[2] = bf2f((bf16_t)(v.y & 0xffff)); f[3] = bf2f((bf16_t)(v.y >> 16));
+  f[4] = bf2f((bf16_t)(v.z & 0xffff)); f[5] = bf2f((bf16_t)(v.z >> 16));
+  f[6] = bf2f((bf16_t)(v.w & 0xffff)); f[7] = bf2f((bf16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+// ------------------------------------------------------------------ RMSNorm
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                          const int* __restrict__ row_idx,
+                                                          const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                          long ldy, float* __restrict__ rstd_out, int rows, int d,
+                                                          float eps) {
+  __shared__ float red[16];
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const bf16_t* xr = x + (long)(row_idx ? row_idx[r] : r) * ldx;
+    float ss = 0.f;
+    for (int c = threadIdx.x * 8; c < d; c += 256 * 8) {
+      float f[8];
+      unpack8(*(const uint4*)(xr + c), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+    }
+    ss = block_sum(ss, red);
+    const float rs = rsqrtf(ss / (float)d + eps);
+    if (rstd_out && threadIdx.x == 0) rstd_out[r] = rs;
+    for (int c = threadIdx.x * 8; c < d; c += 256 * 8) {
+      float f[8], g[8];
+      unpack8(*(const uint4*)(xr + c), f);
+      unpack8(*(const uint4*)(w + c), g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = f[j] * rs * g[j];
+      *(uint4*)(y + (long)r * ldy + c) = pack8(f);
+    }
+  }
+}
+
+// dx = rstd * (g - xhat * mean(g * xhat)) [+ dres], g = dy * w;  dw_partial[block] += dy * xhat
+#define RMS_MAX_ITERS 4
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, long lddy,
+                                                          const bf16_t* __restrict__ x, long ldx,
+                                                          const int* __restrict__ row_idx,
+                                                          const bf16_t* __restrict__ w,
+                                                          const float* __restrict__ rstd,
+                                                          const bf16_t* __restrict__ dres, long lddres,
+                                                          bf16_t* __restrict__ dx, long lddx,
+                                                          float* __restrict__ dw_partial, int rows, int d) {
+  __shared__ float red[16];
+  float dwacc[RMS_MAX_ITERS][8];
+#pragma unroll
+  for (int i = 0; i < RMS_MAX_ITERS; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwacc[i][j] = 0.f;
+  const int rows_per = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = min(rows, r0 + rows_per);
+  for (int r = r0; r < r1; ++r) {
+    const long xrow = row_idx ? row_idx[r] : r;
+    const bf16_t* xr = x + xrow * ldx;
+    const bf16_t* dyr = dy + (long)r * lddy;
+    const float rs = rstd[r];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+      const int c = threadIdx.x * 8 + i * 2048;
+      if (c < d) {
+        float fx[8], fy[8], fw[8];
+        unpack8(*(const uint4*)(xr + c), fx);
+        unpack8(*(const uint4*)(dyr + c), fy);
+        unpack8(*(const uint4*)(w + c), fw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = fx[j] * rs;
+          dot += fy[j] * fw[j] * xh;
+          dwacc[i][j] += fy[j] * xh;
+        }
+      }
+    }
+    dot = block_sum(dot, red) / (float)d;
+    bf16_t* dxr = dx + xrow * lddx;
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+      const int c = threadIdx.x * 8 + i * 2048;
+      if (c < d) {
+        float fx[8], fy[8], fw[8], o[8];
+        unpack8(*(const uint4*)(xr + c), fx);
+        unpack8(*(const uint4*)(dyr + c), fy);
+        unpack8(*(const uint4*)(w + c), fw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (fy[j] * fw[j] - fx[j] * rs * dot);
+        if (dres) {
+          float fr[8];
+          unpack8(*(const uint4*)(dres + xrow * lddres + c), fr);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += fr[j];
+        }
+        *(uint4*)(dxr + c) = pack8(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+    const int c = threadIdx.x * 8 + i * 2048;
+    if (c < d) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dw_partial[(long)blockIdx.x * d + c + j] = dwacc[i][j];
+    }
+  }
+}
+
+// out[c] (bf16) = sum_p partial[p][c]  (+ existing out if accumulate)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int d,
+                                       bf16_t* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float s = accumulate ? bf2f(out[c]) : 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(long)p * d + c];
+  out[c] = f2bf(s);
+}
+
+// ------------------------------------------------------------------ LayerNorm (CLIP, forward only)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                            const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                                                            long ldy, int rows, int d, float eps) {
+  __shared__ float red[16];
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const bf16_t* xr = x + (long)r * ldx;
+    float s = 0.f;
+    for (int c = threadIdx.x * 8; c < d; c += 2048) {
+      float f[8];
+      unpack8(*(const uint4*)(xr + c), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[j];
+    }
+    const float mean = block_sum(s, red) / (float)d;
+    float v = 0.f;
+    for (int c = threadIdx.x * 8; c < d; c += 2048) {
+      float f[8];
+      unpack8(*(const uint4*)(xr + c), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += (f[j] - mean) * (f[j] - mean);
+    }
+    const float rs = rsqrtf(block_sum(v, red) / (float)d + eps);
+    for (int c = threadIdx.x * 8; c < d; c += 2048) {
+      float f[8], g[8], h[8];
+      unpack8(*(const uint4*)(xr + c), f);
+      unpack8(*(const uint4*)(w + c), g);
+      unpack8(*(const uint4*)(b + c), h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rs * g[j] + h[j];
+      *(uint4*)(y + (long)r * ldy + c) = pack8(f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RoPE (half-split layout), in place
+// x: [n_tok][ld]; rotates `n_heads_total` heads of width hd starting at column 0 (q then k are adjacent).
+__global__ void rope_kernel(bf16_t* __restrict__ x, long ld, const float* __restrict__ cs_cos,
+                            const float* __restrict__ cs_sin, long n_tok, int L, int n_heads_total, int hd,
+                            float sign) {
+  const int half = hd >> 1, cpr = half >> 3;  // 16-byte chunks per half head
+  const long total = n_tok * n_heads_total * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    const long t2 = i / cpr;
+    const int h = (int)(t2 % n_heads_total);
+    const long n = t2 / n_heads_total;
+    const int pos = (int)(n % L);
+    bf16_t* p1 = x + n * ld + (long)h * hd + ch * 8;
+    bf16_t* p2 = p1 + half;
+    float a[8], b[8], o1[8], o2[8];
+    unpack8(*(const uint4*)p1, a);
+    unpack8(*(const uint4*)p2, b);
+    const float* c = cs_cos + (long)pos * half + ch * 8;
+    const float* s = cs_sin + (long)pos * half + ch * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cc = c[j], ss = s[j] * sign;
+      o1[j] = a[j] * cc - b[j] * ss;
+      o2[j] = b[j] * cc + a[j] * ss;
+    }
+    *(uint4*)p1 = pack8(o1);
+    *(uint4*)p2 = pack8(o2);
+  }
+}
+
+// ------------------------------------------------------------------ SwiGLU
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, long ldgu, bf16_t* __restrict__ act, long lda,
+                                  long rows, int f) {
+  const int cpr = f >> 3;
+  const long total = rows * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cpr;
+    const int c = (int)(i % cpr) * 8;
+    float g[8], u[8], o[8];
+    unpack8(*(const uint4*)(gu + r * ldgu + c), g);
+    unpack8(*(const uint4*)(gu + r * ldgu + f + c), u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
+    *(uint4*)(act + r * lda + c) = pack8(o);
+  }
+}
+
+__global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, long ldd, const bf16_t* __restrict__ gu,
+                                  long ldgu, bf16_t* __restrict__ dgu, long lddgu, long rows, int f) {
+  const int cpr = f >> 3;
+  const long total = rows * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cpr;
+    const int c = (int)(i % cpr) * 8;
+    float g[8], u[8], da[8], dg[8], du[8];
+    unpack8(*(const uint4*)(gu + r * ldgu + c), g);
+    unpack8(*(const uint4*)(gu + r * ldgu + f + c), u);
+    unpack8(*(const uint4*)(dact + r * ldd + c), da);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sg = 1.f / (1.f + __expf(-g[j]));
+      const float silu = g[j] * sg;
+      dg[j] = da[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
+      du[j] = da[j] * silu;
+    }
+    *(uint4*)(dgu + r * lddgu + c) = pack8(dg);
+    *(uint4*)(dgu + r * lddgu + f + c) = pack8(du);
+  }
+}
+
+// ------------------------------------------------------------------ GELU(erf) for the projector
+__global__ void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(((const uint4*)x)[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = 0.5f * f[j] * (1.f + erff(f[j] * 0.70710678118654752f));
+    ((uint4*)y)[i] = pack8(f);
+  }
+}
+__global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                bf16_t* __restrict__ dx, long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8], g[8];
+    unpack8(((const uint4*)x)[i], f);
+    unpack8(((const uint4*)dy)[i], g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cdf = 0.5f * (1.f + erff(f[j] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * f[j] * f[j]);
+      g[j] = g[j] * (cdf + f[j] * pdf);
+    }
+    ((uint4*)dx)[i] = pack8(g);
+  }
+}
+
+// ------------------------------------------------------------------ 2-D transpose with zero padding
+// in [R][C] (ld_in) -> out [C][ldo], ldo = roundup(R, 64); out[c][r >= R] = 0.   C % 8 == 0.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, long ld_in,
+                                                        bf16_t* __restrict__ out, long ldo, int R, int C) {
+  __shared__ bf16_t tile[64][72];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = threadIdx.x + i * 256;   // 512 chunks of 8
+    const int r = ch >> 3, cc = (ch & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < R && c0 + cc < C) v = *(const uint4*)(in + (long)(r0 + r) * ld_in + c0 + cc);
+    *(uint4*)(&tile[r][cc]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = threadIdx.x + i * 256;
+    const int c = ch >> 3, rr = (ch & 7) * 8;   // output row c, 8 consecutive source rows
+    if (c0 + c < C) {
+      bf16_t t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = tile[rr + j][c];
+      uint4 v;
+      v.x = t[0] | ((uint32_t)t[1] << 16); v.y = t[2] | ((uint32_t)t[3] << 16);
+      v.z = t[4] | ((uint32_t)t[5] << 16); v.w = t[6] | ((uint32_t)t[7] << 16);
+      *(uint4*)(out + (long)(c0 + c) * ldo + r0 + rr) = v;
+    }
+  }
+}
+
+// Per-head transpose for attention: X[(s*L + l)][col0 + h*hd + e] -> XT[((s*H + h)*hd + e)][Lp],
+// Lp = roundup(L,64), zero padded.  Inside every aligned group of 16 positions the 4-element chunks 1
+// and 2 are swapped (pos p <-> token (p&~12) | ((p&4)<<1) | ((p&8)>>1)), which is the order in which a
+// 32x32x16 MFMA B-operand taken straight from accumulators enumerates its contraction index.
+template <int HD>
+__global__ __launch_bounds__(256) void head_transpose_kernel(const bf16_t* __restrict__ x, long ld, int col0,
+                                                             bf16_t* __restrict__ xt, int L, int Lp, int H) {
+  __shared__ bf16_t tile[64][HD + 8];
+  const int l0 = blockIdx.x * 64, h = blockIdx.y, s = blockIdx.z;
+  constexpr int CPR = HD / 8;
+  for (int ch = threadIdx.x; ch < 64 * CPR; ch += 256) {
+    const int r = ch / CPR, cc = (ch % CPR) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (l0 + r < L) v = *(const uint4*)(x + ((long)s * L + l0 + r) * ld + col0 + h * HD + cc);
+    *(uint4*)(&tile[r][cc]) = v;
+  }
+  __syncthreads();
+  bf16_t* base = xt + ((long)(s * H + h) * HD) * Lp + l0;
+  for (int ch = threadIdx.x; ch < HD * 8; ch += 256) {
+    const int e = ch >> 3, p0 = (ch & 7) * 8;   // 8 consecutive output positions
+    bf16_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = p0 + j;
+      const int tok = (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1);
+      t[j] = tile[tok][e];
+    }
+    uint4 v;
+    v.x = t[0] | ((uint32_t)t[1] << 16); v.y = t[2] | ((uint32_t)t[3] << 16);
+    v.z = t[4] | ((uint32_t)t[5] << 16); v.w = t[6] | ((uint32_t)t[7] << 16);
+    *(uint4*)(base + (long)e * Lp + p0) = v;
+  }
+}
+
+// ------------------------------------------------------------------ splice (K4)
+// src[n] >= 0: embed row; -1: zero pad row; <= -2: image feature row (-2 - src[n])
+__global__ void splice_fwd_kernel(const int* __restrict__ src, const bf16_t* __restrict__ embed,
+                                  const bf16_t* __restrict__ feats, bf16_t* __restrict__ out, long n_rows, int d) {
+  const int cpr = d >> 3;
+  const long total = n_rows * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / cpr;
+    const int c = (int)(i % cpr) * 8;
+    const int sidx = src[n];
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (sidx >= 0) v = *(const uint4*)(embed + (long)sidx * d + c);
+    else if (sidx <= -2) v = *(const uint4*)(feats + (long)(-2 - sidx) * d + c);
+    *(uint4*)(out + n * d + c) = v;
+  }
+}
+
+// Deterministic embedding backward: block u sums dx rows pos_sorted[seg_off[u] .. seg_off[u+1]) in fp32
+// and writes row uniq_ids[u] of dW (bf16).  Rows of dW not listed stay as they are (caller zeroes).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ uniq_ids,
+                                                        const int* __restrict__ seg_off,
+                                                        const int* __restrict__ pos_sorted,
+                                                        const bf16_t* __restrict__ dx, bf16_t* __restrict__ dW,
+                                                        int d) {
+  const int u = blockIdx.x;
+  const int a = seg_off[u], b = seg_off[u + 1];
+  const long row = uniq_ids[u];
+  for (int c = threadIdx.x * 8; c < d; c += 2048) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = a; k < b; ++k) {
+      float f[8];
+      unpack8(*(const uint4*)(dx + (long)pos_sorted[k] * d + c), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    *(uint4*)(dW + row * d + c) = pack8(acc);
+  }
+}
+
+// dfeat[r] = dx[src_a[r]] + dx[src_b[r]]   (index -1 = absent)
+__global__ void feat_grad_kernel(const int* __restrict__ src_a, const int* __restrict__ src_b,
+                                 const bf16_t* __restrict__ dx, bf16_t* __restrict__ dfeat, long n_rows, int d) {
+  const int cpr = d >> 3;
+  const long total = n_rows * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cpr;
+    const int c = (int)(i % cpr) * 8;
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f[8];
+    const int a = src_a[r], b = src_b[r];
+    if (a >= 0) {
+      unpack8(*(const uint4*)(dx + (long)a * d + c), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += f[j];
+    }
+    if (b >= 0) {
+      unpack8(*(const uint4*)(dx + (long)b * d + c), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += f[j];
+    }
+    *(uint4*)(dfeat + r * d + c) = pack8(o);
+  }
+}
+
+// Row gather / zero-filled scatter of 16-byte chunks: out[r] = in[idx[r]]  /  out[idx[r]] = in[r]
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ in, long ld_in, const int* __restrict__ idx,
+                                   bf16_t* __restrict__ out, long ld_out, long n_rows, int d, int scatter) {
+  const int cpr = d >> 3;
+  const long total = n_rows * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cpr;
+    const int c = (int)(i % cpr) * 8;
+    const long k = idx[r];
+    if (scatter) *(uint4*)(out + k * ld_out + c) = *(const uint4*)(in + r * ld_in + c);
+    else *(uint4*)(out + r * ld_out + c) = *(const uint4*)(in + k * ld_in + c);
+  }
+}
+
+// column sums: db[c] = sum_m dy[m][c]   (bias gradients; bf16 out)
+__global__ void colsum_kernel(const bf16_t* __restrict__ dy, long ld, bf16_t* __restrict__ db, int M, int N) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += bf2f(dy[(long)m * ld + c]);
+  db[c] = f2bf(s);
+}
+
+// ------------------------------------------------------------------ CLIP front end
+// pixels fp32 [B][3][H][W] -> patches bf16 [B*P][Kp], column = c*ps*ps + ky*ps + kx, zero for col >= 3*ps*ps
+__global__ void im2col_kernel(const float* __restrict__ px, bf16_t* __restrict__ out, int B, int HW, int ps, int Kp) {
+  const int g = HW / ps, P = g * g, K = 3 * ps * ps;
+  const long total = (long)B * P * Kp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % Kp);
+    const long rp = i / Kp;
+    const int p = (int)(rp % P), b = (int)(rp / P);
+    float v = 0.f;
+    if (col < K) {
+      const int c = col / (ps * ps), rem = col % (ps * ps), ky = rem / ps, kx = rem % ps;
+      const int py = p / g, pxx = p % g;
+      v = px[(((long)b * 3 + c) * HW + (py * ps + ky)) * HW + pxx * ps + kx];
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+// x[b][0] = cls + pos[0];  x[b][1+p] = patch[b*P+p] + pos[1+p]
+__global__ void clip_assemble_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls,
+                                     const bf16_t* __restrict__ pos, bf16_t* __restrict__ x, int B, int P, int d) {
+  const int cpr = d >> 3;
+  const long total = (long)B * (P + 1) * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpr) * 8;
+    const long rt = i / cpr;
+    const int t = (int)(rt % (P + 1)), b = (int)(rt / (P + 1));
+    float a[8], q[8];
+    if (t == 0) unpack8(*(const uint4*)(cls + c), a);
+    else unpack8(*(const uint4*)(patch + ((long)b * P + t - 1) * d + c), a);
+    unpack8(*(const uint4*)(pos + (long)t * d + c), q);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += q[j];
+    *(uint4*)(x + rt * d + c) = pack8(a);
+  }
+}
+
+// ------------------------------------------------------------------ optimizer
+__global__ void sumsq_kernel(const bf16_t* __restrict__ g, long n8, float* __restrict__ partial) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(((const uint4*)g)[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[j] * f[j];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// out[0] = ||g||, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0).
+// `extra_sq` (nullable) adds squared norms computed elsewhere (other ranks / buffers).
+__global__ void gradnorm_finish_kernel(const float* __restrict__ partial, int nparts, float max_norm,
+                                       float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf(s);
+    out[0] = nrm;
+    out[1] = (max_norm > 0.f) ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f;
+  }
+}
+
+// AdamW with decoupled weight decay on fp32 master weights; writes the bf16 working copy.
+__global__ void adamw_kernel(bf16_t* __restrict__ p, float* __restrict__ master, float* __restrict__ m,
+                             float* __restrict__ v, const bf16_t* __restrict__ g, long n8, float lr, float b1,
+                             float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                             const float* __restrict__ clip) {
+  const float gs = clip ? clip[1] : 1.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float gf[8], o[8];
+    unpack8(((const uint4*)g)[i], gf);
+    float4 w0 = ((float4*)master)[2 * i], w1 = ((float4*)master)[2 * i + 1];
+    float4 m0 = ((float4*)m)[2 * i], m1 = ((float4*)m)[2 * i + 1];
+    float4 v0 = ((float4*)v)[2 * i], v1 = ((float4*)v)[2 * i + 1];
+    float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float mf[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    float vf[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gg = gf[j] * gs;
+      wf[j] *= (1.f - lr * wd);
+      mf[j] = b1 * mf[j] + (1.f - b1) * gg;
+      vf[j] = b2 * vf[j] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vf[j]) / bc2_sqrt + eps;
+      wf[j] -= (lr / bc1) * (mf[j] / denom);
+      o[j] = wf[j];
+    }
+    ((float4*)master)[2 * i] = make_float4(wf[0], wf[1], wf[2], wf[3]);
+    ((float4*)master)[2 * i + 1] = make_float4(wf[4], wf[5], wf[6], wf[7]);
+    ((float4*)m)[2 * i] = make_float4(mf[0], mf[1], mf[2], mf[3]);
+    ((float4*)m)[2 * i + 1] = make_float4(mf[4], mf[5], mf[6], mf[7]);
+    ((float4*)v)[2 * i] = make_float4(vf[0], vf[1], vf[2], vf[3]);
+    ((float4*)v)[2 * i + 1] = make_float4(vf[4], vf[5], vf[6], vf[7]);
+    ((uint4*)p)[i] = pack8(o);
+  }
+}
+
+// ------------------------------------------------------------------ log-prob reductions + DPO loss
+// lse[m] = log sum_n exp(logit[m][n]) from per-64-column partials; logp[m] = tgt_logit[m] - lse[m]
+__global__ void logp_finish_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                   const float* __restrict__ tgt_logit, int nblk, int M,
+                                   float* __restrict__ lse, float* __restrict__ logp) {
+  const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int lane = threadIdx.x & 63;
+  float mx = -INFINITY;
+  for (int i = lane; i < nblk; i += 64) mx = fmaxf(mx, pmax[(long)m * nblk + i]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int i = lane; i < nblk; i += 64) s += psum[(long)m * nblk + i] * __expf(pmax[(long)m * nblk + i] - mx);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float l = mx + logf(s);
+    lse[m] = l;
+    logp[m] = tgt_logit[m] - l;
+  }
+}
+
+// per sequence: sum of its selected rows' logp (rows of sequence s are seq_off[s]..seq_off[s+1]),
+// fixed summation order -> deterministic.   out_sum[s], out_cnt[s]
+__global__ void seq_sum_kernel(const float* __restrict__ logp, const float* __restrict__ weight,
+                               const int* __restrict__ seq_off, float* __restrict__ out_sum,
+                               float* __restrict__ out_cnt) {
+  __shared__ float red[16];
+  const int s = blockIdx.x, a = seq_off[s], b = seq_off[s + 1];
+  float acc = 0.f, cnt = 0.f;
+  for (int i = a + threadIdx.x; i < b; i += blockDim.x) {
+    const float w = weight ? weight[i] : 1.f;
+    acc += logp[i] * w;
+    cnt += w;
+  }
+  acc = block_sum(acc, red);
+  cnt = block_sum(cnt, red);
+  if (threadIdx.x == 0) { out_sum[s] = acc; out_cnt[s] = cnt; }
+}
+
+// DPO loss (muffin/train/trainers.py:91-126, :297-301) on B pairs, single block.
+//   in : seq_sum[2B], seq_cnt[2B] (wins then rejects), ref_win[B], ref_rej[B]
+//   out: per_pair[5][B] = losses, chosen_rewards, rejected_rewards, policy_win, policy_rej
+//        scalars[8]   = loss, mean chosen reward, mean rejected reward, accuracy, margin, mean win logp, mean rej logp, 0
+//        coef[2B]     = dLoss / d seq_sum  (already divided by count when use_average)
+__global__ void dpo_loss_kernel(const float* __restrict__ seq_sum, const float* __restrict__ seq_cnt,
+                                const float* __restrict__ ref_win, const float* __restrict__ ref_rej, int B,
+                                float beta, int use_average, float sft_w, float dpo_w,
+                                float* __restrict__ per_pair, float* __restrict__ scalars,
+                                float* __restrict__ coef) {
+  __shared__ float red[16];
+  float a_loss = 0, a_cw = 0, a_cr = 0, a_acc = 0, a_pw = 0, a_pr = 0;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    float pw = seq_sum[i], pr = seq_sum[B + i];
+    const float cw_n = seq_cnt[i], cr_n = seq_cnt[B + i];
+    if (use_average) { pw = pw / cw_n; pr = pr / cr_n; }
+    const float z = (pw - pr) - (ref_win[i] - ref_rej[i]);
+    const float bz = beta * z;
+    // -logsigmoid(bz) = softplus(-bz), stable form
+    const float loss = fmaxf(-bz, 0.f) + log1pf(__expf(-fabsf(bz)));
+    const float sig_neg = 1.f / (1.f + __expf(bz));   // sigmoid(-bz)
+    const float cw = beta * (pw - ref_win[i]), cr = beta * (pr - ref_rej[i]);
+    per_pair[0 * B + i] = loss; per_pair[1 * B + i] = cw; per_pair[2 * B + i] = cr;
+    per_pair[3 * B + i] = pw; per_pair[4 * B + i] = pr;
+    float gw = (-dpo_w * beta * sig_neg - sft_w) / (float)B;
+    float gr = (dpo_w * beta * sig_neg) / (float)B;
+    if (use_average) { gw /= cw_n; gr /= cr_n; }
+    coef[i] = gw; coef[B + i] = gr;
+    a_loss += loss; a_cw += cw; a_cr += cr; a_acc += (cw > cr) ? 1.f : 0.f; a_pw += pw; a_pr += pr;
+  }
+  a_loss = block_sum(a_loss, red); a_cw = block_sum(a_cw, red); a_cr = block_sum(a_cr, red);
+  a_acc = block_sum(a_acc, red); a_pw = block_sum(a_pw, red); a_pr = block_sum(a_pr, red);
+  if (threadIdx.x == 0) {
+    const float inv = 1.f / (float)B;
+    scalars[0] = dpo_w * a_loss * inv - sft_w * a_pw * inv;
+    scalars[1] = a_cw * inv; scalars[2] = a_cr * inv; scalars[3] = a_acc * inv;
+    scalars[4] = (a_cw - a_cr) * inv; scalars[5] = a_pw * inv; scalars[6] = a_pr * inv; scalars[7] = 0.f;
+  }
+}
+
+// row_coef[i] = coef[seq_of_row[i]] * (weight ? weight[i] : 1)
+__global__ void row_coef_kernel(const float* __restrict__ coef, const int* __restrict__ seq_of_row,
+                                const float* __restrict__ weight, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = coef[seq_of_row[i]] * (weight ? weight[i] : 1.f);
+}
+
+// delta[(s*H+h)*L + l] = sum_e dO[n][h*hd+e] * O[n][h*hd+e]     (one wave per (n,h))
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, long lddo,
+                                                         const bf16_t* __restrict__ O, long ldo,
+                                                         float* __restrict__ delta, int S, int L, int H, int hd) {
+  const long total = (long)S * L * H;
+  const int lane = threadIdx.x & 63;
+  for (long w = blockIdx.x * 4L + (threadIdx.x >> 6); w < total; w += gridDim.x * 4L) {
+    const int h = (int)(w % H);
+    const long n = w / H;
+    float acc = 0.f;
+    for (int e = lane * 2; e < hd; e += 128) {
+      const uint32_t a = *(const uint32_t*)(dO + n * lddo + (long)h * hd + e);
+      const uint32_t b = *(const uint32_t*)(O + n * ldo + (long)h * hd + e);
+      acc += bf2f((bf16_t)(a & 0xffff)) * bf2f((bf16_t)(b & 0xffff)) + bf2f((bf16_t)(a >> 16)) * bf2f((bf16_t)(b >> 16));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const int s = (int)(n / L), l = (int)(n % L);
+      delta[((long)s * H + h) * L + l] = acc;
+    }
+  }
+}
+
+// fp32 -> bf16 and bf16 -> fp32 casts (parameter initialisation plumbing)
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = f2bf(in[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = bf2f(in[i]);
+}
+
+inline int grid_for(long work, int block, int cap = 4096) {
+  long g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+#define STREAM(s) ((hipStream_t)(s))
+
+extern "C" {
+
+int rv_rmsnorm_fwd(const void* x, long ldx, const int* row_idx, const void* w, void* y, long ldy, float* rstd,
+                   int rows, int d, float eps, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "rv_rmsnorm_fwd: d/ld must be multiples of 8");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx,
+                     row_idx, (const bf16_t*)w, (bf16_t*)y, ldy, rstd, rows, d, eps);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_rmsnorm_bwd_nblocks(int rows) { return rows < 512 ? (rows < 1 ? 1 : rows) : 512; }
+
+int rv_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const int* row_idx, const void* w,
+                   const float* rstd, const void* dres, long lddres, void* dx, long lddx, float* dw_partial,
+                   void* dw, int dw_accumulate, int rows, int d, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && d <= 2048 * RMS_MAX_ITERS, "rv_rmsnorm_bwd: d must be a multiple of 8 and <= 8192");
+  RV_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && lddres % 8 == 0, "rv_rmsnorm_bwd: ld alignment");
+  if (rows == 0) return 0;
+  const int nb = rv_rmsnorm_bwd_nblocks(rows);
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, lddy,
+                     (const bf16_t*)x, ldx, row_idx, (const bf16_t*)w, rstd, (const bf16_t*)dres, lddres,
+                     (bf16_t*)dx, lddx, dw_partial, rows, d);
+  RV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((d + 255) / 256), dim3(256), 0, STREAM(stream), dw_partial, nb, d,
+                     (bf16_t*)dw, dw_accumulate);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int d,
+                     float eps, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "rv_layernorm_fwd: alignment");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx,
+                     (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, rows, d, eps);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_rope_inplace(void* x, long ld, const float* cos_tab, const float* sin_tab, long n_tok, int L,
+                    int n_heads_total, int hd, int backward, void* stream) {
+  RV_REQUIRE(hd % 16 == 0 && ld % 8 == 0, "rv_rope_inplace: hd%16, ld%8");
+  const long total = n_tok * n_heads_total * (hd / 16);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, STREAM(stream), (bf16_t*)x, ld,
+                     cos_tab, sin_tab, n_tok, L, n_heads_total, hd, backward ? -1.f : 1.f);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_swiglu_fwd(const void* gu, long ldgu, void* act, long lda, long rows, int f, void* stream) {
+  RV_REQUIRE(f % 8 == 0 && ldgu % 8 == 0 && lda % 8 == 0, "rv_swiglu_fwd: alignment");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
+                     (const bf16_t*)gu, ldgu, (bf16_t*)act, lda, rows, f);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_swiglu_bwd(const void* dact, long ldd, const void* gu, long ldgu, void* dgu, long lddgu, long rows, int f,
+                  void* stream) {
+  RV_REQUIRE(f % 8 == 0 && ldgu % 8 == 0 && ldd % 8 == 0 && lddgu % 8 == 0, "rv_swiglu_bwd: alignment");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
+                     (const bf16_t*)dact, ldd, (const bf16_t*)gu, ldgu, (bf16_t*)dgu, lddgu, rows, f);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_gelu_fwd(const void* x, void* y, long n, void* stream) {
+  RV_REQUIRE(n % 8 == 0, "rv_gelu_fwd: n%8");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, STREAM(stream), (const bf16_t*)x,
+                     (bf16_t*)y, n / 8);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+int rv_gelu_bwd(const void* dy, const void* x, void* dx, long n, void* stream) {
+  RV_REQUIRE(n % 8 == 0, "rv_gelu_bwd: n%8");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, STREAM(stream), (const bf16_t*)dy,
+                     (const bf16_t*)x, (bf16_t*)dx, n / 8);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_transpose(const void* in, long ld_in, void* out, long ldo, int R, int C, void* stream) {
+  RV_REQUIRE(C % 8 == 0 && ld_in % 8 == 0 && ldo % 8 == 0, "rv_transpose: C, ld_in, ldo must be multiples of 8");
+  RV_REQUIRE(ldo >= ((R + 63) / 64) * 64, "rv_transpose: ldo must be >= roundup(R,64)");
+  if (R == 0 || C == 0) return 0;
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, STREAM(stream),
+                     (const bf16_t*)in, ld_in, (bf16_t*)out, ldo, R, C);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_head_transpose(const void* x, long ld, int col0, void* xt, int S, int L, int H, int hd, void* stream) {
+  RV_REQUIRE(hd == 64 || hd == 128, "rv_head_transpose: head dim must be 64 or 128");
+  RV_REQUIRE(ld % 8 == 0 && col0 % 8 == 0, "rv_head_transpose: alignment");
+  const int Lp = ((L + 63) / 64) * 64;
+  dim3 grid(Lp / 64, H, S);
+  if (hd == 128)
+    hipLaunchKernelGGL(head_transpose_kernel<128>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, ld, col0,
+                       (bf16_t*)xt, L, Lp, H);
+  else
+    hipLaunchKernelGGL(head_transpose_kernel<64>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, ld, col0,
+                       (bf16_t*)xt, L, Lp, H);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_splice_fwd(const int* src, const void* embed, const void* feats, void* out, long n_rows, int d, void* stream) {
+  RV_REQUIRE(d % 8 == 0, "rv_splice_fwd: d%8");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(splice_fwd_kernel, dim3(grid_for(n_rows * (d / 8), 256, 16384)), dim3(256), 0, STREAM(stream), src,
+                     (const bf16_t*)embed, (const bf16_t*)feats, (bf16_t*)out, n_rows, d);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_embed_bwd(const int* uniq_ids, const int* seg_off, const int* pos_sorted, int n_uniq, const void* dx, void* dW,
+                 int d, void* stream) {
+  RV_REQUIRE(d % 8 == 0, "rv_embed_bwd: d%8");
+  if (n_uniq == 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_uniq), dim3(256), 0, STREAM(stream), uniq_ids, seg_off, pos_sorted,
+                     (const bf16_t*)dx, (bf16_t*)dW, d);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_feat_grad(const int* src_a, const int* src_b, const void* dx, void* dfeat, long n_rows, int d, void* stream) {
+  RV_REQUIRE(d % 8 == 0, "rv_feat_grad: d%8");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(feat_grad_kernel, dim3(grid_for(n_rows * (d / 8), 256, 16384)), dim3(256), 0, STREAM(stream), src_a,
+                     src_b, (const bf16_t*)dx, (bf16_t*)dfeat, n_rows, d);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_gather_rows(const void* in, long ld_in, const int* idx, void* out, long ld_out, long n_rows, int d, int scatter,
+                   void* stream) {
+  RV_REQUIRE(d % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, "rv_gather_rows: alignment");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n_rows * (d / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
+                     (const bf16_t*)in, ld_in, idx, (bf16_t*)out, ld_out, n_rows, d, scatter);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_colsum(const void* dy, long ld, void* db, int M, int N, void* stream) {
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, ld,
+                     (bf16_t*)db, M, N);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_im2col_patches(const float* pixels, void* out, int B, int image_size, int patch, int Kp, void* stream) {
+  RV_REQUIRE(image_size % patch == 0 && Kp >= 3 * patch * patch, "rv_im2col_patches: bad geometry");
+  const int g = image_size / patch;
+  const long total = (long)B * g * g * Kp;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, STREAM(stream), pixels,
+                     (bf16_t*)out, B, image_size, patch, Kp);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_clip_assemble(const void* patch, const void* cls, const void* pos, void* x, int B, int P, int d, void* stream) {
+  RV_REQUIRE(d % 8 == 0, "rv_clip_assemble: d%8");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(clip_assemble_kernel, dim3(grid_for((long)B * (P + 1) * (d / 8), 256)), dim3(256), 0,
+                     STREAM(stream), (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)x, B, P, d);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_sumsq_nblocks(void) { return 1024; }
+
+int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float* out2, void* stream) {
+  RV_REQUIRE(n % 8 == 0, "rv_grad_norm: n%8");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, STREAM(stream), (const bf16_t*)g, n / 8, partial);
+  RV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gradnorm_finish_kernel, dim3(1), dim3(256), 0, STREAM(stream), partial, 1024, max_norm, out2);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_adamw_step(void* p, float* master, float* m, float* v, const void* g, long n, float lr, float beta1, float beta2,
+                  float eps, float wd, int step, const float* clip, void* stream) {
+  RV_REQUIRE(n % 8 == 0, "rv_adamw_step: n%8");
+  if (n == 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 8, 256, 8192)), dim3(256), 0, STREAM(stream), (bf16_t*)p, master, m,
+                     v, (const bf16_t*)g, n / 8, lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), clip);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_logp_finish(const float* pmax, const float* psum, const float* tgt_logit, int nblk, int M, float* lse,
+                   float* logp, void* stream) {
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(logp_finish_kernel, dim3((M + 3) / 4), dim3(256), 0, STREAM(stream), pmax, psum, tgt_logit, nblk,
+                     M, lse, logp);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_seq_sum(const float* logp, const float* weight, const int* seq_off, int n_seq, float* out_sum, float* out_cnt,
+               void* stream) {
+  if (n_seq == 0) return 0;
+  hipLaunchKernelGGL(seq_sum_kernel, dim3(n_seq), dim3(256), 0, STREAM(stream), logp, weight, seq_off, out_sum,
+                     out_cnt);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_dpo_loss(const float* seq_sum, const float* seq_cnt, const float* ref_win, const float* ref_rej, int B,
+                float beta, int use_average, float sft_weight, float dpo_weight, float* per_pair, float* scalars,
+                float* coef, void* stream) {
+  RV_REQUIRE(B > 0, "rv_dpo_loss: B must be > 0");
+  hipLaunchKernelGGL(dpo_loss_kernel, dim3(1), dim3(256), 0, STREAM(stream), seq_sum, seq_cnt, ref_win, ref_rej, B,
+                     beta, use_average, sft_weight, dpo_weight, per_pair, scalars, coef);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_row_coef(const float* coef, const int* seq_of_row, const float* weight, float* out, int n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(row_coef_kernel, dim3((n + 255) / 256), dim3(256), 0, STREAM(stream), coef, seq_of_row, weight,
+                     out, n);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
+                  void* stream) {
+  RV_REQUIRE(hd % 2 == 0, "rv_attn_delta: hd even");
+  const long total = (long)S * L * H;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(grid_for(total, 4, 16384)), dim3(256), 0, STREAM(stream),
+                     (const bf16_t*)dO, lddo, (const bf16_t*)O, ldo, delta, S, L, H, hd);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_cast_f32_to_bf16(const float* in, void* out, long n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, STREAM(stream), in,
+                     (bf16_t*)out, n);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+int rv_cast_bf16_to_f32(const void* in, float* out, long n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, STREAM(stream),
+                     (const bf16_t*)in, out, n);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

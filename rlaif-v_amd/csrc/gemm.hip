@@ -1,0 +1,99 @@
+// C-ABI launchers for the bf16 NT GEMM and the fused LM-head log-prob kernels (gemm.hpp).
+#include "gemm.hpp"
+#include "rlaifv_hip.h"
+
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+void rv_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+static int g_default_variant = 1;  // 1 = global_load_lds staging, 0 = register staging
+
+template <int STAGE, class Epi>
+static int launch_gemm(const GemmShape& g, const Epi& epi, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<STAGE, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        GEMM_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (g.N + GEMM_BN - 1) / GEMM_BN;
+  hipLaunchKernelGGL((gemm_nt_kernel<STAGE, Epi>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, g,
+                     epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+template <class Epi>
+static int dispatch(const GemmShape& g, const Epi& epi, int variant, void* stream) {
+  if (variant < 0) variant = g_default_variant;
+  if (variant == 1) return launch_gemm<1, Epi>(g, epi, (hipStream_t)stream);
+  return launch_gemm<0, Epi>(g, epi, (hipStream_t)stream);
+}
+
+static int check_shape(const GemmShape& g, const char* who) {
+  if (g.K % GEMM_BK != 0 || g.K <= 0) { rv_set_error("GEMM: K must be a positive multiple of 64"); return 1; }
+  if (g.N % 4 != 0) { rv_set_error("GEMM: N must be a multiple of 4"); return 1; }
+  if (g.lda % 8 != 0 || g.ldb % 8 != 0) { rv_set_error("GEMM: lda/ldb must be multiples of 8 elements"); return 1; }
+  if (((uintptr_t)g.A | (uintptr_t)g.B) & 15) { rv_set_error("GEMM: A/B must be 16-byte aligned"); return 1; }
+  (void)who;
+  return 0;
+}
+
+extern "C" {
+
+const char* rv_last_error(void) { return g_err; }
+
+int rv_set_gemm_variant(int variant) {
+  RV_REQUIRE(variant == 0 || variant == 1, "rv_set_gemm_variant: 0 (register staging) or 1 (global_load_lds)");
+  g_default_variant = variant;
+  return 0;
+}
+
+int rv_abi_version(void) { return RV_ABI_VERSION; }
+
+int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                    const void* bias, const void* residual, long ldr, int act, float alpha, int variant,
+                    void* stream) {
+  if (M == 0 || N == 0) return 0;
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb};
+  if (check_shape(g, "rv_gemm_nt_bf16")) return 1;
+  RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_bf16: ldc/ldr must be multiples of 4");
+  EpiStore epi{(bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, alpha};
+  return dispatch(g, epi, variant, stream);
+}
+
+int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                           int variant, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb};
+  if (check_shape(g, "rv_gemm_nt_bf16_f32out")) return 1;
+  RV_REQUIRE(ldc % 4 == 0, "rv_gemm_nt_bf16_f32out: ldc must be a multiple of 4");
+  EpiStoreF32 epi{C, ldc};
+  return dispatch(g, epi, variant, stream);
+}
+
+int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, int M, int V, int K,
+                       float* pmax, float* psum, float* tgt_logit, int variant, void* stream) {
+  if (M == 0) return 0;
+  GemmShape g{(const bf16_t*)h, (const bf16_t*)W, M, V, K, ldh, ldw};
+  if (check_shape(g, "rv_lmhead_logp_fwd")) return 1;
+  RV_REQUIRE(V % 64 == 0, "rv_lmhead_logp_fwd: vocabulary must be a multiple of 64");
+  EpiLogpFwd epi{tgt, pmax, psum, tgt_logit};
+  return dispatch(g, epi, variant, stream);
+}
+
+int rv_lmhead_logp_bwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, const float* lse,
+                       const float* coef, void* dlogits, long ldd, int M, int V, int K, int variant, void* stream) {
+  if (M == 0) return 0;
+  GemmShape g{(const bf16_t*)h, (const bf16_t*)W, M, V, K, ldh, ldw};
+  if (check_shape(g, "rv_lmhead_logp_bwd")) return 1;
+  RV_REQUIRE(ldd % 4 == 0, "rv_lmhead_logp_bwd: ldd must be a multiple of 4");
+  EpiLogpBwd epi{tgt, lse, coef, (bf16_t*)dlogits, ldd};
+  return dispatch(g, epi, variant, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// bf16 NT GEMM for gfx950:  D[m][n] = sum_k A[m][k] * B[n][k]   (both operands K-contiguous)
+//
+// Tile 128x128x64, 256 threads = 4 waves in 2x2, each wave 64x64 as 2x2 v_mfma_f32_32x32x16_bf16.
+// The MFMA is issued with SWAPPED operands (A_op <- B rows, B_op <- A rows) so a lane ends up with
+// 4 consecutive n for a fixed m: row-major bf16 stores are 8 bytes wide instead of 2.
+//   acc[tm][tn][r] = D[m = m_w + tm*32 + (lane&31)][n = n_w + tn*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
+//
+// LDS image of a [128 rows][64 k] bf16 operand tile: 128-byte rows, 16-byte chunk kc of row `row`
+// lives at  row*128 + ((kc ^ ((row>>1)&7)) << 4)  -> conflict-free ds_read_b128 for the 32x32x16
+// fragment pattern (rows distinct mod 16 inside every b128 lane group).
+// STAGE=1 fills that image with global_load_lds (LDS destination lane-linear, swizzle applied on the
+// per-lane SOURCE address); STAGE=0 stages through registers (global_load_dwordx4 + ds_write_b128).
+#pragma once
+#include "common.hpp"
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+#define GEMM_THREADS 256
+#define GEMM_LDS_BYTES (2 * 2 * GEMM_BM * GEMM_BK * 2)  // 2 buffers x (A,B) x 16 KiB
+
+struct GemmShape {
+  const bf16_t* A; const bf16_t* B;
+  int M, N, K;
+  long lda, ldb;
+};
+
+__device__ __forceinline__ uint32_t gemm_lds_off(int row, int kc) {
+  return (uint32_t)(row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+}
+
+template <int STAGE, class Epi>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (g.N + GEMM_BN - 1) / GEMM_BN;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP = 8;
+  const int group_size = GROUP * tiles_n;
+  const int first_m = (id / group_size) * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tile_m = first_m + (id % group_size) % gsz;
+  const int tile_n = (id % group_size) / gsz;
+  const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
+
+  auto As = [&](int buf) -> uint8_t* { return smem + buf * 32768; };
+  auto Bs = [&](int buf) -> uint8_t* { return smem + 16384 + buf * 32768; };
+
+  // ---- staging addresses (4 x 16-byte chunks of A and of B per thread per K tile) ----
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+  uint32_t st_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row, kc;
+    if (STAGE == 1) {
+      row = wave * 32 + i * 8 + (lane >> 3);
+      const int slot = lane & 7;
+      kc = slot ^ ((row >> 1) & 7);
+      st_off[i] = (uint32_t)((wave * 4 + i) * 1024);  // wave-uniform LDS base of this DMA piece
+    } else {
+      const int c = tid + i * 256;
+      row = c >> 3;
+      kc = c & 7;
+      st_off[i] = gemm_lds_off(row, kc);
+    }
+    const int ra = min(m0 + row, g.M - 1), rb = min(n0 + row, g.N - 1);
+    a_src[i] = g.A + (long)ra * g.lda + kc * 8;
+    b_src[i] = g.B + (long)rb * g.ldb + kc * 8;
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = g.K / GEMM_BK;
+  u32x4_t ra_[4], rb_[4];
+
+  auto issue = [&](int t, int buf) {
+    const long koff = (long)t * GEMM_BK;
+    if (STAGE == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
+                                         (__attribute__((address_space(3))) void*)(As(buf) + st_off[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + koff),
+                                         (__attribute__((address_space(3))) void*)(Bs(buf) + st_off[i]), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra_[i] = *(const u32x4_t*)(a_src[i] + koff);
+        rb_[i] = *(const u32x4_t*)(b_src[i] + koff);
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+    if (STAGE == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(u32x4_t*)(As(buf) + st_off[i]) = ra_[i];
+        *(u32x4_t*)(Bs(buf) + st_off[i]) = rb_[i];
+      }
+    }
+  };
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kc = ks * 2 + fhalf;
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = *(const bf16x8_t*)(As(buf) + gemm_lds_off(wm * 64 + t * 32 + frow, kc));
+        bfr[t] = *(const bf16x8_t*)(Bs(buf) + gemm_lds_off(wn * 64 + t * 32 + frow, kc));
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[tn], af[tm], acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  commit(0);
+  if (STAGE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    // unconditional (clamped) prefetch: a branch here makes hipcc keep the staging registers in scratch
+    issue(min(t + 1, nt - 1), cur ^ 1);
+    compute(cur);
+    commit(cur ^ 1);
+    if (STAGE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  epi.apply(acc, m0 + wm * 64, n0 + wn * 64, lane, g.M, g.N);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogues.  apply() receives the wave's 64x64 accumulators and its tile origin.
+// ---------------------------------------------------------------------------------------------
+
+enum { RV_ACT_NONE = 0, RV_ACT_QUICK_GELU = 1, RV_ACT_GELU = 2 };
+
+// C[m][n] = act(acc + bias[n]) + R[m][n]   (bf16 out; bias/R optional)
+struct EpiStore {
+  bf16_t* C; long ldc;
+  const bf16_t* bias;
+  const bf16_t* R; long ldr;
+  int act;
+  float alpha;
+  __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = mw + tm * 32 + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int n = nw + tn * 32 + rg * 8 + 4 * (lane >> 5);
+          if (n >= N) continue;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[tm][tn][rg * 4 + j] * alpha;
+          if (bias) {
+            const uint2 bb = *(const uint2*)(bias + n);
+            v[0] += bf2f((bf16_t)(bb.x & 0xffff)); v[1] += bf2f((bf16_t)(bb.x >> 16));
+            v[2] += bf2f((bf16_t)(bb.y & 0xffff)); v[3] += bf2f((bf16_t)(bb.y >> 16));
+          }
+          if (act == RV_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
+          } else if (act == RV_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+          }
+          if (R) {
+            const uint2 rr = *(const uint2*)(R + (long)m * ldr + n);
+            v[0] += bf2f((bf16_t)(rr.x & 0xffff)); v[1] += bf2f((bf16_t)(rr.x >> 16));
+            v[2] += bf2f((bf16_t)(rr.y & 0xffff)); v[3] += bf2f((bf16_t)(rr.y >> 16));
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *(uint2*)(C + (long)m * ldc + n) = o;
+        }
+      }
+    }
+  }
+};
+
+// fp32 output (used where a downstream reduction wants full precision).
+struct EpiStoreF32 {
+  float* C; long ldc;
+  __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = mw + tm * 32 + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int n = nw + tn * 32 + rg * 8 + 4 * (lane >> 5);
+          if (n >= N) continue;
+          float4 o = make_float4(acc[tm][tn][rg * 4], acc[tm][tn][rg * 4 + 1], acc[tm][tn][rg * 4 + 2],
+                                 acc[tm][tn][rg * 4 + 3]);
+          *(float4*)(C + (long)m * ldc + n) = o;
+        }
+    }
+  }
+};
+
+// Fused LM head, forward: logits never reach HBM.  Per (row, 64-column block) write the running
+// (max, sum exp(x - max)) pair and, in the one block whose columns contain the target id, the
+// target logit.  Requires N % 64 == 0.
+struct EpiLogpFwd {
+  const int* tgt;      // [M] target vocabulary id per selected row
+  float* pmax;         // [M][N/64]
+  float* psum;         // [M][N/64]
+  float* tgt_logit;    // [M]
+  __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+    const int nblk = N >> 6;
+    if (nw >= N) return;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = mw + tm * 32 + (lane & 31);
+      const bool ok = m < M;
+      const int t = ok ? tgt[m] : -1;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[tm][tn][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float s = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s += __expf(acc[tm][tn][r] - mx);
+          const int n = nw + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (ok && n == t) tgt_logit[m] = acc[tm][tn][r];
+        }
+      s += __shfl_xor(s, 32, 64);
+      if (ok && (lane >> 5) == 0) {
+        pmax[(long)m * nblk + (nw >> 6)] = mx;
+        psum[(long)m * nblk + (nw >> 6)] = s;
+      }
+    }
+  }
+};
+
+// Fused LM head, backward: recompute the logits tile and emit
+//   dlogits[m][n] = coef[m] * ((n == tgt[m]) - exp(logit - lse[m]))      (bf16)
+struct EpiLogpBwd {
+  const int* tgt; const float* lse; const float* coef;
+  bf16_t* dlogits; long ldd;
+  __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = mw + tm * 32 + (lane & 31);
+      if (m >= M) continue;
+      const int t = tgt[m];
+      const float l = lse[m], c = coef[m];
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int n = nw + tn * 32 + rg * 8 + 4 * (lane >> 5);
+          if (n >= N) continue;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p = __expf(acc[tm][tn][rg * 4 + j] - l);
+            v[j] = c * (((n + j) == t ? 1.f : 0.f) - p);
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *(uint2*)(dlogits + (long)m * ldd + n) = o;
+        }
+    }
+  }
+};

@@ -1,0 +1,313 @@
+"""Thin tensor-level wrappers over the C ABI (rlaif_v_amd.hip).  torch is used only for device
+memory and streams; every FLOP / byte moved below runs in a hand-written gfx950 kernel.
+
+All matrices are 2-D row-major views with unit column stride (``ld = stride(0)``) so callers can pass
+column slices of fused buffers (q/k/v inside qkv, gate/up inside gu) without copies.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2
+
+
+def _chk2d(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != BF16 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a 2-D bf16 CUDA tensor with unit column stride, got "
+                         f"{tuple(t.shape)} {t.dtype} strides {t.stride()} on {t.device}")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------- GEMM
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0,
+            variant: int = -1) -> torch.Tensor:
+    """out[m][n] = act(alpha * sum_k a[m][k] b[n][k] + bias[n]) + residual[m][n]."""
+    _chk2d(a, "a"), _chk2d(b, "b")
+    M, K = a.shape
+    N, Kb = b.shape
+    if K != Kb:
+        raise ValueError(f"gemm_nt: K mismatch {K} vs {Kb}")
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    if residual is not None:
+        _chk2d(residual, "residual")
+    hip.call("rv_gemm_nt_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, K, bias, residual,
+             residual.stride(0) if residual is not None else 0, act, float(alpha), variant)
+    return out
+
+
+def gemm_nt_f32(a, b, variant: int = -1) -> torch.Tensor:
+    _chk2d(a, "a"), _chk2d(b, "b")
+    out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+    hip.call("rv_gemm_nt_bf16_f32out", a, a.stride(0), b, b.stride(0), out, out.stride(0), a.shape[0], b.shape[0],
+             a.shape[1], variant)
+    return out
+
+
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[R, C] -> [C, roundup(R, 64)] (zero padded columns): the K-contiguous operand of a wgrad GEMM."""
+    _chk2d(x, "x")
+    R, C = x.shape
+    Rp = round_up(R, 64)
+    if out is None:
+        out = torch.empty(C, Rp, dtype=BF16, device=x.device)
+    hip.call("rv_transpose", x, x.stride(0), out, out.stride(0), R, C)
+    return out
+
+
+# ------------------------------------------------------------------------------------- norms etc.
+def rmsnorm_fwd(x, w, eps: float, row_idx: Optional[torch.Tensor] = None, out=None, want_rstd: bool = True):
+    _chk2d(x, "x")
+    rows = x.shape[0] if row_idx is None else row_idx.numel()
+    d = x.shape[1]
+    if out is None:
+        out = torch.empty(rows, d, dtype=BF16, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_rstd else None
+    hip.call("rv_rmsnorm_fwd", x, x.stride(0), row_idx, w, out, out.stride(0), rstd, rows, d, float(eps))
+    return out, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dw: torch.Tensor, dres: Optional[torch.Tensor] = None,
+                row_idx: Optional[torch.Tensor] = None, dx: Optional[torch.Tensor] = None,
+                dw_accumulate: bool = False) -> torch.Tensor:
+    """dx (same row indexing as x) = rmsnorm backward (+ dres); dw (bf16 [d]) written or accumulated."""
+    _chk2d(dy, "dy"), _chk2d(x, "x")
+    rows, d = dy.shape
+    if dx is None:
+        dx = torch.empty_like(x) if row_idx is None else torch.zeros_like(x)
+    nb = hip.lib().lib.rv_rmsnorm_bwd_nblocks(rows)
+    partial = torch.empty(nb, d, dtype=torch.float32, device=x.device)
+    hip.call("rv_rmsnorm_bwd", dy, dy.stride(0), x, x.stride(0), row_idx, w, rstd, dres,
+             dres.stride(0) if dres is not None else 0, dx, dx.stride(0), partial, dw, int(dw_accumulate), rows, d)
+    return dx
+
+
+def layernorm_fwd(x, w, b, eps: float, out=None):
+    _chk2d(x, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    hip.call("rv_layernorm_fwd", x, x.stride(0), w, b, out, out.stride(0), x.shape[0], x.shape[1], float(eps))
+    return out
+
+
+def rope_tables(L: int, hd: int, theta: float, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp32 cos/sin [L, hd/2] exactly as HF LlamaRotaryEmbedding computes them (fp32, before any cast)."""
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None, :]
+    return fr.cos().contiguous().to(device), fr.sin().contiguous().to(device)
+
+
+def rope_inplace(x: torch.Tensor, cos, sin, L: int, n_heads_total: int, hd: int, backward: bool = False):
+    _chk2d(x, "x")
+    hip.call("rv_rope_inplace", x, x.stride(0), cos, sin, x.shape[0], L, n_heads_total, hd, int(backward))
+    return x
+
+
+def swiglu_fwd(gu: torch.Tensor, out=None):
+    _chk2d(gu, "gu")
+    rows, f2 = gu.shape
+    f = f2 // 2
+    if out is None:
+        out = torch.empty(rows, f, dtype=BF16, device=gu.device)
+    hip.call("rv_swiglu_fwd", gu, gu.stride(0), out, out.stride(0), rows, f)
+    return out
+
+
+def swiglu_bwd(dact, gu, out=None):
+    rows, f2 = gu.shape
+    if out is None:
+        out = torch.empty_like(gu)
+    hip.call("rv_swiglu_bwd", dact, dact.stride(0), gu, gu.stride(0), out, out.stride(0), rows, f2 // 2)
+    return out
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    hip.call("rv_gelu_fwd", x, y, x.numel())
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    hip.call("rv_gelu_bwd", dy, x, dx, x.numel())
+    return dx
+
+
+# ------------------------------------------------------------------------------------- attention
+def head_transpose(x: torch.Tensor, col0: int, S: int, L: int, H: int, hd: int, out=None) -> torch.Tensor:
+    _chk2d(x, "x")
+    Lp = round_up(L, 64)
+    if out is None:
+        out = torch.empty(S, H, hd, Lp, dtype=BF16, device=x.device)
+    hip.call("rv_head_transpose", x, x.stride(0), col0, out, S, L, H, hd)
+    return out
+
+
+def attn_fwd(qkv: torch.Tensor, S: int, L: int, H: int, hd: int, causal: bool, q_col0: int, k_col0: int,
+             v_col0: int, out: Optional[torch.Tensor] = None, vt: Optional[torch.Tensor] = None):
+    """Returns (out [S*L, H*hd], lse [S,H,L])."""
+    _chk2d(qkv, "qkv")
+    if vt is None:
+        vt = head_transpose(qkv, v_col0, S, L, H, hd)
+    if out is None:
+        out = torch.empty(S * L, H * hd, dtype=BF16, device=qkv.device)
+    lse = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
+    hip.call("rv_attn_fwd", qkv, qkv.stride(0), q_col0, k_col0, vt, out, out.stride(0), lse, S, L, H, hd,
+             int(causal), 1.0 / math.sqrt(hd))
+    return out, lse
+
+
+def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv: Optional[torch.Tensor] = None):
+    """Returns dqkv with dQ/dK/dV written at the qkv column offsets."""
+    _chk2d(qkv, "qkv"), _chk2d(o, "o"), _chk2d(do, "do")
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    delta = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
+    hip.call("rv_attn_delta", do, do.stride(0), o, o.stride(0), delta, S, L, H, hd)
+    qt = head_transpose(qkv, q_col0, S, L, H, hd)
+    kt = head_transpose(qkv, k_col0, S, L, H, hd)
+    dot = head_transpose(do, 0, S, L, H, hd)
+    hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, qt, kt, do, do.stride(0), dot, lse, delta,
+             dqkv, dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd))
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------- LM head / loss
+def lmhead_logp_fwd(h: torch.Tensor, w: torch.Tensor, tgt: torch.Tensor, n_rows: int):
+    """h: [rows_padded, d] (rows >= n_rows), w: [V, d], tgt int32 [n_rows] -> (logp, lse) fp32 [n_rows]."""
+    _chk2d(h, "h"), _chk2d(w, "w")
+    V = w.shape[0]
+    nblk = V // 64
+    dev = h.device
+    pmax = torch.empty(n_rows, nblk, dtype=torch.float32, device=dev)
+    psum = torch.empty(n_rows, nblk, dtype=torch.float32, device=dev)
+    tl = torch.zeros(n_rows, dtype=torch.float32, device=dev)
+    lse = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    logp = torch.empty(n_rows, dtype=torch.float32, device=dev)
+    hip.call("rv_lmhead_logp_fwd", h, h.stride(0), w, w.stride(0), tgt, n_rows, V, h.shape[1], pmax, psum, tl, -1)
+    hip.call("rv_logp_finish", pmax, psum, tl, nblk, n_rows, lse, logp)
+    return logp, lse
+
+
+def lmhead_logp_bwd(h, w, tgt, lse, coef, n_rows: int, out: Optional[torch.Tensor] = None):
+    """dlogits bf16 [rows_padded, V]; rows >= n_rows are zero."""
+    V = w.shape[0]
+    if out is None:
+        out = torch.zeros(h.shape[0], V, dtype=BF16, device=h.device)
+    hip.call("rv_lmhead_logp_bwd", h, h.stride(0), w, w.stride(0), tgt, lse, coef, out, out.stride(0), n_rows, V,
+             h.shape[1], -1)
+    return out
+
+
+def seq_sum(logp, seq_off, n_seq: int, weight=None):
+    s = torch.empty(n_seq, dtype=torch.float32, device=logp.device)
+    c = torch.empty(n_seq, dtype=torch.float32, device=logp.device)
+    hip.call("rv_seq_sum", logp, weight, seq_off, n_seq, s, c)
+    return s, c
+
+
+def dpo_loss(seq_sum_t, seq_cnt_t, ref_win, ref_rej, beta: float, use_average: bool, sft_weight: float,
+             dpo_weight: float):
+    B = ref_win.numel()
+    dev = ref_win.device
+    per_pair = torch.empty(5, B, dtype=torch.float32, device=dev)
+    scalars = torch.empty(8, dtype=torch.float32, device=dev)
+    coef = torch.empty(2 * B, dtype=torch.float32, device=dev)
+    hip.call("rv_dpo_loss", seq_sum_t, seq_cnt_t, ref_win, ref_rej, B, float(beta), int(use_average),
+             float(sft_weight), float(dpo_weight), per_pair, scalars, coef)
+    return per_pair, scalars, coef
+
+
+def row_coef(coef, seq_of_row, weight=None):
+    n = seq_of_row.numel()
+    out = torch.empty(n, dtype=torch.float32, device=coef.device)
+    hip.call("rv_row_coef", coef, seq_of_row, weight, out, n)
+    return out
+
+
+# ------------------------------------------------------------------------------------- data movement
+def splice_fwd(src: torch.Tensor, embed: torch.Tensor, feats: torch.Tensor, d: int):
+    out = torch.empty(src.numel(), d, dtype=BF16, device=embed.device)
+    hip.call("rv_splice_fwd", src, embed, feats, out, src.numel(), d)
+    return out
+
+
+def embed_bwd(uniq_ids, seg_off, pos_sorted, dx, dW):
+    hip.call("rv_embed_bwd", uniq_ids, seg_off, pos_sorted, uniq_ids.numel(), dx, dW, dx.shape[1])
+    return dW
+
+
+def feat_grad(src_a, src_b, dx, d: int):
+    out = torch.empty(src_a.numel(), d, dtype=BF16, device=dx.device)
+    hip.call("rv_feat_grad", src_a, src_b, dx, out, src_a.numel(), d)
+    return out
+
+
+def gather_rows(x, idx, out=None):
+    _chk2d(x, "x")
+    if out is None:
+        out = torch.empty(idx.numel(), x.shape[1], dtype=BF16, device=x.device)
+    hip.call("rv_gather_rows", x, x.stride(0), idx, out, out.stride(0), idx.numel(), x.shape[1], 0)
+    return out
+
+
+def scatter_rows(x, idx, out):
+    hip.call("rv_gather_rows", x, x.stride(0), idx, out, out.stride(0), idx.numel(), x.shape[1], 1)
+    return out
+
+
+def colsum(dy, out=None):
+    _chk2d(dy, "dy")
+    if out is None:
+        out = torch.empty(dy.shape[1], dtype=BF16, device=dy.device)
+    hip.call("rv_colsum", dy, dy.stride(0), out, dy.shape[0], dy.shape[1])
+    return out
+
+
+def im2col_patches(pixels: torch.Tensor, patch: int, Kp: int):
+    B, _, H, _ = pixels.shape
+    P = (H // patch) ** 2
+    out = torch.empty(B * P, Kp, dtype=BF16, device=pixels.device)
+    hip.call("rv_im2col_patches", pixels, out, B, H, patch, Kp)
+    return out
+
+
+def clip_assemble(patch_emb, cls, pos, B: int, P: int):
+    d = patch_emb.shape[1]
+    out = torch.empty(B * (P + 1), d, dtype=BF16, device=patch_emb.device)
+    hip.call("rv_clip_assemble", patch_emb, cls, pos, out, B, P, d)
+    return out
+
+
+def cast_f32_to_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    hip.call("rv_cast_f32_to_bf16", x, out, x.numel())
+    return out
+
+
+# ------------------------------------------------------------------------------------- optimizer
+def grad_norm(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = None):
+    """out2 = [||g||, clip coefficient] on device (no host sync)."""
+    nb = hip.lib().lib.rv_sumsq_nblocks()
+    partial = torch.empty(nb, dtype=torch.float32, device=g.device)
+    if out2 is None:
+        out2 = torch.empty(2, dtype=torch.float32, device=g.device)
+    hip.call("rv_grad_norm", g, g.numel(), partial, float(max_norm), out2)
+    return out2
+
+
+def adamw_step(p, master, m, v, g, lr, beta1, beta2, eps, wd, step: int, clip: Optional[torch.Tensor] = None):
+    hip.call("rv_adamw_step", p, master, m, v, g, p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+             float(wd), int(step), clip)

@@ -1,0 +1,430 @@
+"""Per-kernel numerics: every HIP kernel of librlaifv_hip.so against a plain PyTorch fp32 reference of
+the same op (inputs rounded to bf16 first so both sides see identical values).  Runs on the MI355X box:
+    python -m pytest tests -m gpu -q
+All calls go through the C ABI (rlaif_v_amd.ops -> rlaif_v_amd.hip -> ctypes)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0, dev=None):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(dev)
+
+
+def close(got, ref, rel=1.6e-2, what=""):
+    got = got.float()
+    ref = ref.float()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs().max().item()
+    mag = ref.abs().max().item()
+    assert err <= rel * mag + 1e-6, f"{what}: max err {err:.4e} vs max |ref| {mag:.4e}"
+    # mean error must be far below the max bound (catches a wrong row/column hiding under a loose max)
+    merr = (got - ref).abs().mean().item()
+    mmag = ref.abs().mean().item()
+    assert merr <= 0.5 * rel * mmag + 1e-7, f"{what}: mean err {merr:.4e} vs mean |ref| {mmag:.4e}"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    _dev()
+    from rlaif_v_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 132, 192), (1000, 520, 1024), (7, 4, 64)])
+def test_gemm_nt(ops, variant, M, N, K):
+    dev = _dev()
+    a = rnd(M, K, seed=1, dev=dev)
+    b = rnd(N, K, seed=2, dev=dev)
+    out = ops.gemm_nt(a, b, variant=variant)
+    close(out, a.float() @ b.float().t(), what=f"gemm v{variant} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_identity_asymmetric(ops, variant):
+    """A = I with an asymmetric B catches transposed / permuted output tiles exactly."""
+    dev = _dev()
+    K = 256
+    a = torch.eye(K, dtype=BF, device=dev)
+    b = (torch.arange(384 * K, device=dev).reshape(384, K) % 251).to(BF)
+    out = ops.gemm_nt(a, b, variant=variant)           # out[m][n] = b[n][m]
+    assert torch.equal(out, b.t().contiguous())
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_epilogues(ops, variant, act):
+    dev = _dev()
+    M, N, K = 300, 256, 320
+    a, b = rnd(M, K, seed=3, dev=dev, scale=0.5), rnd(N, K, seed=4, dev=dev, scale=0.5)
+    bias, res = rnd(N, seed=5, dev=dev), rnd(M, N, seed=6, dev=dev)
+    out = ops.gemm_nt(a, b, bias=bias, residual=res, act=act, alpha=0.5, variant=variant)
+    z = 0.5 * (a.float() @ b.float().t()) + bias.float()
+    if act == 1:
+        z = z * torch.sigmoid(1.702 * z)
+    elif act == 2:
+        z = F.gelu(z)
+    close(out, z + res.float(), what=f"gemm epilogue act={act}")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_strided_views(ops, variant):
+    dev = _dev()
+    big_a, big_b = rnd(130, 512, seed=7, dev=dev), rnd(96, 448, seed=8, dev=dev)
+    a, b = big_a[:, 128:384], big_b[:, 64:320]          # K = 256 windows, ld > K
+    outbuf = torch.zeros(130, 200, dtype=BF, device=dev)
+    out = outbuf[:, 8:104]
+    ops.gemm_nt(a, b, out=out, variant=variant)
+    close(out, a.float() @ b.float().t(), what="gemm strided")
+    assert outbuf[:, :8].abs().sum() == 0 and outbuf[:, 104:].abs().sum() == 0
+
+
+def test_gemm_f32_out(ops):
+    dev = _dev()
+    a, b = rnd(190, 128, seed=9, dev=dev), rnd(260, 128, seed=10, dev=dev)
+    out = ops.gemm_nt_f32(a, b)
+    torch.testing.assert_close(out, a.float() @ b.float().t(), rtol=1e-4, atol=1e-3)
+
+
+def test_transpose(ops):
+    dev = _dev()
+    for R, C in [(64, 64), (100, 72), (577, 128), (1, 8), (130, 200)]:
+        x = rnd(R, C, seed=R + C, dev=dev)
+        t = ops.transpose(x)
+        assert t.shape == (C, ops.round_up(R, 64))
+        assert torch.equal(t[:, :R], x.t())
+        assert t[:, R:].abs().sum() == 0
+
+
+# ------------------------------------------------------------------------------------------- norms
+def test_rmsnorm_fwd_bwd(ops):
+    dev = _dev()
+    rows, d = 333, 512
+    x, w, dy, dres = rnd(rows, d, seed=1, dev=dev), (1 + 0.1 * rnd(d, seed=2, dev=dev).float()).to(BF), \
+        rnd(rows, d, seed=3, dev=dev), rnd(rows, d, seed=4, dev=dev)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    ref = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+    close(y, ref.detach(), what="rmsnorm fwd")
+    torch.testing.assert_close(rstd, torch.rsqrt(x.float().pow(2).mean(-1) + 1e-5), rtol=1e-5, atol=1e-6)
+    ref.backward(dy.float())
+    dw = torch.zeros(d, dtype=BF, device=dev)
+    dx = ops.rmsnorm_bwd(dy, x, w, rstd, dw, dres=dres)
+    close(dx, xf.grad + dres.float(), what="rmsnorm dx")
+    close(dw, wf.grad, rel=2e-2, what="rmsnorm dw")
+    # accumulate flag adds onto the existing dw
+    dw2 = dw.clone()
+    ops.rmsnorm_bwd(dy, x, w, rstd, dw2, dw_accumulate=True)
+    close(dw2, 2 * wf.grad, rel=3e-2, what="rmsnorm dw accumulate")
+
+
+def test_rmsnorm_row_gather_scatter(ops):
+    dev = _dev()
+    rows, d = 64, 256
+    x, w = rnd(rows, d, seed=1, dev=dev), rnd(d, seed=2, dev=dev)
+    idx = torch.tensor([3, 60, 7, 8, 21], dtype=torch.int32, device=dev)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-5, row_idx=idx)
+    xs = x[idx.long()].float()
+    close(y, w.float() * xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-5), what="rmsnorm gather")
+    dy = rnd(5, d, seed=3, dev=dev)
+    dw = torch.zeros(d, dtype=BF, device=dev)
+    dx = ops.rmsnorm_bwd(dy, x, w, rstd, dw, row_idx=idx)
+    xf = x.float().requires_grad_(True)
+    sel = xf[idx.long()]
+    (w.float() * sel * torch.rsqrt(sel.pow(2).mean(-1, keepdim=True) + 1e-5)).backward(dy.float())
+    close(dx, xf.grad, what="rmsnorm scatter dx")
+
+
+def test_layernorm(ops):
+    dev = _dev()
+    x, w, b = rnd(577, 1024, seed=1, dev=dev), rnd(1024, seed=2, dev=dev), rnd(1024, seed=3, dev=dev)
+    close(ops.layernorm_fwd(x, w, b, 1e-5), F.layer_norm(x.float(), (1024,), w.float(), b.float(), 1e-5), what="ln")
+
+
+def _rope_ref(x, L, H, hd, theta, inverse=False):
+    n = x.shape[0]
+    xf = x.float().view(n, H, hd)
+    pos = torch.arange(n, device=x.device) % L
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32, device=x.device) / hd))
+    fr = pos[:, None].float() * inv[None]
+    cos, sin = torch.cat([fr, fr], -1).cos()[:, None], torch.cat([fr, fr], -1).sin()[:, None]
+    if inverse:
+        sin = -sin
+    rot = torch.cat([-xf[..., hd // 2:], xf[..., :hd // 2]], -1)
+    return (xf * cos + rot * sin).view(n, H * hd)
+
+
+def test_rope(ops):
+    dev = _dev()
+    S, L, H, hd = 3, 37, 4, 128
+    buf = rnd(S * L, 3 * H * hd, seed=1, dev=dev)
+    orig = buf.clone()
+    cos, sin = ops.rope_tables(L, hd, 10000.0, dev)
+    ops.rope_inplace(buf, cos, sin, L, 2 * H, hd)
+    close(buf[:, :2 * H * hd], _rope_ref(orig[:, :2 * H * hd], L, 2 * H, hd, 10000.0), what="rope fwd")
+    assert torch.equal(buf[:, 2 * H * hd:], orig[:, 2 * H * hd:])      # v untouched
+    ops.rope_inplace(buf, cos, sin, L, 2 * H, hd, backward=True)
+    close(buf, orig, rel=2e-2, what="rope inverse")
+
+
+def test_swiglu_gelu(ops):
+    dev = _dev()
+    rows, f = 77, 264
+    gu, da = rnd(rows, 2 * f, seed=1, dev=dev), rnd(rows, f, seed=2, dev=dev)
+    guf = gu.float().requires_grad_(True)
+    ref = F.silu(guf[:, :f]) * guf[:, f:]
+    close(ops.swiglu_fwd(gu), ref.detach(), what="swiglu fwd")
+    ref.backward(da.float())
+    close(ops.swiglu_bwd(da, gu), guf.grad, what="swiglu bwd")
+    x, dy = rnd(40, 256, seed=3, dev=dev), rnd(40, 256, seed=4, dev=dev)
+    xf = x.float().requires_grad_(True)
+    r = F.gelu(xf)
+    close(ops.gelu_fwd(x), r.detach(), what="gelu fwd")
+    r.backward(dy.float())
+    close(ops.gelu_bwd(dy, x), xf.grad, what="gelu bwd")
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _perm16(L, Lp, dev):
+    p = torch.arange(Lp, device=dev)
+    return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+def test_head_transpose(ops, hd):
+    dev = _dev()
+    S, L, H = 2, 75, 3
+    x = rnd(S * L, 3 * H * hd + 8, seed=hd, dev=dev)
+    col0 = H * hd
+    t = ops.head_transpose(x, col0, S, L, H, hd)
+    Lp = ops.round_up(L, 64)
+    assert t.shape == (S, H, hd, Lp)
+    src = torch.zeros(S, Lp, H, hd, dtype=BF, device=dev)
+    src[:, :L] = x[:, col0:col0 + H * hd].reshape(S, L, H, hd)
+    tok = _perm16(L, Lp, dev)
+    ref = src[:, tok].permute(0, 2, 3, 1)       # [S,H,hd,pos] = X[s, tok(pos), h, e]
+    assert torch.equal(t, ref.contiguous())
+
+
+def _attn_ref(q, k, v, causal):
+    """q,k,v fp32 [S,H,L,hd] -> (out, lse)"""
+    hd = q.shape[-1]
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if causal:
+        L = q.shape[2]
+        s = s + torch.full((L, L), float("-inf"), device=q.device).triu(1)
+    return torch.softmax(s, -1) @ v, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("hd,causal,L", [(128, True, 200), (128, True, 64), (128, False, 130), (64, False, 577),
+                                         (64, True, 33), (128, True, 1)])
+def test_attn_fwd(ops, hd, causal, L):
+    dev = _dev()
+    S, H = 2, 3
+    qkv = rnd(S * L, 3 * H * hd, seed=L + hd, dev=dev)
+    out, lse = ops.attn_fwd(qkv, S, L, H, hd, causal, 0, H * hd, 2 * H * hd)
+    q, k, v = [qkv[:, i * H * hd:(i + 1) * H * hd].float().view(S, L, H, hd).transpose(1, 2) for i in range(3)]
+    ro, rl = _attn_ref(q, k, v, causal)
+    close(out, ro.transpose(1, 2).reshape(S * L, H * hd), rel=2e-2, what=f"attn fwd hd{hd} L{L}")
+    torch.testing.assert_close(lse, rl, rtol=1e-3, atol=2e-3)
+
+
+def test_attn_fwd_online_softmax_rescale(ops):
+    """One key far down the sequence dominates: forces the running-max rescale branch."""
+    dev = _dev()
+    S, H, L, hd = 1, 1, 256, 128
+    qkv = rnd(S * L, 3 * hd, seed=5, dev=dev, scale=0.3)
+    qkv[200, hd:2 * hd] = 6.0 * qkv[255, :hd].sign()      # key 200 aligned with query 255
+    qkv[255, :hd] = qkv[255, :hd].sign() * 1.0
+    out, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, hd, 2 * hd)
+    q, k, v = [qkv[:, i * hd:(i + 1) * hd].float().view(S, L, H, hd).transpose(1, 2) for i in range(3)]
+    ro, rl = _attn_ref(q, k, v, True)
+    close(out, ro.transpose(1, 2).reshape(S * L, hd), rel=2e-2, what="attn rescale")
+    torch.testing.assert_close(lse, rl, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("causal,L", [(True, 200), (True, 128), (False, 97), (True, 1)])
+def test_attn_bwd(ops, causal, L):
+    dev = _dev()
+    S, H, hd = 2, 2, 128
+    qkv = rnd(S * L, 3 * H * hd, seed=L, dev=dev, scale=0.7)
+    do = rnd(S * L, H * hd, seed=L + 1, dev=dev)
+    out, lse = ops.attn_fwd(qkv, S, L, H, hd, causal, 0, H * hd, 2 * H * hd)
+    dqkv = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, causal, 0, H * hd, 2 * H * hd)
+    qf = qkv.float().requires_grad_(True)
+    q, k, v = [qf[:, i * H * hd:(i + 1) * H * hd].view(S, L, H, hd).transpose(1, 2) for i in range(3)]
+    ro, _ = _attn_ref(q, k, v, causal)
+    ro.transpose(1, 2).reshape(S * L, H * hd).backward(do.float())
+    for i, nm in enumerate("qkv"):
+        sl = slice(i * H * hd, (i + 1) * H * hd)
+        close(dqkv[:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"attn bwd d{nm} L{L} causal={causal}")
+
+
+# ------------------------------------------------------------------------------------------- LM head / loss
+def test_lmhead_logp_fwd_bwd(ops):
+    dev = _dev()
+    n, d, V = 150, 256, 512
+    npad = ops.round_up(n, 64)
+    h = torch.zeros(npad, d, dtype=BF, device=dev)
+    h[:n] = rnd(n, d, seed=1, dev=dev)
+    w = rnd(V, d, seed=2, dev=dev, scale=0.2)
+    tgt = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(3)).to(torch.int32).to(dev)
+    tgt[0], tgt[1] = 0, V - 1
+    logp, lse = ops.lmhead_logp_fwd(h, w, tgt, n)
+    hf = h[:n].float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    logits = hf @ wf.t()
+    ref_lp = logits.log_softmax(-1).gather(1, tgt.long()[:, None])[:, 0]
+    torch.testing.assert_close(lse, torch.logsumexp(logits, -1).detach(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(logp, ref_lp.detach(), rtol=1e-4, atol=1e-3)
+    coef = torch.randn(n, generator=torch.Generator().manual_seed(4)).to(dev)
+    dlog = ops.lmhead_logp_bwd(h, w, tgt, lse, coef, n)
+    (ref_lp * coef).sum().backward()
+    p = torch.softmax(logits.detach(), -1)
+    onehot = F.one_hot(tgt.long(), V).float()
+    close(dlog[:n], coef[:, None] * (onehot - p), rel=1e-2, what="dlogits")
+    assert dlog[n:].abs().sum() == 0
+    # the two GEMMs the model runs on dlogits reproduce autograd's dh and dW
+    dh = ops.gemm_nt(dlog, ops.transpose(w)[:, :V])           # [npad, d] = dlog @ w
+    close(dh[:n], hf.grad, rel=2e-2, what="lm head dh")
+    dW = ops.gemm_nt(ops.transpose(dlog), ops.transpose(h))   # [V, d] = dlog^T @ h
+    close(dW, wf.grad, rel=2e-2, what="lm head dW")
+
+
+def test_seq_sum_and_dpo_loss(ops):
+    dev = _dev()
+    from oracle import dpo_oracle as O
+    B = 5
+    g = torch.Generator().manual_seed(0)
+    lens = [7, 1, 12, 3, 9, 4, 0, 6, 2, 11]
+    import itertools
+    off = torch.tensor([0] + list(itertools.accumulate(lens)), dtype=torch.int32, device=dev)
+    logp = (-torch.rand(sum(lens), generator=g) * 5).to(dev)
+    s, c = ops.seq_sum(logp, off, 2 * B)
+    ref_s = torch.stack([logp[off[i]:off[i + 1]].sum() for i in range(2 * B)])
+    torch.testing.assert_close(s, ref_s, rtol=1e-6, atol=1e-5)
+    assert c.tolist() == [float(x) for x in lens]
+    ref_win = (-20 * torch.rand(B, generator=g)).to(dev)
+    ref_rej = (-20 * torch.rand(B, generator=g)).to(dev)
+    for use_avg, sft, dpo in [(False, 0.0, 1.0), (False, 0.3, 0.7)]:
+        per_pair, scal, coef = ops.dpo_loss(s, c, ref_win, ref_rej, 0.1, use_avg, sft, dpo)
+        sv = s.clone().requires_grad_(True)
+        pw, pr = sv[:B], sv[B:]
+        losses, cw, cr = O.dpo_loss(pw, pr, ref_win, ref_rej, 0.1)
+        loss = dpo * losses.mean() - sft * pw.mean()
+        loss.backward()
+        torch.testing.assert_close(per_pair[0], losses.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(per_pair[1], cw, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(per_pair[2], cr, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(scal[0], loss.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(scal[3], (cw > cr).float().mean(), rtol=0, atol=1e-6)
+        torch.testing.assert_close(coef, sv.grad, rtol=1e-4, atol=1e-7)
+    # average log-prob variant (dpo_use_average): row with zero targets gives NaN like the reference
+    cnt_ok = c.clone()
+    cnt_ok[6] = 1.0
+    per_pair, scal, coef = ops.dpo_loss(s, cnt_ok, ref_win, ref_rej, 0.1, True, 0.0, 1.0)
+    sv = s.clone().requires_grad_(True)
+    avg = sv / cnt_ok
+    losses, _, _ = O.dpo_loss(avg[:B], avg[B:], ref_win, ref_rej, 0.1)
+    losses.mean().backward()
+    torch.testing.assert_close(per_pair[0], losses.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(coef, sv.grad, rtol=1e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------- data movement
+def test_splice_and_grads(ops):
+    dev = _dev()
+    d, V, nfeat = 256, 50, 12
+    embed, feats = rnd(V, d, seed=1, dev=dev), rnd(nfeat, d, seed=2, dev=dev)
+    src = torch.tensor([3, 3, -2, -3, -13, -1, 49, 0, -1, 3], dtype=torch.int32, device=dev)
+    out = ops.splice_fwd(src, embed, feats, d)
+    for i, sidx in enumerate(src.tolist()):
+        exp = embed[sidx] if sidx >= 0 else (torch.zeros(d, dtype=BF, device=dev) if sidx == -1 else feats[-2 - sidx])
+        assert torch.equal(out[i], exp)
+    dx = rnd(10, d, seed=3, dev=dev)
+    # embedding backward: rows {3: [0,1,9], 49: [6], 0: [7]}
+    uniq = torch.tensor([0, 3, 49], dtype=torch.int32, device=dev)
+    seg = torch.tensor([0, 1, 4, 5], dtype=torch.int32, device=dev)
+    pos = torch.tensor([7, 0, 1, 9, 6], dtype=torch.int32, device=dev)
+    dW = torch.zeros(V, d, dtype=BF, device=dev)
+    ops.embed_bwd(uniq, seg, pos, dx, dW)
+    ref = torch.zeros(V, d, device=dev)
+    ref.index_add_(0, torch.tensor([3, 3, 49, 0, 3], device=dev), dx[[0, 1, 6, 7, 9]].float())
+    close(dW, ref, rel=1e-2, what="embed bwd")
+    a = torch.tensor([2, -1, 4], dtype=torch.int32, device=dev)
+    b = torch.tensor([3, -1, -1], dtype=torch.int32, device=dev)
+    fg = ops.feat_grad(a, b, dx, d)
+    close(fg[0], dx[2].float() + dx[3].float(), rel=1e-2, what="feat grad")
+    assert fg[1].abs().sum() == 0 and torch.equal(fg[2], dx[4])
+    idx = torch.tensor([9, 0, 4], dtype=torch.int32, device=dev)
+    gth = ops.gather_rows(dx, idx)
+    assert torch.equal(gth, dx[idx.long()])
+    sc = torch.zeros(10, d, dtype=BF, device=dev)
+    ops.scatter_rows(gth, idx, sc)
+    assert torch.equal(sc[idx.long()], gth)
+    mask = torch.ones(10, dtype=torch.bool, device=dev)
+    mask[idx.long()] = False
+    assert sc[mask].abs().sum() == 0
+    close(ops.colsum(dx), dx.float().sum(0), rel=1e-2, what="colsum")
+
+
+def test_clip_front_end(ops):
+    dev = _dev()
+    B, HW, ps, cd = 2, 56, 14, 128
+    px = torch.randn(B, 3, HW, HW, generator=torch.Generator().manual_seed(0)).to(dev)
+    Kp = ops.round_up(3 * ps * ps, 64)
+    cols = ops.im2col_patches(px, ps, Kp)
+    ref = F.unfold(px.to(BF).float(), ps, stride=ps).transpose(1, 2).reshape(B * 16, 3 * ps * ps)
+    assert torch.equal(cols[:, :588].float(), ref) and cols[:, 588:].abs().sum() == 0
+    wconv = rnd(cd, 3, ps, ps, seed=1, dev=dev, scale=0.05)
+    wpad = torch.zeros(cd, Kp, dtype=BF, device=dev)
+    wpad[:, :588] = wconv.reshape(cd, 588)
+    pe = ops.gemm_nt(cols, wpad)
+    conv = F.conv2d(px.to(BF).float(), wconv.float(), stride=ps).flatten(2).transpose(1, 2).reshape(B * 16, cd)
+    close(pe, conv, what="patch embed")
+    cls, pos = rnd(cd, seed=2, dev=dev), rnd(17, cd, seed=3, dev=dev)
+    x = ops.clip_assemble(pe, cls, pos, B, 16)
+    refx = torch.cat([cls.float().expand(B, 1, cd), pe.float().view(B, 16, cd)], 1) + pos.float()[None]
+    close(x, refx.reshape(B * 17, cd), rel=1e-2, what="clip assemble")
+
+
+# ------------------------------------------------------------------------------------------- optimizer
+def test_adamw_and_gradnorm(ops):
+    dev = _dev()
+    n = 8 * 1000
+    g = torch.Generator().manual_seed(0)
+    master = torch.randn(n, generator=g).to(dev)
+    p = master.to(BF)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    ref = torch.nn.Parameter(master.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for step in range(1, 4):
+        grad = (torch.randn(n, generator=g) * 3).to(BF).to(dev)
+        out2 = ops.grad_norm(grad, 1.0)
+        nrm = grad.float().norm()
+        torch.testing.assert_close(out2[0], nrm, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(out2[1], torch.clamp(1.0 / (nrm + 1e-6), max=1.0), rtol=1e-4, atol=1e-6)
+        ops.adamw_step(p, master, m, v, grad, 1e-2, 0.9, 0.999, 1e-8, 0.01, step, clip=out2)
+        ref.grad = grad.float().clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        torch.testing.assert_close(master, ref.detach(), rtol=2e-5, atol=2e-6)
+        assert torch.equal(p, master.to(BF))
