@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: preference-pairs/sec of one full DPO optimisation step (forward + backward +
+gradient all-reduce + clip + AdamW) of LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B) in bf16, spliced
+sequence length 2048, on N MI355X of one node (BASELINE.json configs[1] / configs[2]).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 5 --warmup 2
+
+Synthetic (image, chosen, rejected) triples and HF-default random-init weights (no datasets/checkpoints
+exist offline); inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flops_per_pair(L: int, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000) -> float:
+    """algorithmic FLOPs of one pair, full fine-tune, causal attention counted at
+    half, no recompute, CLIP once per pair (forward only) + projector (fwd+bwd)."""
+    per_tok_linear = layers * (8 * d * d + 6 * d * f) + 2 * d * V
+    per_tok_attn = layers * 2 * d * L
+    f_fwd_seq = L * (per_tok_linear + per_tok_attn)
+    return 3 * 2 * f_fwd_seq + 0.366e12 + 3 * 0.024e12
+
+
+class GemmTimer:
+    """HIP-event timing of every rv_gemm_nt_bf16 launch on the stream it is launched on."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from rlaif_v_amd import ops, hip
+        orig = ops.gemm_nt
+        recs = self.records
+
+        def timed(a, b, out=None, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(a, b, out=out, **kw)
+            e.record()
+            recs.append((s, e, 2.0 * a.shape[0] * b.shape[0] * a.shape[1]))
+            return r
+
+        ops.gemm_nt = timed
+        self._restore = lambda: setattr(ops, "gemm_nt", orig)
+
+    def summary(self):
+        tot_ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        tot_fl = sum(f for _, _, f in self.records)
+        n = len(self.records)
+        return dict(launches=n, total_ms=tot_ms, avg_ms=tot_ms / max(n, 1), tflops=tot_fl / max(tot_ms, 1e-9) / 1e9,
+                    flops=tot_fl)
+
+
+def cpu_baseline(L: int, seed: int = 0):
+    """The oracle (a port of the reference's step) timed on the host cores, on a bounded sample:
+    full-width LLaVA-1.5-7B shapes at reduced depth, ONE pair, one fwd+bwd+AdamW step; per-layer slopes
+    extrapolated linearly to 32 LLM / 23 CLIP layers (BASELINE.md section 2 method)."""
+    from oracle import dpo_oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, 128)
+    torch.set_num_threads(threads)
+    T = L - 575
+
+    def run(layers, clip_layers):
+        cfg = O.LlavaCfg(layers=layers, clip_layers=clip_layers, model_max_length=L)
+        W = O.make_weights(cfg, seed=seed, bf16_round=False)
+        batch = O.make_synthetic_batch(cfg, 1, T, 64, seed=seed, ragged=False)
+        t0 = time.time()
+        O.dpo_train_step(batch, W, cfg, {}, lr=5e-7, step=1, sft_weight=0.0, dpo_weight=1.0)
+        return time.time() - t0
+
+    t11 = run(1, 2)     # 1 LLM layer, 1 CLIP layer used (select_layer=-2)
+    t21 = run(2, 2)     # +1 LLM layer
+    t12 = run(1, 3)     # +1 CLIP layer
+    llm = max(t21 - t11, 1e-6)
+    clip = max(t12 - t11, 0.0)
+    fixed = max(t11 - llm - clip, 0.0)
+    # the reference encodes the image twice per pair (trainers.py:190); the port does the same
+    step = fixed + 32 * llm + 23 * clip
+    return dict(value=1.0 / step, unit="pairs/s", cores=threads, kind="port",
+                sample=(f"oracle/dpo_oracle.py fwd+bwd+AdamW, fp32, 1 pair, L={L}, full 7B widths at depth "
+                        f"(1,1),(2,1),(1,2) LLM/CLIP layers: {t11:.1f}s,{t21:.1f}s,{t12:.1f}s -> per-layer "
+                        f"{llm:.2f}s LLM, {clip:.2f}s CLIP, fixed {fixed:.2f}s; extrapolated to 32/23 layers = "
+                        f"{step:.1f}s per pair on {threads} threads of {cores} host cores"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs-per-gpu", type=int, default=4)
+    ap.add_argument("--seq-len", type=int, default=2048, help="spliced length L (text length = L - 575)")
+    ap.add_argument("--layers", type=int, default=32, help="debug only: anything but 32 is not the headline config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-timer", action="store_true")
+    args = ap.parse_args()
+
+    from rlaif_v_amd.dist import init_process_group_from_env, BucketedAllReduce
+    rank, local, world = init_process_group_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    from rlaif_v_amd.data import SyntheticPreferenceDataset, DataCollatorForDPODataset
+    import torch.distributed as dist
+
+    L, B = args.seq_len, args.pairs_per_gpu
+    cfg = LlavaConfig(layers=args.layers, model_max_length=L)
+    model = LlavaDPOModel(cfg, device=dev)
+    model.init_random(seed=0)            # identical weights on every rank
+    reducer = BucketedAllReduce(model.store.flat_g) if world > 1 else None
+    targs = TrainingArguments(max_steps=1000, per_device_train_batch_size=B)
+    trainer = LLaVA15DPOTrainer(model=model, args=targs, reducer=reducer)
+
+    class _Tok:
+        pad_token_id = cfg.pad_token_id
+    ds = SyntheticPreferenceDataset(n=B * world, vocab=cfg.vocab, text_len=L - (cfg.n_patches - 1), prompt_len=64,
+                                    image_size=cfg.image_size, seed=1234)
+    collate = DataCollatorForDPODataset(_Tok(), beta=0.1, mod_token_weight=1.0)
+    batch = collate([ds[rank * B + i] for i in range(B)])
+    batch["images"] = batch["images"].to(dev)       # inputs resident in HBM before the timed region
+
+    def one_step():
+        return trainer.training_step(dict(batch))
+
+    for _ in range(args.warmup):
+        one_step()
+    timer = GemmTimer()
+    if not args.no_gemm_timer:
+        timer.install()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        pairs_per_s = B * world * args.steps / dt
+        fp = flops_per_pair(L, layers=args.layers)
+        step_tflops_per_gpu = fp * (pairs_per_s / world) / 1e12
+        line = {
+            "metric": "preference-pairs/sec (DPO step) LLaVA-1.5-7B bf16", "value": pairs_per_s, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B) full-FT DPO step, 336px, "
+                                   f"seq_len={L}, {B} pairs/GPU, random-init weights",
+                       "pairs_per_gpu": B, "global_batch_pairs": B * world, "seq_len": L, "llm_layers": args.layers,
+                       "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0",
+                       "gradient_checkpointing": False},
+            "loss": float(loss),
+            "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / PEAK_BF16_TFLOPS,
+            "flops_per_pair": fp,
+        }
+        if not args.no_gemm_timer:
+            g = timer.summary()
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<glds,128x128x64> (all rv_gemm_nt_bf16 launches)",
+                                "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                                "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
+                                "gemm_ms_per_step": g["total_ms"] / args.steps}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(L)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,9 +120,12 @@ int rv_cast_f32_to_bf16(const float* in, void* out, long n, void* stream);
 int rv_cast_bf16_to_f32(const void* in, float* out, long n, void* stream);
 
 /* ---- optimizer (replaces torch.optim.AdamW + clip_grad_norm_ selected by optim="adamw_torch",
- *      muffin/train/train_llava15.py:75).  out2[0] = ||g||, out2[1] = min(1, max_norm/(||g||+1e-6)). */
+ *      muffin/train/train_llava15.py:75).  The buffer may hold a SUM over ranks: pre_scale = 1/world.
+ *      out2[0] = ||pre_scale*g||, out2[1] = pre_scale * min(1, max_norm/(out2[0]+1e-6)) = the factor
+ *      rv_adamw_step multiplies raw gradients by (pass out2 as `clip`; NULL = 1). */
 int rv_sumsq_nblocks(void);
-int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float* out2, void* stream);
+int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float pre_scale, float* out2,
+                 void* stream);
 int rv_adamw_step(void* p, float* master, float* m, float* v, const void* g, long n, float lr, float beta1, float beta2,
                   float eps, float wd, int step, const float* clip, void* stream);
 

@@ -466,18 +466,19 @@ __global__ void sumsq_kernel(const bf16_t* __restrict__ g, long n8, float* __res
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-// out[0] = ||g||, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0).
-// `extra_sq` (nullable) adds squared norms computed elsewhere (other ranks / buffers).
+// The buffer holds pre_scale^-1 times the true gradient (e.g. a SUM over ranks with pre_scale = 1/world).
+// out[0] = ||pre_scale * g||, out[1] = pre_scale * min(1, max_norm / (out[0] + 1e-6))  -> the factor AdamW
+// multiplies the raw buffer by (clip disabled when max_norm <= 0).
 __global__ void gradnorm_finish_kernel(const float* __restrict__ partial, int nparts, float max_norm,
-                                       float* __restrict__ out) {
+                                       float pre_scale, float* __restrict__ out) {
   __shared__ float red[16];
   float s = 0.f;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partial[i];
   s = block_sum(s, red);
   if (threadIdx.x == 0) {
-    const float nrm = sqrtf(s);
+    const float nrm = sqrtf(s) * pre_scale;
     out[0] = nrm;
-    out[1] = (max_norm > 0.f) ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f;
+    out[1] = pre_scale * ((max_norm > 0.f) ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f);
   }
 }
 
@@ -827,11 +828,12 @@ int rv_clip_assemble(const void* patch, const void* cls, const void* pos, void* 
 
 int rv_sumsq_nblocks(void) { return 1024; }
 
-int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float* out2, void* stream) {
+int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float pre_scale, float* out2, void* stream) {
   RV_REQUIRE(n % 8 == 0, "rv_grad_norm: n%8");
   hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, STREAM(stream), (const bf16_t*)g, n / 8, partial);
   RV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gradnorm_finish_kernel, dim3(1), dim3(256), 0, STREAM(stream), partial, 1024, max_norm, out2);
+  hipLaunchKernelGGL(gradnorm_finish_kernel, dim3(1), dim3(256), 0, STREAM(stream), partial, 1024, max_norm, pre_scale,
+                     out2);
   RV_CHECK_LAUNCH();
   return 0;
 }

@@ -298,13 +298,13 @@ def cast_f32_to_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None):
 
 
 # ------------------------------------------------------------------------------------- optimizer
-def grad_norm(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = None):
-    """out2 = [||g||, clip coefficient] on device (no host sync)."""
+def grad_norm(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = None, pre_scale: float = 1.0):
+    """out2 = [||pre_scale*g||, pre_scale * clip coefficient] on device (no host sync)."""
     nb = hip.lib().lib.rv_sumsq_nblocks()
     partial = torch.empty(nb, dtype=torch.float32, device=g.device)
     if out2 is None:
         out2 = torch.empty(2, dtype=torch.float32, device=g.device)
-    hip.call("rv_grad_norm", g, g.numel(), partial, float(max_norm), out2)
+    hip.call("rv_grad_norm", g, g.numel(), partial, float(max_norm), float(pre_scale), out2)
     return out2
 
 

@@ -1,0 +1,285 @@
+"""DPO trainer surface of the reference, re-hosted on the HIP kernels.
+
+Mirrors /root/reference muffin/train/trainers.py:
+  dpo_loss                  :91-126     -> rv_dpo_loss (loss, rewards and the closed-form gradient)
+  get_beta_and_logps        :161-275    -> LlavaDPOModel.forward_logps (is_llava15 branch)
+  collect_preference_metrics:140-158    -> same metric names, computed on device, ONE fused all-reduce
+                                           instead of 7 x (_nested_gather + .item()) per step (C2)
+  LLaVA15DPOTrainer.compute_loss :279-311
+and the optimiser the entry script selects (muffin/train/train_llava15.py:75 adamw_torch; cosine schedule,
+warm-up 5 %, weight decay 0.01 on matrices only, clip 1.0: script/train/llava15_train.sh:31-34).
+The HF ``Trainer`` base class itself is third-party and is not reproduced; only the surface the entry
+script uses (``train``, ``compute_loss``, ``log``, ``save_state``, ``_save``) is.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .model import LlavaDPOModel, StepOutput
+
+
+@dataclass
+class TrainingArguments:
+    """Subset of the reference's TrainingArguments dataclass (train_llava15.py:73-100) that the DPO
+    path reads; names unchanged so the shell scripts' flags map one to one."""
+    output_dir: str = "./checkpoints"
+    task: str = "DPO"
+    dpo_use_average: bool = False
+    dpo_token_weighted: bool = False
+    dpo_token_weight: float = 1.0
+    dpo_beta: float = 0.1
+    learning_rate: float = 5e-7
+    weight_decay: float = 0.01
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    max_grad_norm: float = 1.0
+    warmup_ratio: float = 0.05
+    lr_scheduler_type: str = "cosine"
+    max_steps: int = 2672
+    per_device_train_batch_size: int = 1
+    gradient_accumulation_steps: int = 1
+    logging_steps: int = 2
+    save_steps: int = 167
+    model_max_length: int = 2048
+    past_index: int = -1
+    bf16: bool = True
+    seed: int = 42
+
+
+def cosine_lr(step: int, total: int, base_lr: float, warmup_ratio: float) -> float:
+    """transformers.get_cosine_schedule_with_warmup; ``step`` = optimizer steps already taken."""
+    warm = math.ceil(total * warmup_ratio)
+    if step < warm:
+        return base_lr * step / max(1, warm)
+    prog = (step - warm) / max(1, total - warm)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
+def dpo_loss(policy_chosen_logps, policy_rejected_logps, reference_chosen_logps, reference_rejected_logps,
+             beta: float, reference_free: bool = False):
+    """Same signature / return as trainers.py:91-126 on device tensors: (losses, chosen_rewards,
+    rejected_rewards)."""
+    B = policy_chosen_logps.numel()
+    dev = policy_chosen_logps.device
+    s = torch.cat([policy_chosen_logps.float(), policy_rejected_logps.float()]).contiguous()
+    ones = torch.ones(2 * B, dtype=torch.float32, device=dev)
+    rw = reference_chosen_logps.to(dev, torch.float32).contiguous()
+    rr = reference_rejected_logps.to(dev, torch.float32).contiguous()
+    if reference_free:
+        rw, rr = torch.zeros_like(rw), torch.zeros_like(rr)
+    per_pair, _, _ = ops.dpo_loss(s, ones, rw, rr, beta, False, 0.0, 1.0)
+    if reference_free:     # rewards still use the provided reference (trainers.py:121-124)
+        return per_pair[0], beta * (policy_chosen_logps - reference_chosen_logps.to(dev)), \
+            beta * (policy_rejected_logps - reference_rejected_logps.to(dev))
+    return per_pair[0], per_pair[1], per_pair[2]
+
+
+def get_beta_and_logps(data_dict: Dict, model: LlavaDPOModel, args, is_minicpm: bool = False,
+                       is_llava15: bool = True, save_for_backward: bool = True):
+    """trainers.py:161-275 for the LLaVA-1.5 branch.  Consumes the collator's batch dict (keys popped
+    like the reference does) and returns (policy_win_logp, policy_rej_logp, ref_win_logp, ref_rej_logp,
+    beta).  The StepOutput needed for backward is left on ``model.last_out``."""
+    if not is_llava15 or is_minicpm:
+        raise NotImplementedError("only the LLaVA-1.5 DPO branch is implemented (SURVEY.md section 8f.4)")
+    if args.task != "DPO":
+        raise NotImplementedError("task must be DPO (the KTO image branch is unused by the shipped scripts)")
+    if args.dpo_token_weighted:
+        raise NotImplementedError          # the reference raises here too for LLaVA-1.5 (trainers.py:246-248)
+    for k in ("win_labels", "rej_labels", "win_attention_mask", "rej_attention_mask", "ref_win_per_token_logp",
+              "ref_rej_per_token_logp", "concatenated_attention_mask", "win_token_weight", "rej_token_weight",
+              "concatenated_token_weight"):
+        data_dict.pop(k, None)
+    win_input_ids = data_dict.pop("win_input_ids")
+    rej_input_ids = data_dict.pop("rej_input_ids")
+    ref_win_avg_logp = data_dict.pop("ref_win_avg_logp")
+    ref_rej_avg_logp = data_dict.pop("ref_rej_avg_logp")
+    ref_win_logp = data_dict.pop("ref_win_logp")
+    ref_rej_logp = data_dict.pop("ref_rej_logp")
+    if args.dpo_use_average:
+        ref_win_logp, ref_rej_logp = ref_win_avg_logp, ref_rej_avg_logp
+    beta = data_dict.pop("beta")
+    images = data_dict.pop("images")
+    ids = data_dict.pop("concatenated_input_ids")
+    labels = data_dict.pop("concatenated_labels")
+    assert win_input_ids.shape[0] == rej_input_ids.shape[0]
+    out = model.forward_logps(ids, labels, images, save_for_backward=save_for_backward)
+    model.last_out = out
+    B = win_input_ids.shape[0]
+    logp = out.seq_logp / out.seq_cnt if args.dpo_use_average else out.seq_logp
+    dev = model.device
+    return (logp[:B], logp[B:], ref_win_logp.to(dev, torch.float32).contiguous(),
+            ref_rej_logp.to(dev, torch.float32).contiguous(), beta)
+
+
+class GradReducer:
+    """Interface of the data-parallel gradient exchange (see rlaif_v_amd.dist.BucketedAllReduce)."""
+    world_size = 1
+
+    def on_bucket_ready(self, name: str, start: int, end: int):   # pragma: no cover - trivial
+        pass
+
+    def finish(self):                                            # pragma: no cover - trivial
+        pass
+
+    def reduce_metrics(self, t: torch.Tensor) -> torch.Tensor:   # pragma: no cover - trivial
+        return t
+
+
+class LLaVA15DPOTrainer:
+    """``LLaVA15DPOTrainer(model=, tokenizer=, args=, train_dataset=, eval_dataset=, data_collator=)``
+    then ``.train()`` - the call surface of muffin/train/train_llava15.py:320-334."""
+
+    def __init__(self, model: LlavaDPOModel, tokenizer=None, args: Optional[TrainingArguments] = None,
+                 train_dataset=None, eval_dataset=None, data_collator: Optional[Callable] = None,
+                 reducer: Optional[GradReducer] = None, **kwargs):
+        self.model, self.tokenizer = model, tokenizer
+        self.args = args or TrainingArguments()
+        self.train_dataset, self.eval_dataset, self.data_collator = train_dataset, eval_dataset, data_collator
+        self.reducer = reducer or GradReducer()
+        self.model.grad_ready_hook = self.reducer.on_bucket_ready if self.reducer.world_size > 1 else None
+        self.state = dict(global_step=0, log_history=[])
+        self._clip = torch.zeros(2, dtype=torch.float32, device=model.device)
+        self._pending_metrics: Optional[torch.Tensor] = None
+
+    # ---------------------------------------------------------------- loss
+    def compute_loss(self, model: LlavaDPOModel, inputs: dict, return_outputs: bool = False,
+                     num_items_in_batch=None):
+        """trainers.py:281-311.  Returns the 0-d loss tensor (device).  Metrics are left on the device
+        (``self._pending_metrics``) and reduced/logged without a per-metric host sync."""
+        if self.args.past_index >= 0:
+            raise NotImplementedError
+        data_dict = inputs
+        policy_win, policy_rej, ref_win, ref_rej, beta = get_beta_and_logps(
+            data_dict, model, self.args, is_llava15=True, save_for_backward=model.training)
+        out: StepOutput = model.last_out
+        sft_w = float(os.environ.get("SFT_weight", 0.0))      # trainers.py:299-300 (read on every call)
+        dpo_w = float(os.environ.get("DPO_weight", 1.0))
+        per_pair, scalars, coef = ops.dpo_loss(out.seq_logp, out.seq_cnt, ref_win, ref_rej, beta,
+                                               self.args.dpo_use_average, sft_w, dpo_w)
+        out.loss, out.scalars, out.per_pair = scalars[0], scalars, per_pair
+        model.last_coef = coef
+        # [chosen, rejected, logp_rej, logp_win, ref_rej, ref_win, acc]  (collect_preference_metrics order)
+        self._pending_metrics = torch.stack([scalars[1], scalars[2], scalars[6], scalars[5], ref_rej.mean(),
+                                             ref_win.mean(), scalars[3]])
+        self._pending_task = "train" if model.training else "test"
+        return (out.loss, out) if return_outputs else out.loss
+
+    def pop_metrics(self) -> Dict[str, float]:
+        """One fused cross-rank mean + one host transfer (replaces gather_and_do_mean x7, trainers.py:285-286)."""
+        if self._pending_metrics is None:
+            return {}
+        m = self.reducer.reduce_metrics(self._pending_metrics).tolist()
+        t = self._pending_task
+        self._pending_metrics = None
+        d = {f"rewards_{t}/chosen": m[0], f"rewards_{t}/rejected": m[1], f"logps_{t}/rejected": m[2],
+             f"logps_{t}/chosen": m[3], f"logps_{t}/ref_rejected": m[4], f"logps_{t}/ref_chosen": m[5],
+             f"rewards_{t}/accuracies": m[6]}
+        d[f"rewards_{t}/margins"] = d[f"rewards_{t}/chosen"] - d[f"rewards_{t}/rejected"]
+        return d
+
+    # ---------------------------------------------------------------- optimisation
+    def current_lr(self) -> float:
+        a = self.args
+        if a.lr_scheduler_type == "constant":
+            return a.learning_rate
+        return cosine_lr(self.state["global_step"], a.max_steps, a.learning_rate, a.warmup_ratio)
+
+    def optimizer_step(self, lr: Optional[float] = None):
+        """clip_grad_norm_(max_grad_norm) + AdamW on the flat buffers, then refresh the W^T copies."""
+        a, st = self.args, self.model.store
+        self.reducer.finish()                                  # all gradient buckets reduced (SUM over ranks)
+        step = self.state["global_step"] + 1
+        lr = self.current_lr() if lr is None else lr
+        ops.grad_norm(st.flat_g, a.max_grad_norm, self._clip, pre_scale=1.0 / self.reducer.world_size)
+        nd = st.n_decay
+        ops.adamw_step(st.flat_p[:nd], st.flat_master[:nd], st.flat_m[:nd], st.flat_v[:nd], st.flat_g[:nd], lr,
+                       a.adam_beta1, a.adam_beta2, a.adam_epsilon, a.weight_decay, step, clip=self._clip)
+        ops.adamw_step(st.flat_p[nd:], st.flat_master[nd:], st.flat_m[nd:], st.flat_v[nd:], st.flat_g[nd:], lr,
+                       a.adam_beta1, a.adam_beta2, a.adam_epsilon, 0.0, step, clip=self._clip)
+        st.refresh_transposes()
+        self.state["global_step"] = step
+
+    def training_step(self, inputs: dict) -> torch.Tensor:
+        """forward + backward (+ overlapped gradient all-reduce) + optimizer; returns the device loss."""
+        self.model.train()
+        loss = self.compute_loss(self.model, inputs)
+        self.model.backward(self.model.last_out, self.model.last_coef)
+        self.optimizer_step()
+        return loss
+
+    # ---------------------------------------------------------------- loop / logging / saving
+    def log(self, logs: Dict[str, float]):
+        logs = dict(logs, step=self.state["global_step"])
+        self.state["log_history"].append(logs)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(logs), flush=True)
+
+    def get_train_dataloader(self):
+        from torch.utils.data import DataLoader, RandomSampler
+        world, rank = self.reducer.world_size, int(os.environ.get("RANK", "0"))
+        g = torch.Generator().manual_seed(self.args.seed)
+        sampler = RandomSampler(self.train_dataset, generator=g)       # ZephyrTrainer._get_train_sampler (:45-51)
+        idx = list(iter(sampler))[rank::world]                         # rank-strided shard of one permutation
+        return DataLoader(self.train_dataset, batch_size=self.args.per_device_train_batch_size,
+                          sampler=idx, collate_fn=self.data_collator, drop_last=True)
+
+    def train(self, resume_from_checkpoint=None):
+        a = self.args
+        if resume_from_checkpoint:
+            self.load_checkpoint(resume_from_checkpoint)
+        t0 = time.time()
+        while self.state["global_step"] < a.max_steps:
+            for batch in self.get_train_dataloader():
+                loss = self.training_step(batch)
+                step = self.state["global_step"]
+                if step % a.logging_steps == 0:
+                    m = self.pop_metrics()
+                    m.update(loss=float(loss), learning_rate=self.current_lr(), grad_norm=float(self._clip[0]))
+                    if not math.isfinite(m["loss"]):       # reference: print + exit() on NaN (trainers.py:263-271)
+                        raise FloatingPointError(f"non-finite loss at step {step}")
+                    self.log(m)
+                if a.save_steps and step % a.save_steps == 0:
+                    self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{step}"))
+                if step >= a.max_steps:
+                    break
+        return dict(train_runtime=time.time() - t0, global_step=self.state["global_step"])
+
+    def _save(self, output_dir: str, state_dict=None):
+        """HF-layout weights (safe_save_model_for_hf_trainer, train_llava15.py:102-112)."""
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+        os.makedirs(output_dir, exist_ok=True)
+        torch.save(state_dict or self.model.state_dict(), os.path.join(output_dir, "pytorch_model.bin"))
+
+    def save_state(self):
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+        os.makedirs(self.args.output_dir, exist_ok=True)
+        with open(os.path.join(self.args.output_dir, "trainer_state.json"), "w") as f:
+            json.dump(self.state, f)
+
+    def save_checkpoint(self, path: str):
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+        os.makedirs(path, exist_ok=True)
+        st = self.model.store
+        torch.save(dict(master=st.flat_master.cpu(), m=st.flat_m.cpu(), v=st.flat_v.cpu(), state=self.state),
+                   os.path.join(path, "optimizer.pt"))
+        self._save(path)
+
+    def load_checkpoint(self, path: str):
+        st = self.model.store
+        blob = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
+        st.flat_master.copy_(blob["master"]), st.flat_m.copy_(blob["m"]), st.flat_v.copy_(blob["v"])
+        ops.cast_f32_to_bf16(st.flat_master, st.flat_p)
+        st.refresh_transposes()
+        self.state = blob["state"]

@@ -1,0 +1,167 @@
+"""End-to-end parity of the HIP DPO step against (a) golden vectors produced by the reference itself
+(tests/golden/*.pt) and (b) the CPU oracle (oracle/dpo_oracle.py) on the same seeded inputs.
+
+Bars (bf16 storage / fp32 accumulation vs an fp32 reference):
+  * token indexing (spliced labels, selected rows, targets): BIT EXACT;
+  * per-token log-probs: |err| <= 3e-2;  sequence log-prob sums: relative 1e-3 (north_star tolerance) plus
+    5e-2 absolute;  DPO loss: 2e-3 relative + 2e-3 absolute;
+  * gradients: per-tensor norm within 3 %, direction cosine >= 0.995 for the tensors stored in the fixture.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dpo_oracle as O  # noqa: E402
+
+CASES = ["tiny_b2", "tiny_b3_avg_sft", "tiny_b2_trunc"]
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _build(cfg_dict, seed):
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    cfg = LlavaConfig(**cfg_dict)
+    model = LlavaDPOModel(cfg)
+    W = O.make_weights(O.LlavaCfg(**cfg_dict), seed=seed)
+    model.load_state_dict(W)
+    return model, W
+
+
+def _trainer(model, dpo_use_average=False, **kw):
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    return LLaVA15DPOTrainer(model=model, args=TrainingArguments(dpo_use_average=dpo_use_average, **kw))
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference_golden(golden_dir, name, monkeypatch):
+    _need_gpu()
+    g = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    monkeypatch.setenv("SFT_weight", str(g["sft_weight"]))
+    monkeypatch.setenv("DPO_weight", "1.0")
+    model, _ = _build(g["cfg"], g["seed"])
+    tr = _trainer(model, g["dpo_use_average"])
+    cfg = O.LlavaCfg(**g["cfg"])
+    batch = O.make_synthetic_batch(cfg, g["n_pairs"], g["text_len"], g["prompt_len"], seed=g["seed"])
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    # ---- integer indexing: bit exact
+    assert torch.equal(out.plan.labels.cpu(), g["labels"])
+    mask = g["labels"][:, 1:] != -100
+    s_idx, l_idx = torch.nonzero(mask, as_tuple=True)
+    assert torch.equal(out.plan.sel_idx.cpu().long(), s_idx * g["labels"].shape[1] + l_idx)
+    assert torch.equal(out.plan.tgt.cpu().long(), g["labels"][:, 1:][mask])
+    # ---- floating point
+    ref_tok = g["per_token_logps"][mask]
+    err_tok = (out.per_token_logp.cpu() - ref_tok).abs().max().item()
+    ref_lp = g["log_prob"]
+    err_lp = (out.seq_logp.cpu() - ref_lp).abs()
+    print(f"[{name}] per-token max err {err_tok:.3e}; seq logp err {err_lp.tolist()} of {ref_lp.tolist()}; "
+          f"loss {float(loss):.6f} vs {float(g['loss']):.6f}")
+    assert err_tok <= 3e-2
+    assert bool((err_lp <= 1e-3 * ref_lp.abs() + 5e-2).all())
+    torch.testing.assert_close(out.per_pair[0].cpu(), g["losses"], rtol=2e-3, atol=2e-3 + 0.1 * 5e-2)
+    torch.testing.assert_close(loss.cpu(), g["loss"], rtol=2e-3, atol=2e-3 + 0.1 * 5e-2)
+    torch.testing.assert_close(out.per_pair[1].cpu(), g["chosen_rewards"], rtol=2e-3, atol=1e-2)
+    torch.testing.assert_close(out.per_pair[2].cpu(), g["rejected_rewards"], rtol=2e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("name", CASES[:2])
+def test_backward_matches_reference_golden(golden_dir, name, monkeypatch):
+    _need_gpu()
+    g = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    monkeypatch.setenv("SFT_weight", str(g["sft_weight"]))
+    monkeypatch.setenv("DPO_weight", "1.0")
+    model, _ = _build(g["cfg"], g["seed"])
+    tr = _trainer(model, g["dpo_use_average"])
+    cfg = O.LlavaCfg(**g["cfg"])
+    batch = O.make_synthetic_batch(cfg, g["n_pairs"], g["text_len"], g["prompt_len"], seed=g["seed"])
+    tr.compute_loss(model, dict(batch))
+    model.backward(model.last_out, model.last_coef)
+    grads = model.grads_state_dict()
+    worst = 0.0
+    for k, ref in g["grad_norms"].items():
+        if k not in grads:
+            assert "vision_tower" in k, k
+            continue
+        got = float(grads[k].double().norm())
+        rel = abs(got - ref) / max(ref, 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 3e-2 or ref < 1e-6, (k, got, ref)
+    print(f"[{name}] worst per-tensor grad-norm rel err {worst:.3e}")
+    for k, ref in g["grad_full"].items():
+        c = _cos(grads[k], ref)
+        assert c >= 0.995, (k, c)
+    c = _cos(grads["model.embed_tokens.weight"].double().sum(-1), g["grad_embed_rowsum"])
+    assert c >= 0.995, c
+
+
+def test_training_step_matches_oracle():
+    """forward + backward + clip + AdamW for two consecutive steps vs the CPU oracle."""
+    _need_gpu()
+    cfg = O.tiny_cfg()
+    model, W = _build(O.asdict(cfg), seed=5)
+    tr = _trainer(model, learning_rate=1e-3, max_steps=10, warmup_ratio=0.0, lr_scheduler_type="constant")
+    Wo = {k: v.clone() for k, v in W.items()}
+    state = {}
+    for step in (1, 2):
+        batch = O.make_synthetic_batch(cfg, 2, 36, 12, seed=10 + step)
+        loss = tr.training_step(dict(batch))
+        out_o, grads_o, gn_o = O.dpo_train_step(batch, Wo, cfg, state, lr=1e-3, step=step, sft_weight=0.0,
+                                                dpo_weight=1.0)
+        assert abs(float(loss) - float(out_o["loss"])) <= 2e-3 * abs(float(out_o["loss"])) + 7e-3
+        gn = float(tr._clip[0])
+        assert abs(gn - gn_o) <= 3e-2 * gn_o, (gn, gn_o)
+        new = model.state_dict()
+        # parameter updates: compare the fp32 master deltas through their direction
+        for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "lm_head.weight",
+                  "model.mm_projector.2.weight", "model.norm.weight"):
+            ref_delta = Wo[k] - W[k]
+            key, r0, n = model.store.hf_slices(model.cfg)[k]
+            off, shp = model.store.offsets[key]
+            master = model.store.flat_master[off:off + torch.Size(shp).numel()].view(*shp)[r0:r0 + n].cpu()
+            got_delta = master - W[k]
+            c = _cos(got_delta, ref_delta)
+            assert c >= 0.97, (step, k, c)
+            assert abs(float(got_delta.norm()) - float(ref_delta.norm())) <= 5e-2 * float(ref_delta.norm()), k
+            assert torch.equal(new[k], master.to(torch.bfloat16))
+
+
+def test_full_width_shallow_vs_oracle():
+    """LLaVA-1.5-7B widths (d=4096, f=11008, V=32000, 32 heads; CLIP-L width) with 2 LLM / 2 CLIP layers
+    against the fp32 CPU oracle: exercises the production tile shapes."""
+    _need_gpu()
+    cfg = O.LlavaCfg(layers=2, clip_layers=3, image_size=112, model_max_length=256)   # 64 patches
+    model, W = _build(O.asdict(cfg), seed=7)
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, 1, 48, 16, seed=3)
+    loss = tr.compute_loss(model, dict(batch))
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    for k in O.trainable_names(cfg):
+        W[k].requires_grad_(True)
+    ref = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)
+    out = model.last_out
+    assert torch.equal(out.plan.labels.cpu(), ref["labels"])
+    err = (out.seq_logp.cpu() - ref["log_prob"].detach()).abs()
+    print("full-width shallow: seq logp", out.seq_logp.tolist(), "ref", ref["log_prob"].tolist())
+    assert bool((err <= 1e-3 * ref["log_prob"].detach().abs() + 5e-2).all())
+    assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])) + 7e-3
+    ref["loss"].backward()
+    model.backward(out, model.last_coef)
+    grads = model.grads_state_dict()
+    for k in ("model.layers.1.mlp.gate_proj.weight", "model.layers.0.self_attn.v_proj.weight", "lm_head.weight",
+              "model.mm_projector.0.weight", "model.layers.0.input_layernorm.weight"):
+        c = _cos(grads[k], W[k].grad)
+        rel = abs(float(grads[k].double().norm()) - float(W[k].grad.double().norm())) / float(W[k].grad.double().norm())
+        print(f"  grad {k}: cos {c:.5f} norm rel err {rel:.3e}")
+        assert c >= 0.99 and rel <= 5e-2, (k, c, rel)
