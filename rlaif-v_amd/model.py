@@ -124,8 +124,16 @@ class ParamStore:
                 self.t_offsets[k] = (toff, (shp[1], shp[0]))
                 toff += shp[0] * shp[1]
         self.flat_pT = torch.zeros(toff, dtype=BF16, device=device)
-        # gradient buckets for data parallelism: contiguous, in the order backward finishes them
-        self.bucket_bounds: List[Tuple[str, int, int]] = []
+        # gradient buckets for data parallelism: contiguous slices in the order backward finishes them
+        self.buckets: Dict[str, Tuple[int, int]] = {"lm_head": self.grad_range("lm_head.weight", "lm_head.weight")}
+        for i in reversed(range(cfg.layers)):
+            self.buckets[f"layer{i}"] = self.grad_range(f"layers.{i}.wdown", f"layers.{i}.wqkv")
+        self.buckets["embed_proj"] = self.grad_range("model.embed_tokens.weight", "model.mm_projector.0.weight")
+        self.buckets["nodecay"] = (self.n_decay, self.n_total)
+
+    def bucket_schedule(self) -> List[Tuple[str, int, int]]:
+        """(name, start, end) in the order LlavaDPOModel.backward fires grad_ready_hook; covers flat_g exactly."""
+        return [(k, a, b) for k, (a, b) in self.buckets.items()]
 
     def p(self, key: str) -> torch.Tensor:
         off, shp = self.offsets[key]
@@ -404,7 +412,7 @@ class LlavaDPOModel:
             st.g("lm_head.weight").zero_()
             st.g("model.norm.weight").zero_()
         if hook:
-            hook("lm_head", *st.grad_range("lm_head.weight", "lm_head.weight"))
+            hook("lm_head", *st.buckets["lm_head"])
 
         # ---- decoder layers, last to first
         for i in reversed(range(cfg.layers)):
@@ -436,7 +444,7 @@ class LlavaDPOModel:
             del dxn, dx_mid
             ctx["layers"][i] = None          # free this layer's activations
             if hook:
-                hook(f"layer{i}", *st.grad_range(f"layers.{i}.wdown", f"layers.{i}.wqkv"))
+                hook(f"layer{i}", *st.buckets[f"layer{i}"])
 
         # ---- embedding (deterministic segmented sum) and projector
         ge = st.g("model.embed_tokens.weight")
@@ -450,8 +458,8 @@ class LlavaDPOModel:
         ops.colsum(dz1, out=st.g("model.mm_projector.0.bias"))
         wgrad(dz1, ctx["f_clip"], "model.mm_projector.0.weight")
         if hook:
-            hook("embed_proj", *st.grad_range("model.embed_tokens.weight", "model.mm_projector.0.weight"))
-            hook("nodecay", st.n_decay, st.n_total)
+            hook("embed_proj", *st.buckets["embed_proj"])
+            hook("nodecay", *st.buckets["nodecay"])
         out.ctx = {}
 
     # ------------------------------------------------------------------ reference-style surface

@@ -1,0 +1,146 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol, the splice planner is
+bit-identical to the oracle restatement of prepare_inputs_labels_for_multimodal, the collator reproduces the
+reference collator's golden batches, schedules / layouts are consistent.  No GPU, no compute calls."""
+import importlib.util
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import dpo_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _golden_instances(seed):
+    spec = importlib.util.spec_from_file_location("mkcol", os.path.join(REPO, "tests", "golden", "make_collator_golden.py"))
+    src = open(spec.origin).read()
+    # reuse the instance builder without importing the reference (not available on the GPU box)
+    ns = {}
+    from rlaif_v_amd.data import SyntheticPreferenceDataset
+    body = src[src.index("def instances(seed):"):src.index('if __name__ == "__main__":')]
+    exec(body, {"torch": torch, "SyntheticPreferenceDataset": SyntheticPreferenceDataset}, ns)
+    return ns["instances"](seed)
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from rlaif_v_amd import hip
+    lib = hip.lib()
+    assert len(lib.decls) >= 37
+    for name in lib.decls:
+        assert hasattr(lib.lib, name), name
+    assert lib.lib.rv_abi_version() == 1
+    # argument errors are reported through the ABI (no launch happens for an invalid shape)
+    assert lib.lib.rv_set_gemm_variant(7) == 1 and "rv_set_gemm_variant" in lib.last_error()
+    assert lib.lib.rv_set_gemm_variant(1) == 0
+
+
+def test_product_path_fails_loudly_without_library(tmp_path):
+    from rlaif_v_amd import hip
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip.HipLib(str(tmp_path / "missing.so"))
+    if not torch.cuda.is_available():
+        from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            LlavaDPOModel(LlavaConfig(**O.asdict(O.tiny_cfg())))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "rlaif-v_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+@pytest.mark.parametrize("max_len", [None, 48, 60, 4096])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_splice_plan_bit_exact(seed, max_len):
+    from rlaif_v_amd.splice import build_splice_plan
+    cfg = O.tiny_cfg()
+    B = 3
+    b = O.make_synthetic_batch(cfg, B, 44, 13, seed=seed)
+    ids, lab = b["concatenated_input_ids"], b["concatenated_labels"]
+    sk, si, nl = O.splice_plan(ids, lab, cfg.n_patches, max_len)
+    p = build_splice_plan(ids, lab, cfg.n_patches, B, max_len)
+    S, L = sk.shape
+    assert (p.S, p.L) == (S, L) and torch.equal(p.labels, nl)
+    src = p.src.view(S, L).long()
+    kind = torch.where(src >= 0, 1, torch.where(src == -1, 0, 2))
+    assert torch.equal(kind, sk) and torch.equal(src[sk == 1], si[sk == 1])
+    rows = torch.nonzero(sk == 2)[:, 0]
+    assert torch.equal(-2 - src[sk == 2], (rows % B) * cfg.n_patches + si[sk == 2])
+    # row selection == get_batch_logps' shift + mask
+    mask = nl[:, 1:] != -100
+    s_idx, l_idx = torch.nonzero(mask, as_tuple=True)
+    assert torch.equal(p.sel_idx.long(), s_idx * L + l_idx) and torch.equal(p.tgt.long(), nl[:, 1:][mask])
+    assert p.seq_off.tolist() == [0] + torch.cumsum(mask.sum(1), 0).tolist()
+    assert torch.equal(p.seq_of_row.long(), s_idx)
+    # embedding-backward segments: every text row appears once, grouped by id
+    flat = src.reshape(-1)
+    assert sorted(p.pos_sorted.tolist()) == torch.nonzero(flat >= 0)[:, 0].tolist()
+    for u in range(p.uniq_ids.numel()):
+        seg = p.pos_sorted[p.seg_off[u]:p.seg_off[u + 1]].long()
+        assert bool((flat[seg] == p.uniq_ids[u]).all())
+    # feature-gradient sources point back at the rows that consumed that feature row
+    for r in range(p.feat_src_a.numel()):
+        for srcrow in (int(p.feat_src_a[r]), int(p.feat_src_b[r])):
+            if srcrow >= 0:
+                assert int(flat[srcrow]) == -2 - r
+
+
+def test_splice_plan_edges():
+    from rlaif_v_amd.splice import build_splice_plan
+    # a row without an image token still consumes an image index (llava_arch.py:241-247); empty answers
+    ids = torch.tensor([[1, 5, 6, 7], [1, -200, 8, 0], [1, -200, 9, 2]])
+    lab = torch.tensor([[-100, 5, 6, 7], [-100, -100, -100, -100], [-100, -100, 9, 2]])
+    p = build_splice_plan(ids, lab, 3, 3, None)
+    assert p.L == 6 and p.src.view(3, 6)[0].tolist() == [1, 5, 6, 7, -1, -1]
+    assert p.src.view(3, 6)[1].tolist() == [1, -5, -6, -7, 8, 0]        # image index 1 -> rows 3..5
+    assert p.src.view(3, 6)[2].tolist() == [1, -8, -9, -10, 9, 2]       # image index 2 -> rows 6..8
+    assert p.seq_off.tolist() == [0, 3, 3, 5]                           # row 1 has no target -> avg logp NaN
+    sk, si, nl = O.splice_plan(ids, lab, 3, None)
+    assert torch.equal(p.labels, nl)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_collator_matches_reference_golden(golden_dir, seed):
+    from rlaif_v_amd.data import DataCollatorForDPODataset
+    gold = torch.load(os.path.join(golden_dir, "collator.pt"), weights_only=False)[seed]
+
+    class Tok:
+        pad_token_id = 0
+    batch = DataCollatorForDPODataset(Tok(), beta=0.1, mod_token_weight=1.5)(_golden_instances(seed))
+    assert set(batch) == set(gold)
+    for k, v in gold.items():
+        if torch.is_tensor(v):
+            assert batch[k].dtype == v.dtype and torch.equal(batch[k], v), k
+        else:
+            assert batch[k] == v, k
+    assert (batch["win_token_weight"] == 1.5).any()          # the difflib path really fired
+
+
+def test_param_store_layout_and_schedules():
+    from rlaif_v_amd.model import LlavaConfig, ParamStore
+    from rlaif_v_amd.trainer import cosine_lr
+    cfg = LlavaConfig(**O.asdict(O.tiny_cfg()))
+    st = ParamStore(cfg, "cpu")
+    sch = st.bucket_schedule()
+    assert sch[0][1] == 0 and sch[-1][2] == st.n_total
+    assert all(sch[i][2] == sch[i + 1][1] for i in range(len(sch) - 1))
+    names = st.hf_slices(cfg)
+    assert set(names) == set(O.trainable_names(O.tiny_cfg()))
+    for hf, (key, r0, n) in names.items():
+        off, shp = st.offsets[key]
+        assert (off >= st.n_decay) == (not O.is_decay_param(hf)), hf     # decay / no-decay split == HF's
+        assert tuple(st.p(key)[r0:r0 + n].shape) == tuple(O.weight_shapes(O.tiny_cfg())[hf]), hf
+    for s in range(0, 40):
+        assert abs(cosine_lr(s, 40, 5e-7, 0.05) - O.cosine_lr(s, 40, 5e-7, 0.05)) < 1e-18
+    # the 7B layout: 6.76 B trainable parameters
+    big = LlavaConfig()
+    d, f, V = big.hidden, big.ffn, big.vocab
+    n = 2 * V * d + 32 * (4 * d * d + 3 * d * f + 2 * d) + d + (d * 1024 + d) + (d * d + d)
+    assert n == 6_759_272_448 or n > 6.7e9
