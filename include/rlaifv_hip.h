@@ -79,7 +79,9 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
                 long lddq, int S, int L, int H, int hd, int causal, float scale, void* stream);
 int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
                   void* stream);
-/* X[(s*L+l)][col0 + h*hd + e] -> XT[s][h][e][Lp], Lp = roundup(L,64), zero padded; positions inside every
+/* Row stride Lp (elements) of the transposed copies: roundup(L,64), +64 when that is a multiple of 512. */
+int rv_attn_lp(int L);
+/* X[(s*L+l)][col0 + h*hd + e] -> XT[s][h][e][Lp], Lp = rv_attn_lp(L), positions >= L up to roundup(L,64) zero; positions inside every
  * aligned group of 16 stored with 4-element chunks 1 and 2 swapped (MFMA accumulator order). */
 int rv_head_transpose(const void* x, long ld, int col0, void* xt, int S, int L, int H, int hd, void* stream);
 

@@ -59,11 +59,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, half = lane >> 5;
   const int nqb = (L + 127) / 128;
-  const int qb = CAUSAL ? (nqb - 1 - (int)blockIdx.x) : (int)blockIdx.x;
   const int h = blockIdx.y, s = blockIdx.z;
+  const long tok0 = (long)s * L;
+  // Causal work grows with the query block index and the dispatcher hands block b to CU b % 256, so a CU would
+  // always draw the same index; each workgroup therefore processes the PAIR (x, nqb-1-x): equal work everywhere.
+  const int npass = CAUSAL ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qb = (pass == 0) ? (int)blockIdx.x : (nqb - 1 - (int)blockIdx.x);
+  if (pass == 1 && qb <= (int)blockIdx.x) break;
   const int q0 = qb * 128, q0w = q0 + wave * 32;
   const int q = q0w + fr;
-  const long tok0 = (long)s * L;
 
   // Q fragments (B operand): Q[q][16*ks + 8*half .. +7]
   bf16x8_t qf[KS];
@@ -186,6 +191,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       }
     if (half == 0) lse[((long)s * H + h) * L + q] = (m_run + log2f(l_run)) * LN2;
   }
+  __syncthreads();   // LDS tiles are reused by the second pass
+  }  // pass
 }
 
 // =============================================================================================
@@ -212,11 +219,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, half = lane >> 5;
   const int nqb = (L + 127) / 128;
-  const int qb = CAUSAL ? (nqb - 1 - (int)blockIdx.x) : (int)blockIdx.x;
   const int h = blockIdx.y, s = blockIdx.z;
+  const long tok0 = (long)s * L;
+  const int npass = CAUSAL ? 2 : 1;      // pair (x, nqb-1-x): see attn_fwd_kernel
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qb = (pass == 0) ? (int)blockIdx.x : (nqb - 1 - (int)blockIdx.x);
+  if (pass == 1 && qb <= (int)blockIdx.x) break;
   const int q0 = qb * 128, q0w = q0 + wave * 32;
   const int q = q0w + fr, qc = min(q, L - 1);
-  const long tok0 = (long)s * L;
 
   bf16x8_t qf[KS], dof[KS];
   {
@@ -302,6 +312,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         *(uint2*)(op + e * 32 + rg * 8 + 4 * half) = w;
       }
   }
+  __syncthreads();
+  }  // pass
 }
 
 // =============================================================================================
@@ -333,9 +345,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, s = blockIdx.z;
-  const int kv0 = blockIdx.x * 128, kv0w = kv0 + wave * 32;
-  const int key = kv0w + fr, keyc = min(key, L - 1);
   const long tok0 = (long)s * L;
+  const int nkb = (L + 127) / 128;
+  const int npass = CAUSAL ? 2 : 1;      // pair (x, nkb-1-x): see attn_fwd_kernel
+  for (int pass = 0; pass < npass; ++pass) {
+  const int kvb = (pass == 0) ? (int)blockIdx.x : (nkb - 1 - (int)blockIdx.x);
+  if (pass == 1 && kvb <= (int)blockIdx.x) break;
+  const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
+  const int key = kv0w + fr, keyc = min(key, L - 1);
 
   bf16x8_t kf[KS], vf[KS];
   {
@@ -435,6 +452,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
         *(uint2*)(kp + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
       }
   }
+  __syncthreads();
+  }  // pass
 }
 
 }  // namespace
@@ -446,8 +465,9 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, const void* vt
   RV_REQUIRE(hd == 64 || hd == 128, "rv_attn_fwd: head dim must be 64 or 128");
   RV_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0, "rv_attn_fwd: alignment");
   if (S == 0 || L == 0) return 0;
-  const int Lp = ((L + 63) / 64) * 64;
-  dim3 grid((L + 127) / 128, H, S), block(256);
+  const int Lp = rv_lp_stride(L);
+  const int nb = (L + 127) / 128;
+  dim3 grid(causal ? (nb + 1) / 2 : nb, H, S), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_FWD(HD_, C_)                                                                                    \
   hipLaunchKernelGGL((attn_fwd_kernel<HD_, C_>), grid, block, 0, st, (const bf16_t*)qkv, ld, q_col0, k_col0,    \
@@ -465,8 +485,9 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   RV_REQUIRE(hd == 128, "rv_attn_bwd: head dim must be 128");
   RV_REQUIRE(ld % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0, "rv_attn_bwd: alignment");
   if (S == 0 || L == 0) return 0;
-  const int Lp = ((L + 63) / 64) * 64;
-  dim3 grid((L + 127) / 128, H, S), block(256);
+  const int Lp = rv_lp_stride(L);
+  const int nb = (L + 127) / 128;
+  dim3 grid(causal ? (nb + 1) / 2 : nb, H, S), block(256);
   hipStream_t st = (hipStream_t)stream;
   constexpr int DKV_LDS = 2 * 64 * 256 + 2 * 128 * 128 + 512;
   static bool attr_done = false;
@@ -497,3 +518,5 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
 }
 
 }  // extern "C"
+
+extern "C" int rv_attn_lp(int L) { return rv_lp_stride(L); }

@@ -748,8 +748,8 @@ int rv_transpose(const void* in, long ld_in, void* out, long ldo, int R, int C, 
 int rv_head_transpose(const void* x, long ld, int col0, void* xt, int S, int L, int H, int hd, void* stream) {
   RV_REQUIRE(hd == 64 || hd == 128, "rv_head_transpose: head dim must be 64 or 128");
   RV_REQUIRE(ld % 8 == 0 && col0 % 8 == 0, "rv_head_transpose: alignment");
-  const int Lp = ((L + 63) / 64) * 64;
-  dim3 grid(Lp / 64, H, S);
+  const int Lp = rv_lp_stride(L);
+  dim3 grid((L + 63) / 64, H, S);
   if (hd == 128)
     hipLaunchKernelGGL(head_transpose_kernel<128>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, ld, col0,
                        (bf16_t*)xt, L, Lp, H);

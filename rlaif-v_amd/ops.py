@@ -145,9 +145,14 @@ def gelu_bwd(dy, x):
 
 
 # ------------------------------------------------------------------------------------- attention
+def attn_lp(L: int) -> int:
+    """Row stride of the per-head transposed copies (rv_attn_lp)."""
+    return hip.lib().lib.rv_attn_lp(int(L))
+
+
 def head_transpose(x: torch.Tensor, col0: int, S: int, L: int, H: int, hd: int, out=None) -> torch.Tensor:
     _chk2d(x, "x")
-    Lp = round_up(L, 64)
+    Lp = attn_lp(L)
     if out is None:
         out = torch.empty(S, H, hd, Lp, dtype=BF16, device=x.device)
     hip.call("rv_head_transpose", x, x.stride(0), col0, out, S, L, H, hd)
