@@ -25,7 +25,8 @@ extern "C" {
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
-/* 0 = register-staged GEMM tiles, 1 = global_load_lds (LDS-DMA) tiles (default). */
+/* GEMM kernel selection: -1 = auto (default), 0 = 128x128x64 register-staged, 1 = 128x128x64 global_load_lds,
+ * 2 = 256x256x32 ping-pong (two wave groups alternating MFMA / load segments). */
 int rv_set_gemm_variant(int variant);
 
 /* ---- dense contractions (replace torch.nn.Linear inside HF LlamaForCausalLM / CLIPVisionModel /
@@ -33,7 +34,7 @@ int rv_set_gemm_variant(int variant);
  *      llava/model/multimodal_encoder/clip_encoder.py:55, llava/model/multimodal_projector/builder.py:39-46)
  *   C[m][n] = act(alpha * sum_k A[m][k] * B[n][k] + bias[n]) + R[m][n]        (bf16 in, fp32 accumulate)
  *   act: 0 none, 1 quick_gelu (CLIP MLP), 2 gelu(erf) (projector).  K % 64 == 0, N % 4 == 0.
- *   variant: -1 = process default, 0 / 1 as rv_set_gemm_variant. */
+ *   variant: -1 = process default, else as rv_set_gemm_variant. */
 int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* bias, const void* residual, long ldr, int act, float alpha, int variant,
                     void* stream);

@@ -10,7 +10,22 @@ void rv_set_error(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 
-static int g_default_variant = 1;  // 1 = global_load_lds staging, 0 = register staging
+// variants: 0 = 128x128x64 register staging, 1 = 128x128x64 global_load_lds, 2 = 256x256x32 ping-pong,
+// -1 (default) = pick 2 when the problem fills the chip with 256x256 tiles, else 1.
+static int g_default_variant = -1;
+
+template <class Epi>
+static int launch_gemm256(const GemmShape& g, const Epi& epi, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nt_256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+  hipLaunchKernelGGL((gemm_nt_256_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st, g, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
 
 template <int STAGE, class Epi>
 static int launch_gemm(const GemmShape& g, const Epi& epi, hipStream_t st) {
@@ -30,6 +45,11 @@ static int launch_gemm(const GemmShape& g, const Epi& epi, hipStream_t st) {
 template <class Epi>
 static int dispatch(const GemmShape& g, const Epi& epi, int variant, void* stream) {
   if (variant < 0) variant = g_default_variant;
+  if (variant < 0) {
+    const long t256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
+    variant = (t256 >= 192) ? 2 : 1;
+  }
+  if (variant == 2) return launch_gemm256<Epi>(g, epi, (hipStream_t)stream);
   if (variant == 1) return launch_gemm<1, Epi>(g, epi, (hipStream_t)stream);
   return launch_gemm<0, Epi>(g, epi, (hipStream_t)stream);
 }
@@ -48,7 +68,7 @@ extern "C" {
 const char* rv_last_error(void) { return g_err; }
 
 int rv_set_gemm_variant(int variant) {
-  RV_REQUIRE(variant == 0 || variant == 1, "rv_set_gemm_variant: 0 (register staging) or 1 (global_load_lds)");
+  RV_REQUIRE(variant >= -1 && variant <= 2, "rv_set_gemm_variant: -1 (auto), 0, 1 or 2");
   g_default_variant = variant;
   return 0;
 }

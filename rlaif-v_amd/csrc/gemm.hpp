@@ -147,6 +147,142 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, E
   epi.apply(acc, m0 + wm * 64, n0 + wn * 64, lane, g.M, g.N);
 }
 
+// =============================================================================================
+// 256x256x32 "ping-pong" kernel for large GEMMs.
+//
+// 8 waves (2 M-halves x 4 N-quarters), per-wave output 128x64 = 4x2 MFMA tiles (128 accumulator VGPRs),
+// K step 32, 4-stage LDS ring (4 x (16 KiB A + 16 KiB B) = 128 KiB) filled two tiles ahead with
+// global_load_lds.  Each SIMD hosts one wave of group 0 (M-half 0) and one of group 1; group 1 runs ONE
+// barrier behind group 0, so at any time one wave of a SIMD is in its MFMA segment while its partner is in
+// its load segment (12 ds_read_b128 + 4 LDS-DMA issues):
+//     L-seg: ds_read tile p | issue DMA tile p+2 | vmcnt(4): own pieces of tile p+1 landed | lgkmcnt(0)
+//     s_barrier   (X)
+//     M-seg: 16 x v_mfma_f32_32x32x16_bf16 under s_setprio 1
+//     s_barrier   (Y)
+// Hazards (barrier instance 2p = G0.X(p) = G1.Y(p-1); 2p+1 = G0.Y(p) = G1.X(p)):
+//   RAW tile p+1: every wave retires its own DMA pieces (counted vmcnt) before its X(p); G0 reads after
+//       instance 2p+1, G1 after 2p+2 - both later than every wave's X(p).
+//   WAR stage (p+2)%4: last read in L-seg(p-2), two phases earlier; reads are retired (lgkmcnt(0)) before X.
+// LDS image of a [256 rows][32 k] tile: 64-byte rows, 16-byte chunk kc of row r at r*64 + ((kc ^ ((r>>2)&3))<<4):
+// the 16 rows of every ds_read_b128 lane group land on 16 distinct 16-byte slots of the 256-byte bank row.
+// =============================================================================================
+#define G2_BM 256
+#define G2_BN 256
+#define G2_BK 32
+#define G2_THREADS 512
+#define G2_STAGE_BYTES 32768
+#define G2_LDS_BYTES (4 * G2_STAGE_BYTES)
+
+template <class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP = 8;
+  const int group_size = GROUP * tiles_n;
+  const int first_m = (id / group_size) * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tile_m = first_m + (id % group_size) % gsz;
+  const int tile_n = (id % group_size) / gsz;
+  const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
+
+  // ---- LDS-DMA sources: 2 pieces (1 KiB = 16 rows x 64 B) of A and of B per wave per K tile ----
+  const bf16_t* a_src[2];
+  const bf16_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    const int kc = (lane & 3) ^ ((row >> 2) & 3);
+    a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+    b_src[i] = g.B + (long)min(n0 + row, g.N - 1) * g.ldb + kc * 8;
+  }
+  const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
+
+  auto issue = [&](int t) {
+    uint8_t* st = smem + (t & 3) * G2_STAGE_BYTES;
+    const long koff = (long)t * G2_BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(st + 16384 + piece0 + i * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets: row = base + t*32 + fr with base a multiple of 32 => swizzle depends on fr only
+  const int fr = lane & 31, half = lane >> 5;
+  uint32_t a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t sw = (uint32_t)(((ks * 2 + half) ^ ((fr >> 2) & 3)) << 4);
+    a_off[ks] = (uint32_t)((wm * 128 + fr) * 64) + sw;
+    b_off[ks] = (uint32_t)((wn * 64 + fr) * 64) + sw + 16384u;
+  }
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = g.K / G2_BK;
+  issue(0);
+  if (nt > 1) {
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+  for (int p = 0; p < nt; ++p) {
+    const uint8_t* st = smem + (p & 3) * G2_STAGE_BYTES;
+    bf16x8_t af[2][4], bfr[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bfr[ks][t] = *(const bf16x8_t*)(st + b_off[ks] + t * 2048);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[ks][t] = *(const bf16x8_t*)(st + a_off[ks] + t * 2048);
+    }
+    if (p + 2 < nt) {
+      issue(p + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count
+
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogues.  apply() receives the wave's 64x64 accumulators and its tile origin.
 // ---------------------------------------------------------------------------------------------
