@@ -14,15 +14,31 @@ void rv_set_error(const char* msg) {
 // -1 (default) = pick 2 when the problem fills the chip with 256x256 tiles, else 1.
 static int g_default_variant = -1;
 
-template <class Epi>
+template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3>
 static int launch_gemm256(const GemmShape& g, const Epi& epi, hipStream_t st) {
+  constexpr int LDS = (DMA_IN_MSEG ? DIST + 1 : 4) * G2_STAGE_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_nt_256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nt_256_kernel<Epi, DMA_IN_MSEG, ABLATE, DIST>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
-  hipLaunchKernelGGL((gemm_nt_256_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st, g, epi);
+  hipLaunchKernelGGL((gemm_nt_256_kernel<Epi, DMA_IN_MSEG, ABLATE, DIST>), dim3(tiles_m * tiles_n), dim3(G2_THREADS),
+                     LDS, st, g, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+template <class Epi>
+static int launch_gemm256x64(const GemmShape& g, const Epi& epi, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nt_256x64_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+  hipLaunchKernelGGL((gemm_nt_256x64_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G3_LDS_BYTES, st, g, epi);
   RV_CHECK_LAUNCH();
   return 0;
 }
@@ -47,9 +63,14 @@ static int dispatch(const GemmShape& g, const Epi& epi, int variant, void* strea
   if (variant < 0) variant = g_default_variant;
   if (variant < 0) {
     const long t256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
-    variant = (t256 >= 192) ? 2 : 1;
+    variant = (t256 >= 192) ? 3 : 1;
   }
-  if (variant == 2) return launch_gemm256<Epi>(g, epi, (hipStream_t)stream);
+  if (variant == 101) return launch_gemm256<Epi, true, 1>(g, epi, (hipStream_t)stream);   // ablation: no DMA
+  if (variant == 102) return launch_gemm256<Epi, true, 2>(g, epi, (hipStream_t)stream);   // ablation: stale ds_reads
+  if (variant == 5) return launch_gemm256x64<Epi>(g, epi, (hipStream_t)stream);
+  if (variant == 4) return launch_gemm256<Epi, true, 0, 4>(g, epi, (hipStream_t)stream);
+  if (variant == 3) return launch_gemm256<Epi, true>(g, epi, (hipStream_t)stream);
+  if (variant == 2) return launch_gemm256<Epi, false>(g, epi, (hipStream_t)stream);
   if (variant == 1) return launch_gemm<1, Epi>(g, epi, (hipStream_t)stream);
   return launch_gemm<0, Epi>(g, epi, (hipStream_t)stream);
 }
@@ -68,7 +89,7 @@ extern "C" {
 const char* rv_last_error(void) { return g_err; }
 
 int rv_set_gemm_variant(int variant) {
-  RV_REQUIRE(variant >= -1 && variant <= 2, "rv_set_gemm_variant: -1 (auto), 0, 1 or 2");
+  RV_REQUIRE(variant >= -1 && variant <= 5, "rv_set_gemm_variant: -1 (auto), 0..5");
   g_default_variant = variant;
   return 0;
 }

@@ -173,8 +173,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, E
 #define G2_STAGE_BYTES 32768
 #define G2_LDS_BYTES (4 * G2_STAGE_BYTES)
 
-template <class Epi>
+// DMA_IN_MSEG = true issues the LDS-DMA pieces of tile p+3 between the MFMAs of M-seg(p) (free issue slots of the
+// matrix pipe) instead of tile p+2 at the end of L-seg(p): the load segment shrinks to the 12 ds_reads.
+// WAR for stage (p+3)%4 = (p-1)%4: G0 issues after instance 2p = G1.Y(p-1), G1 after 2p+1 = G0.Y(p); both groups
+// retired their L-seg(p-1) reads before X(p-1).  RAW and the counted vmcnt(4) are unchanged.
+// ABLATE (debug/profiling only, results are wrong): 1 = no LDS-DMA in the main loop, 2 = no ds_reads in the loop.
+// DIST = prefetch distance in K tiles when DMA_IN_MSEG (ring of DIST+1 stages: 3 -> 128 KiB, 4 -> 160 KiB).
+template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g, Epi epi) {
+  constexpr int NST = DMA_IN_MSEG ? DIST + 1 : 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,16 +210,20 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
   }
   const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
 
-  auto issue = [&](int t) {
-    uint8_t* st = smem + (t & 3) * G2_STAGE_BYTES;
+  auto issue_piece = [&](int t, int j) {   // j: 0 = A piece 0, 1 = B piece 0, 2 = A piece 1, 3 = B piece 1
+    uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
     const long koff = (long)t * G2_BK;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    const int i = j >> 1;
+    if ((j & 1) == 0)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
                                        (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
+    else
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + koff),
                                        (__attribute__((address_space(3))) void*)(st + 16384 + piece0 + i * 1024), 16, 0, 0);
-    }
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_piece(t, j);
   };
 
   // ---- fragment read offsets: row = base + t*32 + fr with base a multiple of 32 => swizzle depends on fr only
@@ -235,17 +246,21 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
 
   const int nt = g.K / G2_BK;
   issue(0);
-  if (nt > 1) {
-    issue(1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nt > 1) issue(1);
+  if (DMA_IN_MSEG && nt > 2) issue(2);
+  if (DMA_IN_MSEG && DIST > 3 && nt > 3) issue(3);
+  {
+    const int issued = DMA_IN_MSEG ? min(nt, DIST) : min(nt, 2);
+    if (issued >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (issued == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
   for (int p = 0; p < nt; ++p) {
-    const uint8_t* st = smem + (p & 3) * G2_STAGE_BYTES;
+    const uint8_t* st = smem + ((ABLATE == 2 ? 0 : p) % NST) * G2_STAGE_BYTES;
     bf16x8_t af[2][4], bfr[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -254,30 +269,163 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
 #pragma unroll
       for (int t = 0; t < 4; ++t) af[ks][t] = *(const bf16x8_t*)(st + a_off[ks] + t * 2048);
     }
-    if (p + 2 < nt) {
-      issue(p + 2);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!DMA_IN_MSEG && p + 2 < nt && ABLATE != 1) issue(p + 2);
+    {
+      // tiles newer than p+1 that are already in flight (each = 4 DMA pieces of this wave)
+      const int newer = (ABLATE == 1) ? 0 : min((DMA_IN_MSEG ? DIST : 2) - 1, nt - 2 - p);
+      if (newer >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    const bool dma = DMA_IN_MSEG && (p + DIST < nt) && ABLATE != 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < 2; ++tn) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int k = (ks * 4 + tm) * 2 + tn;
+          if (DMA_IN_MSEG && (k & 3) == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (dma) issue_piece(p + DIST, k >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count
+
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
+}
+
+// =============================================================================================
+// 256x256x64 ping-pong kernel: same two-group schedule, but a K tile is 64 deep so every LDS-DMA lane group
+// reads FULL 128-byte lines from L2 (the 32-deep tile reads half lines twice).  Two 64 KiB stages; a tile is
+// consumed in two phases (k halves); all 8 DMA pieces of tile t+1 are issued between the MFMAs of phase 2t.
+//   WAR stage (t+1)&1 (last read in phase 2t-1): G0 issues after instance 4t = G1.Y(2t-1), G1 after 4t+1.
+//   RAW tile t+1 (first read in L-seg(2t+2)): every wave drains its DMA (vmcnt(0)) before its X(2t+1).
+// =============================================================================================
+#define G3_STAGE_BYTES 65536
+#define G3_LDS_BYTES (2 * G3_STAGE_BYTES)
+
+template <class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256x64_kernel(GemmShape g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP = 8;
+  const int group_size = GROUP * tiles_n;
+  const int first_m = (id / group_size) * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tile_m = first_m + (id % group_size) % gsz;
+  const int tile_n = (id % group_size) / gsz;
+  const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
+
+  // 4 pieces (1 KiB = 8 rows x 128 B) of A and of B per wave per K tile
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((row >> 1) & 7);
+    a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+    b_src[i] = g.B + (long)min(n0 + row, g.N - 1) * g.ldb + kc * 8;
+  }
+  const uint32_t piece0 = (uint32_t)(wave * 4) * 1024u;
+  auto issue_piece = [&](int t, int j) {   // j = 0..7: A piece j>>1 for even j, B piece j>>1 for odd j
+    uint8_t* st = smem + (t & 1) * G3_STAGE_BYTES;
+    const long koff = (long)t * 64;
+    const int i = j >> 1;
+    if ((j & 1) == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(st + 32768 + piece0 + i * 1024), 16, 0, 0);
+  };
+
+  const int fr = lane & 31, half = lane >> 5;
+  uint32_t a_off[2], b_off[2];   // k-substep ks of the FIRST half tile; the second half is the same offset ^ 64
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const uint32_t sw = (uint32_t)(((ks * 2 + half) ^ ((fr >> 1) & 7)) << 4);
+    a_off[ks] = (uint32_t)((wm * 128 + fr) * 128) + sw;
+    b_off[ks] = (uint32_t)((wn * 64 + fr) * 128) + sw + 32768u;
+  }
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = g.K / 64;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) issue_piece(0, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nt; ++t) {
+    const uint8_t* st = smem + (t & 1) * G3_STAGE_BYTES;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8_t af[2][4], bfr[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bfr[ks][u] = *(const bf16x8_t*)(st + ((b_off[ks] ^ (h * 64)) + u * 4096));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) af[ks][u] = *(const bf16x8_t*)(st + ((a_off[ks] ^ (h * 64)) + u * 4096));
+      }
+      if (h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      const bool dma = (h == 0) && (t + 1 < nt);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
+            const int k = (ks * 4 + tm) * 2 + tn;
+            if (h == 0 && (k & 1) == 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (dma) issue_piece(t + 1, k >> 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
 
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);

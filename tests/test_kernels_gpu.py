@@ -46,7 +46,7 @@ def ops():
 
 
 # ------------------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 132, 192), (1000, 520, 1024), (7, 4, 64)])
 def test_gemm_nt(ops, variant, M, N, K):
     dev = _dev()
@@ -56,7 +56,7 @@ def test_gemm_nt(ops, variant, M, N, K):
     close(out, a.float() @ b.float().t(), what=f"gemm v{variant} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_gemm_identity_asymmetric(ops, variant):
     """A = I with an asymmetric B catches transposed / permuted output tiles exactly."""
     dev = _dev()
@@ -67,7 +67,7 @@ def test_gemm_identity_asymmetric(ops, variant):
     assert torch.equal(out, b.t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_epilogues(ops, variant, act):
     dev = _dev()
@@ -83,7 +83,7 @@ def test_gemm_epilogues(ops, variant, act):
     close(out, z + res.float(), what=f"gemm epilogue act={act}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_gemm_strided_views(ops, variant):
     dev = _dev()
     big_a, big_b = rnd(130, 512, seed=7, dev=dev), rnd(96, 448, seed=8, dev=dev)
@@ -95,17 +95,18 @@ def test_gemm_strided_views(ops, variant):
     assert outbuf[:, :8].abs().sum() == 0 and outbuf[:, 104:].abs().sum() == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 768, 64), (700, 1000, 2048), (4096, 4096, 4096)])
-def test_gemm_pingpong_large(ops, M, N, K):
+@pytest.mark.parametrize("v", [2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 64), (300, 520, 128), (700, 1000, 2048), (4096, 4096, 4096)])
+def test_gemm_pingpong_large(ops, M, N, K, v):
     """256x256x32 ping-pong kernel: K = 1 / 2 / many ring tiles, ragged M and N edges, bit-stable across runs."""
     dev = _dev()
     a, b = rnd(M, K, seed=11, dev=dev, scale=0.5), rnd(N, K, seed=12, dev=dev, scale=0.5)
-    out = ops.gemm_nt(a, b, variant=2)
+    out = ops.gemm_nt(a, b, variant=v)
     ref = ops.gemm_nt(a, b, variant=1)
     close(out, a.float() @ b.float().t(), what=f"gemm256 {M}x{N}x{K}")
     assert torch.equal(out, ref)                      # same accumulation order as the 128x128 kernel
     for _ in range(3):                                # race screen: repeated launches must agree exactly
-        assert torch.equal(ops.gemm_nt(a, b, variant=2), out)
+        assert torch.equal(ops.gemm_nt(a, b, variant=v), out)
 
 
 def test_gemm_f32_out(ops):

@@ -43,7 +43,7 @@ def main():
         a = torch.randn(M, K, device=dev).to(BF)
         b = torch.randn(Nn, K, device=dev).to(BF)
         out = torch.empty(M, Nn, dtype=BF, device=dev)
-        for variant in (1, 2):
+        for variant in (1, 2, 3):
             ms = timeit(lambda: ops.gemm_nt(a, b, out=out, variant=variant))
             tf = 2.0 * M * Nn * K / ms / 1e9
             res.append(dict(kernel="gemm_nt", name=name, variant=variant, M=M, N=Nn, K=K, ms=ms, tflops=tf))
