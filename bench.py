@@ -53,7 +53,18 @@ class GemmTimer:
             return r
 
         ops.gemm_nt = timed
-        self._restore = lambda: setattr(ops, "gemm_nt", orig)
+        orig_tn = ops.gemm_tn
+
+        def timed_tn(p, q, out=None, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_tn(p, q, out=out, **kw)
+            e.record()
+            recs.append((s, e, 2.0 * p.shape[0] * p.shape[1] * q.shape[1]))
+            return r
+
+        ops.gemm_tn = timed_tn
+        self._restore = lambda: (setattr(ops, "gemm_nt", orig), setattr(ops, "gemm_tn", orig_tn))
 
     def summary(self):
         tot_ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
@@ -174,13 +185,13 @@ def main():
                        "pairs_per_gpu": B, "global_batch_pairs": B * world, "seq_len": L, "llm_layers": args.layers,
                        "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0",
                        "gradient_checkpointing": False},
-            "loss": float(loss),
+            "loss": float(loss), "max_memory_allocated_gb": torch.cuda.max_memory_allocated() / 2**30,
             "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / PEAK_BF16_TFLOPS,
             "flops_per_pair": fp,
         }
         if not args.no_gemm_timer:
             g = timer.summary()
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<glds,128x128x64> (all rv_gemm_nt_bf16 launches)",
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256_kernel / gemm_tn_256_kernel (256x256x32 ping-pong; all rv_gemm_nt_bf16 + rv_gemm_tn_bf16 launches)",
                                 "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
                                 "launches": g["launches"], "avg_launch_ms": g["avg_ms"],

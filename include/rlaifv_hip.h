@@ -38,6 +38,11 @@ int rv_set_gemm_variant(int variant);
 int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* bias, const void* residual, long ldr, int act, float alpha, int variant,
                     void* stream);
+/* Weight-gradient contraction over the ROW index of both operands (no transposed copies in HBM):
+ *   C[i][j] = alpha * sum_r P[r][i] * Q[r][j] + residual[i][j]      P [R][I], Q [R][J], C [I][J]; I, J % 8 == 0
+ * e.g. dW = dY^T X (autograd of nn.Linear); operands are transposed on the fly by ds_read_b64_tr_b16. */
+int rv_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, void* C, long ldc, int R, int I, int J,
+                    const void* residual, long ldr, float alpha, void* stream);
 int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                            int variant, void* stream);
 

@@ -43,6 +43,21 @@ static int launch_gemm256x64(const GemmShape& g, const Epi& epi, hipStream_t st)
   return 0;
 }
 
+template <class Epi>
+static int launch_gemm_tn(const bf16_t* P, long ldp, const bf16_t* Q, long ldq, int R, int I, int J, const Epi& epi,
+                          hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_tn_256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_i = (I + 255) / 256, tiles_j = (J + 255) / 256;
+  hipLaunchKernelGGL((gemm_tn_256_kernel<Epi>), dim3(tiles_i * tiles_j), dim3(G2_THREADS), G2_LDS_BYTES, st, P, ldp, Q,
+                     ldq, R, I, J, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int STAGE, class Epi>
 static int launch_gemm(const GemmShape& g, const Epi& epi, hipStream_t st) {
   static bool attr_done = false;
@@ -105,6 +120,18 @@ int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_bf16: ldc/ldr must be multiples of 4");
   EpiStore epi{(bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, alpha};
   return dispatch(g, epi, variant, stream);
+}
+
+int rv_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, void* C, long ldc, int R, int I, int J,
+                    const void* residual, long ldr, float alpha, void* stream) {
+  if (I == 0 || J == 0) return 0;
+  RV_REQUIRE(R > 0, "rv_gemm_tn_bf16: R must be > 0");
+  RV_REQUIRE(I % 8 == 0 && J % 8 == 0 && I >= 8 && J >= 8, "rv_gemm_tn_bf16: I and J must be multiples of 8");
+  RV_REQUIRE(ldp % 8 == 0 && ldq % 8 == 0 && ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0),
+             "rv_gemm_tn_bf16: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
+  RV_REQUIRE((((uintptr_t)P | (uintptr_t)Q) & 15) == 0, "rv_gemm_tn_bf16: P/Q must be 16-byte aligned");
+  EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
+  return launch_gemm_tn((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, R, I, J, epi, (hipStream_t)stream);
 }
 
 int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,

@@ -431,6 +431,162 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256x64_kernel(GemmShape
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
 }
 
+// =============================================================================================
+// TN GEMM (weight gradients):  out[i][j] = sum_r P[r][i] * Q[r][j]   (P [R][I], Q [R][J] row-major, the
+// contraction index r is the ROW of both operands - e.g. dW = dY^T X with r = token).
+// Same 256x256 ping-pong schedule as gemm_nt_256_kernel; the operand tiles are staged exactly as they lie
+// in memory ([32 r][256 cols], 512-byte rows, coalesced 512-byte global segments) and the MFMA fragments
+// ("8 consecutive r for one column") come from ds_read_b64_tr_b16, gfx950's transposing LDS read:
+// inside a 16-lane group lane t receives element (t&3) of the 8-byte chunk addressed by lane 4j+(t>>2),
+// j = 0..3 - so when lane s addresses row (s>>2), columns 4(s&3).., lane t ends up with 4 consecutive rows of
+// column t.  No transposed copies of dY / X are ever written to HBM.
+// LDS swizzle: the 64-byte block b of row r lives at block b ^ (r & 3) (4 consecutive rows of a transposing
+// read hit 4 different quarters of the 256-byte bank row); applied on the DMA source address.
+// Rows r >= R of the last tile are redirected to a zero row (zero_row: >= 512 zero bytes in HBM).
+// =============================================================================================
+typedef __attribute__((ext_vector_type(4))) short bf16x4s_t;
+__device__ bf16_t g_zero_row[256];   // 512 zero bytes: DMA source for contraction rows beyond R
+
+template <class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t* __restrict__ P, long ldp,
+                                                                    const bf16_t* __restrict__ Q, long ldq, int R,
+                                                                    int I, int J, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NST = 4, DIST = 3;
+  const bf16_t* zero_row = g_zero_row;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 2, wj = wave & 3;
+
+  const int tiles_i = (I + 255) / 256, tiles_j = (J + 255) / 256;
+  const int nwg = tiles_i * tiles_j;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP = 8;
+  const int group_size = GROUP * tiles_j;
+  const int first_i = (id / group_size) * GROUP;
+  const int gsz = min(tiles_i - first_i, GROUP);
+  const int tile_i = first_i + (id % group_size) % gsz;
+  const int tile_j = (id % group_size) / gsz;
+  const int i0 = tile_i * 256, j0 = tile_j * 256;
+
+  // ---- LDS-DMA: a stage = P tile (16 KiB) + Q tile (16 KiB); one piece = 2 rows x 512 B; 2 pieces each per wave
+  int p_row[2];   // tile row filled by this lane in piece i
+#pragma unroll
+  for (int i = 0; i < 2; ++i) p_row[i] = (wave * 2 + i) * 2 + (lane >> 5);
+  // source column (elements) of LDS chunk c = lane&31 of row r: 64-byte block (c>>2) ^ (r&3), 16-byte slot c&3
+  auto src_col = [&](int r, int base, int limit) {
+    const int c = lane & 31;
+    const int col = (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3);
+    return min(base + col, limit - 8);
+  };
+  const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
+  auto issue_piece = [&](int t, int jj) {   // jj: 0 = P piece 0, 1 = Q piece 0, 2 = P piece 1, 3 = Q piece 1
+    uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
+    const int i = jj >> 1;
+    const int r = p_row[i];
+    const long rg = (long)t * 32 + r;
+    const bool valid = rg < R;
+    if ((jj & 1) == 0) {
+      const bf16_t* src = valid ? (P + rg * ldp + src_col(r, i0, I)) : (zero_row + ((lane & 31) << 3));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
+    } else {
+      const bf16_t* src = valid ? (Q + rg * ldq + src_col(r, j0, J)) : (zero_row + ((lane & 31) << 3));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 16384 + piece0 + i * 1024), 16, 0, 0);
+    }
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) issue_piece(t, jj);
+  };
+
+  // ---- transposing fragment reads
+  const int g4 = lane >> 4, s16 = lane & 15;
+  const uint32_t lane_part = (uint32_t)((8 * (g4 >> 1) + (s16 >> 2)) * 512 + 32 * (g4 & 1) + 8 * (s16 & 3));
+  uint32_t q_blk[2], p_blk[4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) q_blk[t] = lane_part + 16384u + (uint32_t)((((wj * 2 + t) ^ (s16 >> 2))) << 6);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) p_blk[t] = lane_part + (uint32_t)((((wi * 4 + t) ^ (s16 >> 2))) << 6);
+
+  auto tr8 = [&](const uint8_t* st, uint32_t off) -> bf16x8_t {
+    const bf16x4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4s_t*)(st + off));
+    const bf16x4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4s_t*)(st + off + 2048));
+    bf16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+  };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = (R + 31) / 32;
+  issue(0);
+  if (nt > 1) issue(1);
+  if (nt > 2) issue(2);
+  {
+    const int issued = min(nt, DIST);
+    if (issued == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wi == 1) __builtin_amdgcn_s_barrier();
+
+  for (int p = 0; p < nt; ++p) {
+    const uint8_t* st = smem + (p % NST) * G2_STAGE_BYTES;
+    bf16x8_t qf[2][2], pf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) qf[ks][t] = tr8(st, q_blk[t] + ks * 8192);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pf[ks][t] = tr8(st, p_blk[t] + ks * 8192);
+    }
+    {
+      const int newer = min(DIST - 1, nt - 2 - p);
+      if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    const bool dma = (p + DIST < nt);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks][tj], pf[ks][ti], acc[ti][tj], 0, 0, 0);
+          const int k = (ks * 4 + ti) * 2 + tj;
+          if ((k & 3) == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (dma) issue_piece(p + DIST, k >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wi == 0) __builtin_amdgcn_s_barrier();
+
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), i0 + wi * 128, j0 + wj * 64, lane, I, J);
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), i0 + wi * 128 + 64, j0 + wj * 64, lane, I, J);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogues.  apply() receives the wave's 64x64 accumulators and its tile origin.
 // ---------------------------------------------------------------------------------------------

@@ -393,9 +393,9 @@ class LlavaDPOModel:
         hook = self.grad_ready_hook
 
         def wgrad(dy: torch.Tensor, xin: torch.Tensor, key: str, rows: Optional[Tuple[int, int]] = None):
-            """dW[key] = dy^T @ xin through two K-contiguous transposes and the NT GEMM."""
+            """dW[key] = dy^T @ xin: TN GEMM (operands transposed on the fly by ds_read_b64_tr_b16)."""
             tgt = st.g(key) if rows is None else st.g(key)[rows[0]:rows[1]]
-            ops.gemm_nt(ops.transpose(dy), ops.transpose(xin), out=tgt)
+            ops.gemm_tn(dy, xin, out=tgt)
 
         # ---- LM head + final norm
         n_sel = plan.n_sel

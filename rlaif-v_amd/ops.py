@@ -47,6 +47,22 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+            alpha: float = 1.0) -> torch.Tensor:
+    """out[i][j] = alpha * sum_r p[r][i] q[r][j] + residual[i][j]  (weight gradient dW = dY^T X)."""
+    _chk2d(p, "p"), _chk2d(q, "q")
+    R, I = p.shape
+    Rq, J = q.shape
+    if R != Rq:
+        raise ValueError(f"gemm_tn: row mismatch {R} vs {Rq}")
+    if out is None:
+        out = torch.empty(I, J, dtype=BF16, device=p.device)
+    _chk2d(out, "out")
+    hip.call("rv_gemm_tn_bf16", p, p.stride(0), q, q.stride(0), out, out.stride(0), R, I, J, residual,
+             residual.stride(0) if residual is not None else 0, float(alpha))
+    return out
+
+
 def gemm_nt_f32(a, b, variant: int = -1) -> torch.Tensor:
     _chk2d(a, "a"), _chk2d(b, "b")
     out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)

@@ -109,6 +109,36 @@ def test_gemm_pingpong_large(ops, M, N, K, v):
         assert torch.equal(ops.gemm_nt(a, b, variant=v), out)
 
 
+@pytest.mark.parametrize("R,I,J", [(32, 256, 256), (64, 512, 264), (100, 136, 520), (1000, 768, 256), (4096, 1024, 2048),
+                                   (7, 8, 8)])
+def test_gemm_tn(ops, R, I, J):
+    """dW = dY^T X through the transposing-LDS-read kernel: ragged R (zero-row redirect), ragged I / J."""
+    dev = _dev()
+    p, q = rnd(R, I, seed=21, dev=dev, scale=0.5), rnd(R, J, seed=22, dev=dev, scale=0.5)
+    out = ops.gemm_tn(p, q)
+    close(out, p.float().t() @ q.float(), what=f"gemm_tn {R}x{I}x{J}")
+    # identical to the explicit-transpose + NT path (same accumulation order when R % 32 == 0)
+    ref = ops.gemm_nt(ops.transpose(p), ops.transpose(q))
+    close(out, ref, rel=4e-3, what="gemm_tn vs transpose+nt")
+    res = rnd(I, J, seed=23, dev=dev)
+    out2 = ops.gemm_tn(p, q, residual=res, alpha=0.5)
+    close(out2, 0.5 * (p.float().t() @ q.float()) + res.float(), what="gemm_tn epilogue")
+    for _ in range(2):
+        assert torch.equal(ops.gemm_tn(p, q), out)
+
+
+def test_gemm_tn_identity_asymmetric(ops):
+    dev = _dev()
+    R = 256
+    p = torch.eye(R, dtype=BF, device=dev)                                   # P[r][i] = delta(r, i)
+    q = (torch.arange(R * 384, device=dev).reshape(R, 384) % 251).to(BF)
+    assert torch.equal(ops.gemm_tn(p, q), q)                                 # out[i][j] = Q[i][j]
+    assert torch.equal(ops.gemm_tn(q, p), q.t().contiguous())                # out[i][j] = Q[j][i]
+    strided = rnd(300, 1024, seed=5, dev=dev)
+    a, b = strided[:, 128:384], strided[:, 512:1024]
+    close(ops.gemm_tn(a, b), a.float().t() @ b.float(), what="gemm_tn strided views")
+
+
 def test_gemm_f32_out(ops):
     dev = _dev()
     a, b = rnd(190, 128, seed=9, dev=dev), rnd(260, 128, seed=10, dev=dev)

@@ -49,6 +49,15 @@ def main():
             res.append(dict(kernel="gemm_nt", name=name, variant=variant, M=M, N=Nn, K=K, ms=ms, tflops=tf))
             print(f"gemm {name:12s} v{variant} {M}x{Nn}x{K}: {ms:8.3f} ms  {tf:8.1f} TF/s", flush=True)
         del a, b, out
+    for name, R, I, J in [("wgrad_qkv", N, 12288, 4096), ("wgrad_gu", N, 22016, 4096), ("wgrad_down", N, 4096, 11008)]:
+        pp = torch.randn(R, I, device=dev).to(BF)
+        qq = torch.randn(R, J, device=dev).to(BF)
+        out = torch.empty(I, J, dtype=BF, device=dev)
+        ms = timeit(lambda: ops.gemm_tn(pp, qq, out=out))
+        ms2 = timeit(lambda: ops.gemm_nt(ops.transpose(pp), ops.transpose(qq), out=out))
+        print(f"gemm_tn {name:11s} {R}x{I}x{J}: {ms:8.3f} ms {2.0 * R * I * J / ms / 1e9:8.1f} TF/s   (transpose x2 + NT: {ms2:.3f} ms)", flush=True)
+        res.append(dict(kernel="gemm_tn", name=name, ms=ms, tflops=2.0 * R * I * J / ms / 1e9, ms_transpose_nt=ms2))
+        del pp, qq, out
     # attention, LLaVA shape
     S, L, H, hd = (8, 2048, 32, 128)
     qkv = torch.randn(S * L, 3 * H * hd, device=dev).to(BF)
