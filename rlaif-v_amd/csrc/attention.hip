@@ -12,6 +12,8 @@
 #include "common.hpp"
 #include "rlaifv_hip.h"
 
+#include <stdlib.h>
+
 namespace {
 
 template <int ROWBYTES>
@@ -32,6 +34,20 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int base) {
 __device__ __forceinline__ void zero16(f32x16_t& a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// MFMA accumulating into AGPRs.  hipcc picks the VGPR form of v_mfma for builtins and, once the kernel needs more
+// than 256 registers, shuttles the accumulators through v_accvgpr_read/write around EVERY MFMA (600+ copies per
+// loop iteration in the dK/dV kernel).  The "a" constraint pins the long-lived accumulators in the accumulator file.
+// s_nop 1 covers a VALU-written (cvt_pk) B operand; consecutive MFMAs on one accumulator need no wait states.
+__device__ __forceinline__ void mfma_agpr(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// acc = 0 produced INSIDE the accumulator file (0 x 0 + 0), so the value never has a VGPR-class definition
+__device__ __forceinline__ void mfma_agpr_zero(f32x16_t& acc) {
+  const bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));
 }
 
 #define LOG2E 1.4426950408889634f
@@ -456,6 +472,191 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
   }  // pass
 }
 
+// =============================================================================================
+// backward, dK/dV, version 2: no pre-transposed copies.
+//   * Q / dO tiles (64 queries x 128, row-major as in HBM) are double-buffered in LDS by global_load_lds
+//     (no staging registers; next tile in flight while the current one is consumed; one barrier per tile);
+//   * the operands whose contraction index is the query (Q^T for dK, dO^T for dV) are read from the SAME tiles
+//     with ds_read_b64_tr_b16, in the order in which P / dS leave the accumulators;
+//   * chunk swizzle c ^ (((row&3)<<2) | ((row>>2)&3)): the 32-row ds_read_b128 pattern sees 16 distinct chunks and
+//     the 4 rows of a transposing read fall into 4 different quarters of the 256-byte bank row;
+//   * lse / delta of the tile arrive through 4-byte LDS-DMA.
+// =============================================================================================
+__device__ __forceinline__ uint32_t qtile_off(int row, int c) {
+  return (uint32_t)(row * 256 + ((c ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4));
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
+                                                               int k_col0, int v_col0,
+                                                               const bf16_t* __restrict__ dO, long lddo,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
+                                                               float scale) {
+  constexpr int HD = 128, KS = 8, ET = 4;
+  constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64]
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, s = blockIdx.z;
+  const long tok0 = (long)s * L;
+  const int nkb = (L + 127) / 128;
+  const float c = scale * LOG2E;
+  const float* lse_base = lse + ((long)s * H + h) * L;
+  const float* delta_base = delta + ((long)s * H + h) * L;
+
+  // LDS-DMA assignment: each wave fills 4 pieces (4 rows x 256 B) of Q and of dO per tile; wave 0 also lse/delta
+  int d_row[4], d_chunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d_row[i] = (wave * 4 + i) * 4 + (lane >> 4);
+    d_chunk[i] = (lane & 15) ^ (((d_row[i] & 3) << 2) | ((d_row[i] >> 2) & 3));
+  }
+  auto issue_tile = [&](int t, int buf) {
+    uint8_t* st = smem + buf * STAGE;
+    const int qs0 = t * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long tk = tok0 + min(qs0 + d_row[i], L - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(qkv + tk * ld + q_col0 + h * HD + d_chunk[i] * 8),
+          (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(dO + tk * lddo + h * HD + d_chunk[i] * 8),
+          (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+    if (wave == 0) {
+      const int qq = min(qs0 + lane, L - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse_base + qq),
+                                       (__attribute__((address_space(3))) void*)(st + 32768), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta_base + qq),
+                                       (__attribute__((address_space(3))) void*)(st + 32768 + 256), 4, 0, 0);
+    }
+  };
+
+  // ---- per-lane LDS offsets, hoisted so the loops only add compile-time constants (the XOR swizzle defeats
+  // the compiler's immediate-offset folding and it would otherwise keep ~100 address VGPRs alive)
+  // row-operand reads (ds_read_b128): row = qt*32 + fr (+8192 per qt), chunk 2*ks + half
+  uint32_t boff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) boff[ks] = qtile_off(fr, 2 * ks + half);
+  // transposing reads: row = qt*32 + 16*k2 + 8u + 4*(g4>>1) + (s16>>2); column e = et*32 + 16*(g4&1) + 4*(s16&3)
+  const int g4 = lane >> 4, s16 = lane & 15;
+  uint32_t toff[2][ET];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+      toff[u][et] = qtile_off(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
+                    (uint32_t)((s16 & 1) * 8);
+  auto tr8 = [&](const uint8_t* tile, int row0, int et) -> bf16x8_t {   // row0 = qt*32 + k2*16 (multiple of 16)
+    typedef __attribute__((ext_vector_type(4))) short s4_t;
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s4_t*)(tile + toff[0][et] + row0 * 256));
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s4_t*)(tile + toff[1][et] + row0 * 256));
+    bf16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+  };
+
+  const int npass = CAUSAL ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int kvb = (pass == 0) ? (int)blockIdx.x : (nkb - 1 - (int)blockIdx.x);
+    if (pass == 1 && kvb <= (int)blockIdx.x) break;
+    const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
+    const int key = kv0w + fr, keyc = min(key, L - 1);
+
+    bf16x8_t kf[KS], vf[KS];
+    {
+      const bf16_t* kp = qkv + (tok0 + keyc) * ld + h * HD + 8 * half;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *(const bf16x8_t*)(kp + k_col0 + 16 * ks);
+        vf[ks] = *(const bf16x8_t*)(kp + v_col0 + 16 * ks);
+      }
+    }
+    f32x16_t dk[ET], dv[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) { mfma_agpr_zero(dk[e]); mfma_agpr_zero(dv[e]); }
+
+    const int t_begin = CAUSAL ? (kv0 / 64) : 0;
+    const int nt = (L + 63) / 64;
+    issue_tile(t_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = t_begin; t < nt; ++t) {
+      const int buf = (t - t_begin) & 1;
+      const uint8_t* Qs = smem + buf * STAGE;
+      const uint8_t* dOs = Qs + 16384;
+      const float* lse_s = (const float*)(Qs + 32768);
+      const float* delta_s = lse_s + 64;
+      const int qs0 = t * 64;
+      if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
+
+      if (!(CAUSAL && qs0 + 63 < kv0w)) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          f32x16_t sacc, pacc;
+          zero16(sacc);
+          zero16(pacc);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t qf = *(const bf16x8_t*)(Qs + boff[ks] + qt * 8192);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sacc, 0, 0, 0);
+            const bf16x8_t df = *(const bf16x8_t*)(dOs + boff[ks] + qt * 8192);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], pacc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int qg = qs0 + ql;
+            float p = exp2f(sacc[r] * c - lse_s[ql] * LOG2E);
+            if (qg >= L || key >= L || (CAUSAL && key > qg)) p = 0.f;
+            sacc[r] = p;
+            pacc[r] = p * (pacc[r] - delta_s[ql]);
+          }
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const bf16x8_t pf = pack_frag(sacc, k2 * 8);
+            const bf16x8_t dsf = pack_frag(pacc, k2 * 8);
+            const int row0 = qt * 32 + k2 * 16;
+#pragma unroll
+            for (int e = 0; e < ET; ++e) {
+              mfma_agpr(dv[e], tr8(dOs, row0, e), pf);
+              mfma_agpr(dk[e], tr8(Qs, row0, e), dsf);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
+
+    if (key < L) {
+      bf16_t* kp = dqkv + (tok0 + key) * lddq + h * HD;
+#pragma unroll
+      for (int e = 0; e < ET; ++e)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          uint2 w;
+          w.x = pack2bf(dk[e][rg * 4 + 0] * scale, dk[e][rg * 4 + 1] * scale);
+          w.y = pack2bf(dk[e][rg * 4 + 2] * scale, dk[e][rg * 4 + 3] * scale);
+          *(uint2*)(kp + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
+          w.x = pack2bf(dv[e][rg * 4 + 0], dv[e][rg * 4 + 1]);
+          w.y = pack2bf(dv[e][rg * 4 + 2], dv[e][rg * 4 + 3]);
+          *(uint2*)(kp + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
+        }
+    }
+  }  // pass
+}
+
 }  // namespace
 
 extern "C" {
@@ -490,28 +691,43 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   dim3 grid(causal ? (nb + 1) / 2 : nb, H, S), block(256);
   hipStream_t st = (hipStream_t)stream;
   constexpr int DKV_LDS = 2 * 64 * 256 + 2 * 128 * 128 + 512;
+  constexpr int DKV2_LDS = 2 * (2 * 64 * 256 + 512);
   static bool attr_done = false;
+  static int dkv_version = 2;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS);
+    const char* e = getenv("RV_ATTN_DKV");       // 1 = pre-transposed-copy kernel (needs qt / dOt), 2 = tr-read kernel
+    if (e && e[0] == '1') dkv_version = 1;
     attr_done = true;
   }
+  RV_REQUIRE(dkv_version == 2 || (qt != nullptr && dOt != nullptr), "rv_attn_bwd: qt / dOt required for RV_ATTN_DKV=1");
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), grid, block, 0, st, (const bf16_t*)qkv, ld, q_col0, k_col0,
                        v_col0, (const bf16_t*)kt, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, Lp, H,
                        scale);
     RV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), grid, block, DKV_LDS, st, (const bf16_t*)qkv, ld, q_col0,
-                       k_col0, v_col0, (const bf16_t*)qt, (const bf16_t*)dO, lddo, (const bf16_t*)dOt, lse, delta,
-                       (bf16_t*)dqkv, lddq, L, Lp, H, scale);
+    if (dkv_version == 2)
+      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid, block, DKV2_LDS, st, (const bf16_t*)qkv, ld, q_col0,
+                         k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, scale);
+    else
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), grid, block, DKV_LDS, st, (const bf16_t*)qkv, ld, q_col0,
+                         k_col0, v_col0, (const bf16_t*)qt, (const bf16_t*)dO, lddo, (const bf16_t*)dOt, lse, delta,
+                         (bf16_t*)dqkv, lddq, L, Lp, H, scale);
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), grid, block, 0, st, (const bf16_t*)qkv, ld, q_col0, k_col0,
                        v_col0, (const bf16_t*)kt, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, Lp, H,
                        scale);
     RV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, false>), grid, block, DKV_LDS, st, (const bf16_t*)qkv, ld, q_col0,
-                       k_col0, v_col0, (const bf16_t*)qt, (const bf16_t*)dO, lddo, (const bf16_t*)dOt, lse, delta,
-                       (bf16_t*)dqkv, lddq, L, Lp, H, scale);
+    if (dkv_version == 2)
+      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid, block, DKV2_LDS, st, (const bf16_t*)qkv, ld, q_col0,
+                         k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, scale);
+    else
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, false>), grid, block, DKV_LDS, st, (const bf16_t*)qkv, ld, q_col0,
+                         k_col0, v_col0, (const bf16_t*)qt, (const bf16_t*)dO, lddo, (const bf16_t*)dOt, lse, delta,
+                         (bf16_t*)dqkv, lddq, L, Lp, H, scale);
   }
   RV_CHECK_LAUNCH();
   return 0;
