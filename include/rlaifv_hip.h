@@ -73,23 +73,19 @@ int rv_dpo_loss(const float* seq_sum, const float* seq_cnt, const float* ref_win
 int rv_row_coef(const float* coef, const int* seq_of_row, const float* weight, float* out, int n, void* stream);
 
 /* ---- attention (replaces HF LlamaAttention eager/SDPA math and CLIPAttention).
- *   qkv: [S*L][ld] with q heads at q_col0 + h*hd, k heads at k_col0 + h*hd; vt = rv_head_transpose of V.
+ *   qkv: [S*L][ld] with q heads at q_col0 + h*hd, k heads at k_col0 + h*hd, v heads at v_col0 + h*hd.
  *   out: [S*L][ldo] (head h at column h*hd); lse: [S][H][L] natural-log of sum exp(scale * q.k).
- *   causal=1: pure causal mask, no padding mask (muffin/train/trainers.py:199). hd in {64,128}. */
-int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, const void* vt, void* out, long ldo, float* lse,
-                int S, int L, int H, int hd, int causal, float scale, void* stream);
-/* backward (hd = 128): qt/kt/dOt are rv_head_transpose copies of Q, K, dO; delta = rv_attn_delta.
- * Writes dQ, dK, dV into dqkv at the same column offsets as qkv. */
-int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* qt, const void* kt,
-                const void* dO, long lddo, const void* dOt, const float* lse, const float* delta, void* dqkv,
-                long lddq, int S, int L, int H, int hd, int causal, float scale, void* stream);
+ *   causal=1: pure causal mask, no padding mask (muffin/train/trainers.py:199). hd in {64,128}.
+ *   K/V tiles are staged by LDS-DMA and transposed on the fly (ds_read_b64_tr_b16): no side copies. */
+int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
+                int L, int H, int hd, int causal, float scale, void* stream);
+/* backward (hd = 128): delta = rv_attn_delta(dO, O).  Writes dQ, dK, dV into dqkv at the column offsets of
+ * qkv.  Deterministic (no atomics): one kernel per 128-query block for dQ, one per 128-key block for dK/dV. */
+int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
+                const float* lse, const float* delta, void* dqkv, long lddq, int S, int L, int H, int hd, int causal,
+                float scale, void* stream);
 int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
                   void* stream);
-/* Row stride Lp (elements) of the transposed copies: roundup(L,64), +64 when that is a multiple of 512. */
-int rv_attn_lp(int L);
-/* X[(s*L+l)][col0 + h*hd + e] -> XT[s][h][e][Lp], Lp = rv_attn_lp(L), positions >= L up to roundup(L,64) zero; positions inside every
- * aligned group of 16 stored with 4-element chunks 1 and 2 swapped (MFMA accumulator order). */
-int rv_head_transpose(const void* x, long ld, int col0, void* xt, int S, int L, int H, int hd, void* stream);
 
 /* ---- norms / rotary / activations (replace HF LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP, CLIP LayerNorm) */
 int rv_rmsnorm_fwd(const void* x, long ldx, const int* row_idx, const void* w, void* y, long ldy, float* rstd,

@@ -5,22 +5,16 @@
 //  * every MFMA is issued so that the per-lane "column" index j = lane&31 is the row the wave owns
 //    (a query in fwd / dQ, a key in dK/dV).  Softmax statistics are then per-lane scalars.
 //  * a B operand taken straight from 32x32 accumulators enumerates its contraction index inside each
-//    group of 16 as {0-3, 8-11 | 4-7, 12-15}; the matching A operand comes from a PRE-TRANSPOSED,
-//    chunk-swapped copy (rv_head_transpose) so that it is a single 16-byte LDS read.
-//  * LDS tiles are XOR-swizzled per 16-byte chunk so that ds_read_b128 of "32 rows x same chunk" is
-//    bank-conflict free: 256-byte rows use chunk ^ (row & 15); 128-byte rows use chunk ^ ((row >> 1) & 7).
+//    group of 16 as {0-3, 8-11 | 4-7, 12-15}; the matching A operand (V^T, K^T, Q^T, dO^T) is read from the
+//    row-major tile with ds_read_b64_tr_b16 in exactly that order - no transposed copies exist in HBM.
+//  * K/V (or Q/dO) tiles are double-buffered in LDS by global_load_lds; XOR chunk swizzles keep both the
+//    32-row ds_read_b128 pattern and the 4-row transposing reads bank-conflict free.
 #include "common.hpp"
 #include "rlaifv_hip.h"
 
 #include <stdlib.h>
 
 namespace {
-
-template <int ROWBYTES>
-__device__ __forceinline__ uint32_t tile_off(int row, int c) {
-  if (ROWBYTES == 256) return (uint32_t)(row * 256 + ((c ^ (row & 15)) << 4));
-  return (uint32_t)(row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-}
 
 __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& a, int base) {
   union { uint32_t u[4]; bf16x8_t v; } r;
@@ -54,421 +48,308 @@ __device__ __forceinline__ void mfma_agpr_zero(f32x16_t& acc) {
 #define LN2 0.6931471805599453f
 
 // =============================================================================================
-// forward
+// Version-2 forward and dQ kernels: K / V tiles (64 keys, row-major as in HBM) double-buffered in LDS by
+// global_load_lds, and the key-contracted operand (V^T in forward, K^T in dQ) read from the same tiles by
+// ds_read_b64_tr_b16 - no rv_head_transpose copies are needed any more.
+// Row-operand reads are ds_read_b128 (32 rows x one chunk); chunk swizzles (see qtile_off for 256-byte rows):
+//   128-byte rows (head dim 64): chunk ^ f(row), f = ((x&1)<<2)|(x>>1) with x = (row>>1)&7.
 // =============================================================================================
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
-                                                          int k_col0, const bf16_t* __restrict__ vt,
-                                                          bf16_t* __restrict__ out, long ldo,
-                                                          float* __restrict__ lse, int L, int Lp, int H,
-                                                          float scale) {
-  constexpr int KS = HD / 16;        // k-steps of the QK^T contraction
-  constexpr int ET = HD / 32;        // 32-row tiles of the output head dim
-  constexpr int KROW = HD * 2;       // bytes per K row in LDS
-  constexpr int KCPR = HD / 8;       // 16-byte chunks per K row
-  constexpr int NCH_K = 64 * KCPR / 256;   // K chunks per thread
-  constexpr int NCH_V = HD * 8 / 256;      // V^T chunks per thread
-  __shared__ __attribute__((aligned(16))) uint8_t smem[64 * KROW + HD * 128];
-  uint8_t* Ks = smem;
-  uint8_t* Vs = smem + 64 * KROW;
+template <int HD>
+__device__ __forceinline__ uint32_t kvtile_off(int row, int c) {
+  if (HD == 128) return (uint32_t)(row * 256 + ((c ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4));
+  const int x = (row >> 1) & 7;
+  return (uint32_t)(row * 128 + ((c ^ (((x & 1) << 2) | (x >> 1))) << 4));
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// lane constants of the transposing reads over a [64 rows][HD] tile (rows = contraction index)
+template <int HD>
+struct TrOffsets {
+  uint32_t off[2][HD / 32];
+  __device__ __forceinline__ void init(int lane) {
+    const int g4 = lane >> 4, s16 = lane & 15;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int et = 0; et < HD / 32; ++et)
+        off[u][et] = kvtile_off<HD>(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
+                     (uint32_t)((s16 & 1) * 8);
+  }
+  // 8 contraction rows row0 + {4*half + 0..3, 8 + 4*half + 0..3} of column et*32 + (lane&31); row0 % 16 == 0
+  __device__ __forceinline__ bf16x8_t read(const uint8_t* tile, int row0, int et) const {
+    typedef __attribute__((ext_vector_type(4))) short s4_t;
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s4_t*)(tile + off[0][et] + row0 * (HD * 2)));
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s4_t*)(tile + off[1][et] + row0 * (HD * 2)));
+    bf16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+  }
+};
+
+// LDS-DMA of a [64 rows][HD] tile: 64*HD*2/1024 pieces of 1 KiB, split over the 4 waves
+template <int HD>
+struct TileDma {
+  static constexpr int NP = 64 * HD * 2 / 1024 / 4;       // pieces per wave (4 for HD 128, 2 for HD 64)
+  static constexpr int RPP = 1024 / (HD * 2);             // rows per piece (4 / 8)
+  static constexpr int CPR = HD / 8;                      // 16-byte chunks per row
+  int row[NP], col[NP];
+  __device__ __forceinline__ void init(int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      row[i] = (wave * NP + i) * RPP + lane / CPR;
+      const int cp = lane % CPR;                           // chunk position in the LDS row
+      // inverse of the read swizzle (an involution): source chunk = cp ^ f(row)
+      col[i] = (int)((kvtile_off<HD>(row[i], cp) - (uint32_t)(row[i] * HD * 2)) >> 4) * 8;
+    }
+  }
+  __device__ __forceinline__ void issue(const bf16_t* base, long ld, long tok0, int r0, int L, uint8_t* dst, int wave) const {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(base + (tok0 + min(r0 + row[i], L - 1)) * ld + col[i]),
+          (__attribute__((address_space(3))) void*)(dst + (wave * NP + i) * 1024), 16, 0, 0);
+  }
+};
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
+                                                           int k_col0, int v_col0, bf16_t* __restrict__ out, long ldo,
+                                                           float* __restrict__ lse, int L, int H, float scale) {
+  constexpr int KS = HD / 16, ET = HD / 32, TILE = 64 * HD * 2, STAGE = 2 * TILE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, half = lane >> 5;
   const int nqb = (L + 127) / 128;
   const int h = blockIdx.y, s = blockIdx.z;
   const long tok0 = (long)s * L;
-  // Causal work grows with the query block index and the dispatcher hands block b to CU b % 256, so a CU would
-  // always draw the same index; each workgroup therefore processes the PAIR (x, nqb-1-x): equal work everywhere.
+  const float c = scale * LOG2E;
+
+  TileDma<HD> dma;
+  dma.init(wave, lane);
+  TrOffsets<HD> tro;
+  tro.init(lane);
+  uint32_t boff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) boff[ks] = kvtile_off<HD>(fr, 2 * ks + half);
+  const bf16_t* kbase = qkv + k_col0 + h * HD;
+  const bf16_t* vbase = qkv + v_col0 + h * HD;
+
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int qb = (pass == 0) ? (int)blockIdx.x : (nqb - 1 - (int)blockIdx.x);
-  if (pass == 1 && qb <= (int)blockIdx.x) break;
-  const int q0 = qb * 128, q0w = q0 + wave * 32;
-  const int q = q0w + fr;
+    const int qb = (pass == 0) ? (int)blockIdx.x : (nqb - 1 - (int)blockIdx.x);
+    if (pass == 1 && qb <= (int)blockIdx.x) break;
+    const int q0 = qb * 128, q0w = q0 + wave * 32;
+    const int q = q0w + fr;
 
-  // Q fragments (B operand): Q[q][16*ks + 8*half .. +7]
-  bf16x8_t qf[KS];
-  {
-    const bf16_t* qp = qkv + (tok0 + min(q, L - 1)) * ld + q_col0 + h * HD + 8 * half;
+    bf16x8_t qf[KS];
+    {
+      const bf16_t* qp = qkv + (tok0 + min(q, L - 1)) * ld + q_col0 + h * HD + 8 * half;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qp + 16 * ks);
-  }
-
-  f32x16_t o[ET];
-#pragma unroll
-  for (int e = 0; e < ET; ++e) zero16(o[e]);
-  float m_run = -INFINITY, l_run = 0.f;
-  const float c = scale * LOG2E;
-
-  const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
-  const int nt = (kv_end + 63) / 64;
-  const bf16_t* vt_base = vt + ((long)(s * H + h) * HD) * Lp;
-
-  u32x4_t pk[NCH_K], pv[NCH_V];
-  auto prefetch = [&](int t) {
-    const int k0 = t * 64;
-#pragma unroll
-    for (int i = 0; i < NCH_K; ++i) {
-      const int ch = tid + i * 256, row = ch / KCPR, cc = ch % KCPR;
-      pk[i] = *(const u32x4_t*)(qkv + (tok0 + min(k0 + row, L - 1)) * ld + k_col0 + h * HD + cc * 8);
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qp + 16 * ks);
     }
+    f32x16_t o[ET];
 #pragma unroll
-    for (int i = 0; i < NCH_V; ++i) {
-      const int ch = tid + i * 256, row = ch >> 3, cc = ch & 7;
-      pv[i] = *(const u32x4_t*)(vt_base + (long)row * Lp + k0 + cc * 8);
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < NCH_K; ++i) {
-      const int ch = tid + i * 256, row = ch / KCPR, cc = ch % KCPR;
-      *(u32x4_t*)(Ks + tile_off<KROW>(row, cc)) = pk[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NCH_V; ++i) {
-      const int ch = tid + i * 256, row = ch >> 3, cc = ch & 7;
-      *(u32x4_t*)(Vs + tile_off<128>(row, cc)) = pv[i];
-    }
-  };
+    for (int e = 0; e < ET; ++e) zero16(o[e]);
+    float m_run = -INFINITY, l_run = 0.f;
 
-  prefetch(0);
-  for (int t = 0; t < nt; ++t) {
-    const int k0 = t * 64;
+    const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
+    const int nt = (kv_end + 63) / 64;
+    dma.issue(kbase, ld, tok0, 0, L, smem, wave);
+    dma.issue(vbase, ld, tok0, 0, L, smem + TILE, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    commit();
-    __syncthreads();
-    if (t + 1 < nt) prefetch(t + 1);
-    if (CAUSAL && k0 > q0w + 31) continue;   // wave-uniform: whole tile above this wave's diagonal
 
-    f32x16_t sacc[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      zero16(sacc[kt]);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Ks + tile_off<KROW>(kt * 32 + fr, 2 * ks + half));
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+    for (int t = 0; t < nt; ++t) {
+      const int k0 = t * 64;
+      const uint8_t* Ks = smem + (t & 1) * STAGE;
+      const uint8_t* Vs = Ks + TILE;
+      if (t + 1 < nt) {
+        dma.issue(kbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE, wave);
+        dma.issue(vbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE + TILE, wave);
       }
+      if (!(CAUSAL && k0 > q0w + 31)) {
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          zero16(sacc[kt]);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t kf = *(const bf16x8_t*)(Ks + boff[ks] + kt * 32 * HD * 2);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+          }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = sacc[kt][r] * c;
+            if (key >= L || (CAUSAL && key > q)) v = -INFINITY;
+            sacc[kt][r] = v;
+            tmax = fmaxf(tmax, v);
+          }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(sacc[kt][r] - m_new);
+            sacc[kt][r] = p;
+            psum += p;
+          }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < ET; ++e)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8_t pf = pack_frag(sacc[kk >> 1], (kk & 1) * 8);
+#pragma unroll
+          for (int e = 0; e < ET; ++e)
+            o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tro.read(Vs, kk * 16, e), pf, o[e], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    // scale to log2 domain, mask, tile max
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = sacc[kt][r] * c;
-        if (key >= L || (CAUSAL && key > q)) v = -INFINITY;
-        sacc[kt][r] = v;
-        tmax = fmaxf(tmax, v);
-      }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f(m_run - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(sacc[kt][r] - m_new);
-        sacc[kt][r] = p;
-        psum += p;
-      }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int e = 0; e < ET; ++e)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
-    // O^T[e][q] += V^T[e][key] * P^T[key][q]
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8_t pf = pack_frag(sacc[kk >> 1], (kk & 1) * 8);
-#pragma unroll
-      for (int e = 0; e < ET; ++e) {
-        const bf16x8_t vf = *(const bf16x8_t*)(Vs + tile_off<128>(e * 32 + fr, 2 * kk + half));
-        o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[e], 0, 0, 0);
-      }
-    }
-  }
 
-  if (q < L) {
-    const float inv = 1.f / l_run;
-    bf16_t* op = out + (tok0 + q) * ldo + h * HD;
+    if (q < L) {
+      const float inv = 1.f / l_run;
+      bf16_t* op = out + (tok0 + q) * ldo + h * HD;
 #pragma unroll
-    for (int e = 0; e < ET; ++e)
+      for (int e = 0; e < ET; ++e)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        uint2 w;
-        w.x = pack2bf(o[e][rg * 4 + 0] * inv, o[e][rg * 4 + 1] * inv);
-        w.y = pack2bf(o[e][rg * 4 + 2] * inv, o[e][rg * 4 + 3] * inv);
-        *(uint2*)(op + e * 32 + rg * 8 + 4 * half) = w;
-      }
-    if (half == 0) lse[((long)s * H + h) * L + q] = (m_run + log2f(l_run)) * LN2;
-  }
-  __syncthreads();   // LDS tiles are reused by the second pass
+        for (int rg = 0; rg < 4; ++rg) {
+          uint2 w;
+          w.x = pack2bf(o[e][rg * 4 + 0] * inv, o[e][rg * 4 + 1] * inv);
+          w.y = pack2bf(o[e][rg * 4 + 2] * inv, o[e][rg * 4 + 3] * inv);
+          *(uint2*)(op + e * 32 + rg * 8 + 4 * half) = w;
+        }
+      if (half == 0) lse[((long)s * H + h) * L + q] = (m_run + log2f(l_run)) * LN2;
+    }
   }  // pass
 }
 
-// =============================================================================================
-// backward, dQ:   one workgroup = 128 queries (32 per wave), loop over 64-key tiles
-//   S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T
-// =============================================================================================
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
-                                                             int k_col0, int v_col0,
-                                                             const bf16_t* __restrict__ kt_,   // K^T swz [S][H][HD][Lp]
-                                                             const bf16_t* __restrict__ dO, long lddo,
-                                                             const float* __restrict__ lse,
-                                                             const float* __restrict__ delta,
-                                                             bf16_t* __restrict__ dqkv, long lddq, int L, int Lp,
-                                                             int H, float scale) {
-  constexpr int KS = HD / 16, ET = HD / 32, KROW = HD * 2, KCPR = HD / 8;
-  constexpr int NCH = 64 * KCPR / 256;
-  constexpr int NCH_T = HD * 8 / 256;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 64 * KROW + HD * 128];
-  uint8_t* Ks = smem;
-  uint8_t* Vs = smem + 64 * KROW;
-  uint8_t* KTs = smem + 2 * 64 * KROW;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
+                                                              int k_col0, int v_col0, const bf16_t* __restrict__ dO,
+                                                              long lddo, const float* __restrict__ lse,
+                                                              const float* __restrict__ delta,
+                                                              bf16_t* __restrict__ dqkv, long lddq, int L, int H,
+                                                              float scale) {
+  constexpr int HD = 128, KS = 8, ET = 4, TILE = 64 * HD * 2, STAGE = 2 * TILE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, half = lane >> 5;
   const int nqb = (L + 127) / 128;
   const int h = blockIdx.y, s = blockIdx.z;
   const long tok0 = (long)s * L;
-  const int npass = CAUSAL ? 2 : 1;      // pair (x, nqb-1-x): see attn_fwd_kernel
-  for (int pass = 0; pass < npass; ++pass) {
-  const int qb = (pass == 0) ? (int)blockIdx.x : (nqb - 1 - (int)blockIdx.x);
-  if (pass == 1 && qb <= (int)blockIdx.x) break;
-  const int q0 = qb * 128, q0w = q0 + wave * 32;
-  const int q = q0w + fr, qc = min(q, L - 1);
-
-  bf16x8_t qf[KS], dof[KS];
-  {
-    const bf16_t* qp = qkv + (tok0 + qc) * ld + q_col0 + h * HD + 8 * half;
-    const bf16_t* dp = dO + (tok0 + qc) * lddo + h * HD + 8 * half;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qf[ks] = *(const bf16x8_t*)(qp + 16 * ks);
-      dof[ks] = *(const bf16x8_t*)(dp + 16 * ks);
-    }
-  }
-  const float lse_q = lse[((long)s * H + h) * L + qc] * LOG2E;
-  const float delta_q = delta[((long)s * H + h) * L + qc];
   const float c = scale * LOG2E;
 
-  f32x16_t dq[ET];
+  TileDma<HD> dma;
+  dma.init(wave, lane);
+  TrOffsets<HD> tro;
+  tro.init(lane);
+  uint32_t boff[KS];
 #pragma unroll
-  for (int e = 0; e < ET; ++e) zero16(dq[e]);
+  for (int ks = 0; ks < KS; ++ks) boff[ks] = kvtile_off<HD>(fr, 2 * ks + half);
+  const bf16_t* kbase = qkv + k_col0 + h * HD;
+  const bf16_t* vbase = qkv + v_col0 + h * HD;
 
-  const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
-  const int nt = (kv_end + 63) / 64;
-  const bf16_t* kt_base = kt_ + ((long)(s * H + h) * HD) * Lp;
-
-  for (int t = 0; t < nt; ++t) {
-    const int k0 = t * 64;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int ch = tid + i * 256, row = ch / KCPR, cc = ch % KCPR;
-      const bf16_t* src = qkv + (tok0 + min(k0 + row, L - 1)) * ld + h * HD + cc * 8;
-      *(u32x4_t*)(Ks + tile_off<KROW>(row, cc)) = *(const u32x4_t*)(src + k_col0);
-      *(u32x4_t*)(Vs + tile_off<KROW>(row, cc)) = *(const u32x4_t*)(src + v_col0);
-    }
-#pragma unroll
-    for (int i = 0; i < NCH_T; ++i) {
-      const int ch = tid + i * 256, row = ch >> 3, cc = ch & 7;
-      *(u32x4_t*)(KTs + tile_off<128>(row, cc)) = *(const u32x4_t*)(kt_base + (long)row * Lp + k0 + cc * 8);
-    }
-    __syncthreads();
-    if (CAUSAL && k0 > q0w + 31) continue;
-
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      f32x16_t sacc, pacc;
-      zero16(sacc);
-      zero16(pacc);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Ks + tile_off<KROW>(kt * 32 + fr, 2 * ks + half));
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
-        const bf16x8_t vf = *(const bf16x8_t*)(Vs + tile_off<KROW>(kt * 32 + fr, 2 * ks + half));
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float p = exp2f(sacc[r] * c - lse_q);
-        if (key >= L || (CAUSAL && key > q)) p = 0.f;
-        sacc[r] = p * (pacc[r] - delta_q);   // dS^T
-      }
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const int kk = kt * 2 + k2;
-        const bf16x8_t df = pack_frag(sacc, k2 * 8);
-#pragma unroll
-        for (int e = 0; e < ET; ++e) {
-          const bf16x8_t kf = *(const bf16x8_t*)(KTs + tile_off<128>(e * 32 + fr, 2 * kk + half));
-          dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, df, dq[e], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  if (q < L) {
-    bf16_t* op = dqkv + (tok0 + q) * lddq + q_col0 + h * HD;
-#pragma unroll
-    for (int e = 0; e < ET; ++e)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        uint2 w;
-        w.x = pack2bf(dq[e][rg * 4 + 0] * scale, dq[e][rg * 4 + 1] * scale);
-        w.y = pack2bf(dq[e][rg * 4 + 2] * scale, dq[e][rg * 4 + 3] * scale);
-        *(uint2*)(op + e * 32 + rg * 8 + 4 * half) = w;
-      }
-  }
-  __syncthreads();
-  }  // pass
-}
-
-// =============================================================================================
-// backward, dK/dV:  one workgroup = 128 keys (32 per wave), loop over 64-query tiles
-//   S = Q K^T, dP = dO V^T, P, dS;   dV^T += dO^T P,   dK^T += Q^T dS
-// Register heavy (two 32x128 fp32 accumulators + K/V fragments): runs one wave per SIMD.
-// =============================================================================================
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
-                                                              int k_col0, int v_col0,
-                                                              const bf16_t* __restrict__ qt_,    // Q^T swz
-                                                              const bf16_t* __restrict__ dO, long lddo,
-                                                              const bf16_t* __restrict__ dot_,   // dO^T swz
-                                                              const float* __restrict__ lse,
-                                                              const float* __restrict__ delta,
-                                                              bf16_t* __restrict__ dqkv, long lddq, int L, int Lp,
-                                                              int H, float scale) {
-  constexpr int KS = HD / 16, ET = HD / 32, KROW = HD * 2, KCPR = HD / 8;
-  constexpr int NCH = 64 * KCPR / 256;
-  constexpr int NCH_T = HD * 8 / 256;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* Qs = smem;
-  uint8_t* dOs = smem + 64 * KROW;
-  uint8_t* QTs = smem + 2 * 64 * KROW;
-  uint8_t* dOTs = QTs + HD * 128;
-  float* lse_s = (float*)(dOTs + HD * 128);
-  float* delta_s = lse_s + 64;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 31, half = lane >> 5;
-  const int h = blockIdx.y, s = blockIdx.z;
-  const long tok0 = (long)s * L;
-  const int nkb = (L + 127) / 128;
-  const int npass = CAUSAL ? 2 : 1;      // pair (x, nkb-1-x): see attn_fwd_kernel
+  const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int kvb = (pass == 0) ? (int)blockIdx.x : (nkb - 1 - (int)blockIdx.x);
-  if (pass == 1 && kvb <= (int)blockIdx.x) break;
-  const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
-  const int key = kv0w + fr, keyc = min(key, L - 1);
+    const int qb = (pass == 0) ? (int)blockIdx.x : (nqb - 1 - (int)blockIdx.x);
+    if (pass == 1 && qb <= (int)blockIdx.x) break;
+    const int q0 = qb * 128, q0w = q0 + wave * 32;
+    const int q = q0w + fr, qc = min(q, L - 1);
 
-  bf16x8_t kf[KS], vf[KS];
-  {
-    const bf16_t* kp = qkv + (tok0 + keyc) * ld + h * HD + 8 * half;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      kf[ks] = *(const bf16x8_t*)(kp + k_col0 + 16 * ks);
-      vf[ks] = *(const bf16x8_t*)(kp + v_col0 + 16 * ks);
-    }
-  }
-  const float c = scale * LOG2E;
-  f32x16_t dk[ET], dv[ET];
-#pragma unroll
-  for (int e = 0; e < ET; ++e) { zero16(dk[e]); zero16(dv[e]); }
-
-  const int t_begin = CAUSAL ? (kv0 / 64) : 0;
-  const int nt = (L + 63) / 64;
-  const bf16_t* qt_base = qt_ + ((long)(s * H + h) * HD) * Lp;
-  const bf16_t* dot_base = dot_ + ((long)(s * H + h) * HD) * Lp;
-  const float* lse_base = lse + ((long)s * H + h) * L;
-  const float* delta_base = delta + ((long)s * H + h) * L;
-
-  for (int t = t_begin; t < nt; ++t) {
-    const int qs0 = t * 64;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int ch = tid + i * 256, row = ch / KCPR, cc = ch % KCPR;
-      const long tk = tok0 + min(qs0 + row, L - 1);
-      *(u32x4_t*)(Qs + tile_off<KROW>(row, cc)) = *(const u32x4_t*)(qkv + tk * ld + q_col0 + h * HD + cc * 8);
-      *(u32x4_t*)(dOs + tile_off<KROW>(row, cc)) = *(const u32x4_t*)(dO + tk * lddo + h * HD + cc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < NCH_T; ++i) {
-      const int ch = tid + i * 256, row = ch >> 3, cc = ch & 7;
-      *(u32x4_t*)(QTs + tile_off<128>(row, cc)) = *(const u32x4_t*)(qt_base + (long)row * Lp + qs0 + cc * 8);
-      *(u32x4_t*)(dOTs + tile_off<128>(row, cc)) = *(const u32x4_t*)(dot_base + (long)row * Lp + qs0 + cc * 8);
-    }
-    if (tid < 64) {
-      const int qq = min(qs0 + tid, L - 1);
-      lse_s[tid] = lse_base[qq] * LOG2E;
-      delta_s[tid] = delta_base[qq];
-    }
-    __syncthreads();
-    if (CAUSAL && qs0 + 63 < kv0w) continue;   // every query of the tile precedes this wave's keys
-
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      f32x16_t sacc, pacc;
-      zero16(sacc);
-      zero16(pacc);
+    bf16x8_t qf[KS], dof[KS];
+    {
+      const bf16_t* qp = qkv + (tok0 + qc) * ld + q_col0 + h * HD + 8 * half;
+      const bf16_t* dp = dO + (tok0 + qc) * lddo + h * HD + 8 * half;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t qf = *(const bf16x8_t*)(Qs + tile_off<KROW>(qt * 32 + fr, 2 * ks + half));
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sacc, 0, 0, 0);
-        const bf16x8_t df = *(const bf16x8_t*)(dOs + tile_off<KROW>(qt * 32 + fr, 2 * ks + half));
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], pacc, 0, 0, 0);
-      }
-      // acc[r] <-> query ql = qt*32 + (r&3) + 8*(r>>2) + 4*half (tile-local), key = this lane's key
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int qg = qs0 + ql;
-        float p = exp2f(sacc[r] * c - lse_s[ql]);
-        if (qg >= L || key >= L || (CAUSAL && key > qg)) p = 0.f;
-        sacc[r] = p;
-        pacc[r] = p * (pacc[r] - delta_s[ql]);   // dS
-      }
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const bf16x8_t pf = pack_frag(sacc, k2 * 8);
-        const bf16x8_t dsf = pack_frag(pacc, k2 * 8);
-        const int cch = qt * 4 + k2 * 2 + half;
-#pragma unroll
-        for (int e = 0; e < ET; ++e) {
-          const bf16x8_t dotf = *(const bf16x8_t*)(dOTs + tile_off<128>(e * 32 + fr, cch));
-          dv[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, dv[e], 0, 0, 0);
-          const bf16x8_t qtf = *(const bf16x8_t*)(QTs + tile_off<128>(e * 32 + fr, cch));
-          dk[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk[e], 0, 0, 0);
-        }
+        qf[ks] = *(const bf16x8_t*)(qp + 16 * ks);
+        dof[ks] = *(const bf16x8_t*)(dp + 16 * ks);
       }
     }
-  }
+    const float lse_q = lse[((long)s * H + h) * L + qc] * LOG2E;
+    const float delta_q = delta[((long)s * H + h) * L + qc];
+    f32x16_t dq[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) zero16(dq[e]);
 
-  if (key < L) {
-    bf16_t* kp = dqkv + (tok0 + key) * lddq + h * HD;
-#pragma unroll
-    for (int e = 0; e < ET; ++e)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        uint2 w;
-        w.x = pack2bf(dk[e][rg * 4 + 0] * scale, dk[e][rg * 4 + 1] * scale);
-        w.y = pack2bf(dk[e][rg * 4 + 2] * scale, dk[e][rg * 4 + 3] * scale);
-        *(uint2*)(kp + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
-        w.x = pack2bf(dv[e][rg * 4 + 0], dv[e][rg * 4 + 1]);
-        w.y = pack2bf(dv[e][rg * 4 + 2], dv[e][rg * 4 + 3]);
-        *(uint2*)(kp + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
+    const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
+    const int nt = (kv_end + 63) / 64;
+    dma.issue(kbase, ld, tok0, 0, L, smem, wave);
+    dma.issue(vbase, ld, tok0, 0, L, smem + TILE, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+      const int k0 = t * 64;
+      const uint8_t* Ks = smem + (t & 1) * STAGE;
+      const uint8_t* Vs = Ks + TILE;
+      if (t + 1 < nt) {
+        dma.issue(kbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE, wave);
+        dma.issue(vbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE + TILE, wave);
       }
-  }
-  __syncthreads();
+      if (!(CAUSAL && k0 > q0w + 31)) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          f32x16_t sacc, pacc;
+          zero16(sacc);
+          zero16(pacc);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t kf = *(const bf16x8_t*)(Ks + boff[ks] + kt * 32 * HD * 2);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+            const bf16x8_t vf = *(const bf16x8_t*)(Vs + boff[ks] + kt * 32 * HD * 2);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float p = exp2f(sacc[r] * c - lse_q);
+            if (key >= L || (CAUSAL && key > q)) p = 0.f;
+            sacc[r] = p * (pacc[r] - delta_q);
+          }
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const bf16x8_t df = pack_frag(sacc, k2 * 8);
+#pragma unroll
+            for (int e = 0; e < ET; ++e)
+              dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tro.read(Ks, kt * 32 + k2 * 16, e), df, dq[e], 0, 0, 0);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+
+    if (q < L) {
+      bf16_t* op = dqkv + (tok0 + q) * lddq + q_col0 + h * HD;
+#pragma unroll
+      for (int e = 0; e < ET; ++e)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          uint2 w;
+          w.x = pack2bf(dq[e][rg * 4 + 0] * scale, dq[e][rg * 4 + 1] * scale);
+          w.y = pack2bf(dq[e][rg * 4 + 2] * scale, dq[e][rg * 4 + 3] * scale);
+          *(uint2*)(op + e * 32 + rg * 8 + 4 * half) = w;
+        }
+    }
   }  // pass
 }
 
@@ -661,18 +542,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 
 extern "C" {
 
-int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, const void* vt, void* out, long ldo, float* lse,
-                int S, int L, int H, int hd, int causal, float scale, void* stream) {
+int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
+                int L, int H, int hd, int causal, float scale, void* stream) {
   RV_REQUIRE(hd == 64 || hd == 128, "rv_attn_fwd: head dim must be 64 or 128");
-  RV_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0, "rv_attn_fwd: alignment");
+  RV_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0 && v_col0 % 8 == 0,
+             "rv_attn_fwd: alignment");
   if (S == 0 || L == 0) return 0;
-  const int Lp = rv_lp_stride(L);
   const int nb = (L + 127) / 128;
   dim3 grid(causal ? (nb + 1) / 2 : nb, H, S), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_FWD(HD_, C_)                                                                                    \
-  hipLaunchKernelGGL((attn_fwd_kernel<HD_, C_>), grid, block, 0, st, (const bf16_t*)qkv, ld, q_col0, k_col0,    \
-                     (const bf16_t*)vt, (bf16_t*)out, ldo, lse, L, Lp, H, scale)
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_done = true;
+  }
+#define LAUNCH_FWD(HD_, C_)                                                                                      \
+  hipLaunchKernelGGL((attn_fwd2_kernel<HD_, C_>), grid, block, 4 * 64 * HD_ * 2, st, (const bf16_t*)qkv, ld, q_col0, \
+                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, scale)
   if (hd == 128) { if (causal) LAUNCH_FWD(128, true); else LAUNCH_FWD(128, false); }
   else { if (causal) LAUNCH_FWD(64, true); else LAUNCH_FWD(64, false); }
 #undef LAUNCH_FWD
@@ -680,59 +567,38 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, const void* vt
   return 0;
 }
 
-int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* qt, const void* kt,
-                const void* dO, long lddo, const void* dOt, const float* lse, const float* delta, void* dqkv,
-                long lddq, int S, int L, int H, int hd, int causal, float scale, void* stream) {
+int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
+                const float* lse, const float* delta, void* dqkv, long lddq, int S, int L, int H, int hd, int causal,
+                float scale, void* stream) {
   RV_REQUIRE(hd == 128, "rv_attn_bwd: head dim must be 128");
   RV_REQUIRE(ld % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0, "rv_attn_bwd: alignment");
   if (S == 0 || L == 0) return 0;
-  const int Lp = rv_lp_stride(L);
   const int nb = (L + 127) / 128;
   dim3 grid(causal ? (nb + 1) / 2 : nb, H, S), block(256);
   hipStream_t st = (hipStream_t)stream;
-  constexpr int DKV_LDS = 2 * 64 * 256 + 2 * 128 * 128 + 512;
-  constexpr int DKV2_LDS = 2 * (2 * 64 * 256 + 512);
+  constexpr int DQ_LDS = 4 * 64 * 256;
+  constexpr int DKV_LDS = 2 * (2 * 64 * 256 + 512);
   static bool attr_done = false;
-  static int dkv_version = 2;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_LDS);
-    const char* e = getenv("RV_ATTN_DKV");       // 1 = pre-transposed-copy kernel (needs qt / dOt), 2 = tr-read kernel
-    if (e && e[0] == '1') dkv_version = 1;
+    hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     attr_done = true;
   }
-  RV_REQUIRE(dkv_version == 2 || (qt != nullptr && dOt != nullptr), "rv_attn_bwd: qt / dOt required for RV_ATTN_DKV=1");
+#define BWD_ARGS (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, scale
   if (causal) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), grid, block, 0, st, (const bf16_t*)qkv, ld, q_col0, k_col0,
-                       v_col0, (const bf16_t*)kt, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, Lp, H,
-                       scale);
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_ARGS);
     RV_CHECK_LAUNCH();
-    if (dkv_version == 2)
-      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid, block, DKV2_LDS, st, (const bf16_t*)qkv, ld, q_col0,
-                         k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, scale);
-    else
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), grid, block, DKV_LDS, st, (const bf16_t*)qkv, ld, q_col0,
-                         k_col0, v_col0, (const bf16_t*)qt, (const bf16_t*)dO, lddo, (const bf16_t*)dOt, lse, delta,
-                         (bf16_t*)dqkv, lddq, L, Lp, H, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid, block, DKV_LDS, st, BWD_ARGS);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), grid, block, 0, st, (const bf16_t*)qkv, ld, q_col0, k_col0,
-                       v_col0, (const bf16_t*)kt, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, Lp, H,
-                       scale);
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, block, DQ_LDS, st, BWD_ARGS);
     RV_CHECK_LAUNCH();
-    if (dkv_version == 2)
-      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid, block, DKV2_LDS, st, (const bf16_t*)qkv, ld, q_col0,
-                         k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, scale);
-    else
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, false>), grid, block, DKV_LDS, st, (const bf16_t*)qkv, ld, q_col0,
-                         k_col0, v_col0, (const bf16_t*)qt, (const bf16_t*)dO, lddo, (const bf16_t*)dOt, lse, delta,
-                         (bf16_t*)dqkv, lddq, L, Lp, H, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid, block, DKV_LDS, st, BWD_ARGS);
   }
+#undef BWD_ARGS
   RV_CHECK_LAUNCH();
   return 0;
 }
 
 }  // extern "C"
-
-extern "C" int rv_attn_lp(int L) { return rv_lp_stride(L); }

@@ -58,14 +58,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-// Row stride (elements) of the per-head transposed attention copies for sequence length L: the next
-// multiple of 64, plus 64 when that is a multiple of 512 - a 2^k-byte row stride lands every row of a tile on
-// the same HBM channel / L2 bank (measured: attention backward 5.4 ms -> 3.5 ms at L 2048 -> 2112).
-static inline int rv_lp_stride(int L) {
-  const int lp = ((L + 63) / 64) * 64;
-  return (lp % 512 == 0) ? lp + 64 : lp;
-}
-
 // Error plumbing for the C ABI (no exceptions across the boundary).
 void rv_set_error(const char* msg);
 #define RV_CHECK_LAUNCH()                                   \

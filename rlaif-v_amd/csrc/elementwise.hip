@@ -294,40 +294,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   }
 }
 
-// Per-head transpose for attention: X[(s*L + l)][col0 + h*hd + e] -> XT[((s*H + h)*hd + e)][Lp],
-// Lp = roundup(L,64), zero padded.  Inside every aligned group of 16 positions the 4-element chunks 1
-// and 2 are swapped (pos p <-> token (p&~12) | ((p&4)<<1) | ((p&8)>>1)), which is the order in which a
-// 32x32x16 MFMA B-operand taken straight from accumulators enumerates its contraction index.
-template <int HD>
-__global__ __launch_bounds__(256) void head_transpose_kernel(const bf16_t* __restrict__ x, long ld, int col0,
-                                                             bf16_t* __restrict__ xt, int L, int Lp, int H) {
-  __shared__ bf16_t tile[64][HD + 8];
-  const int l0 = blockIdx.x * 64, h = blockIdx.y, s = blockIdx.z;
-  constexpr int CPR = HD / 8;
-  for (int ch = threadIdx.x; ch < 64 * CPR; ch += 256) {
-    const int r = ch / CPR, cc = (ch % CPR) * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (l0 + r < L) v = *(const uint4*)(x + ((long)s * L + l0 + r) * ld + col0 + h * HD + cc);
-    *(uint4*)(&tile[r][cc]) = v;
-  }
-  __syncthreads();
-  bf16_t* base = xt + ((long)(s * H + h) * HD) * Lp + l0;
-  for (int ch = threadIdx.x; ch < HD * 8; ch += 256) {
-    const int e = ch >> 3, p0 = (ch & 7) * 8;   // 8 consecutive output positions
-    bf16_t t[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int p = p0 + j;
-      const int tok = (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1);
-      t[j] = tile[tok][e];
-    }
-    uint4 v;
-    v.x = t[0] | ((uint32_t)t[1] << 16); v.y = t[2] | ((uint32_t)t[3] << 16);
-    v.z = t[4] | ((uint32_t)t[5] << 16); v.w = t[6] | ((uint32_t)t[7] << 16);
-    *(uint4*)(base + (long)e * Lp + p0) = v;
-  }
-}
-
 // ------------------------------------------------------------------ splice (K4)
 // src[n] >= 0: embed row; -1: zero pad row; <= -2: image feature row (-2 - src[n])
 __global__ void splice_fwd_kernel(const int* __restrict__ src, const bf16_t* __restrict__ embed,
@@ -741,21 +707,6 @@ int rv_transpose(const void* in, long ld_in, void* out, long ldo, int R, int C, 
   if (R == 0 || C == 0) return 0;
   hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, STREAM(stream),
                      (const bf16_t*)in, ld_in, (bf16_t*)out, ldo, R, C);
-  RV_CHECK_LAUNCH();
-  return 0;
-}
-
-int rv_head_transpose(const void* x, long ld, int col0, void* xt, int S, int L, int H, int hd, void* stream) {
-  RV_REQUIRE(hd == 64 || hd == 128, "rv_head_transpose: head dim must be 64 or 128");
-  RV_REQUIRE(ld % 8 == 0 && col0 % 8 == 0, "rv_head_transpose: alignment");
-  const int Lp = rv_lp_stride(L);
-  dim3 grid((L + 63) / 64, H, S);
-  if (hd == 128)
-    hipLaunchKernelGGL(head_transpose_kernel<128>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, ld, col0,
-                       (bf16_t*)xt, L, Lp, H);
-  else
-    hipLaunchKernelGGL(head_transpose_kernel<64>, grid, dim3(256), 0, STREAM(stream), (const bf16_t*)x, ld, col0,
-                       (bf16_t*)xt, L, Lp, H);
   RV_CHECK_LAUNCH();
   return 0;
 }

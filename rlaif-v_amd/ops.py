@@ -161,30 +161,14 @@ def gelu_bwd(dy, x):
 
 
 # ------------------------------------------------------------------------------------- attention
-def attn_lp(L: int) -> int:
-    """Row stride of the per-head transposed copies (rv_attn_lp)."""
-    return hip.lib().lib.rv_attn_lp(int(L))
-
-
-def head_transpose(x: torch.Tensor, col0: int, S: int, L: int, H: int, hd: int, out=None) -> torch.Tensor:
-    _chk2d(x, "x")
-    Lp = attn_lp(L)
-    if out is None:
-        out = torch.empty(S, H, hd, Lp, dtype=BF16, device=x.device)
-    hip.call("rv_head_transpose", x, x.stride(0), col0, out, S, L, H, hd)
-    return out
-
-
 def attn_fwd(qkv: torch.Tensor, S: int, L: int, H: int, hd: int, causal: bool, q_col0: int, k_col0: int,
-             v_col0: int, out: Optional[torch.Tensor] = None, vt: Optional[torch.Tensor] = None):
+             v_col0: int, out: Optional[torch.Tensor] = None):
     """Returns (out [S*L, H*hd], lse [S,H,L])."""
     _chk2d(qkv, "qkv")
-    if vt is None:
-        vt = head_transpose(qkv, v_col0, S, L, H, hd)
     if out is None:
         out = torch.empty(S * L, H * hd, dtype=BF16, device=qkv.device)
     lse = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
-    hip.call("rv_attn_fwd", qkv, qkv.stride(0), q_col0, k_col0, vt, out, out.stride(0), lse, S, L, H, hd,
+    hip.call("rv_attn_fwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, out, out.stride(0), lse, S, L, H, hd,
              int(causal), 1.0 / math.sqrt(hd))
     return out, lse
 
@@ -196,11 +180,8 @@ def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv:
         dqkv = torch.empty_like(qkv)
     delta = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
     hip.call("rv_attn_delta", do, do.stride(0), o, o.stride(0), delta, S, L, H, hd)
-    qt = head_transpose(qkv, q_col0, S, L, H, hd)
-    kt = head_transpose(qkv, k_col0, S, L, H, hd)
-    dot = head_transpose(do, 0, S, L, H, hd)
-    hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, qt, kt, do, do.stride(0), dot, lse, delta,
-             dqkv, dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd))
+    hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, do, do.stride(0), lse, delta, dqkv,
+             dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd))
     return dqkv
 
 

@@ -246,28 +246,6 @@ def test_swiglu_gelu(ops):
 
 
 # ------------------------------------------------------------------------------------------- attention
-def _perm16(L, Lp, dev):
-    p = torch.arange(Lp, device=dev)
-    return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)
-
-
-@pytest.mark.parametrize("hd", [64, 128])
-def test_head_transpose(ops, hd):
-    dev = _dev()
-    S, L, H = 2, 75, 3
-    x = rnd(S * L, 3 * H * hd + 8, seed=hd, dev=dev)
-    col0 = H * hd
-    t = ops.head_transpose(x, col0, S, L, H, hd)
-    Lp = ops.attn_lp(L)
-    assert t.shape == (S, H, hd, Lp) and Lp >= ops.round_up(L, 64)
-    src = torch.zeros(S, Lp, H, hd, dtype=BF, device=dev)
-    src[:, :L] = x[:, col0:col0 + H * hd].reshape(S, L, H, hd)
-    tok = _perm16(L, Lp, dev)
-    ref = src[:, tok].permute(0, 2, 3, 1)       # [S,H,hd,pos] = X[s, tok(pos), h, e]
-    Lr = ops.round_up(L, 64)        # positions beyond roundup(L,64) are stride padding, never read
-    assert torch.equal(t[..., :Lr], ref[..., :Lr].contiguous())
-
-
 def _attn_ref(q, k, v, causal):
     """q,k,v fp32 [S,H,L,hd] -> (out, lse)"""
     hd = q.shape[-1]

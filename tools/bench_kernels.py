@@ -62,19 +62,16 @@ def main():
     S, L, H, hd = (8, 2048, 32, 128)
     qkv = torch.randn(S * L, 3 * H * hd, device=dev).to(BF)
     do = torch.randn(S * L, H * hd, device=dev).to(BF)
-    vt = ops.head_transpose(qkv, 2 * H * hd, S, L, H, hd)
     out = torch.empty(S * L, H * hd, dtype=BF, device=dev)
-    ms = timeit(lambda: ops.attn_fwd(qkv, S, L, H, hd, True, 0, H * hd, 2 * H * hd, out=out, vt=vt))
+    ms = timeit(lambda: ops.attn_fwd(qkv, S, L, H, hd, True, 0, H * hd, 2 * H * hd, out=out))
     fl = 4.0 * S * H * L * L * hd / 2
     print(f"attn_fwd causal S{S} L{L}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s (causal-halved flops)", flush=True)
     res.append(dict(kernel="attn_fwd", ms=ms, tflops=fl / ms / 1e9))
-    o, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, H * hd, 2 * H * hd, vt=vt)
+    o, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, H * hd, 2 * H * hd)
     dqkv = torch.empty_like(qkv)
     ms = timeit(lambda: ops.attn_bwd(qkv, o, do, lse, S, L, H, hd, True, 0, H * hd, 2 * H * hd, dqkv=dqkv), iters=5)
     print(f"attn_bwd (delta+3 transposes+dq+dkv): {ms:8.3f} ms  {2.5 * fl / ms / 1e9:8.1f} TF/s (2.5x fwd flops)", flush=True)
     res.append(dict(kernel="attn_bwd", ms=ms, tflops=2.5 * fl / ms / 1e9))
-    ms = timeit(lambda: ops.head_transpose(qkv, 0, S, L, H, hd, out=vt))
-    print(f"head_transpose: {ms:8.3f} ms  {2 * S * L * H * hd * 2 / ms / 1e6:8.1f} GB/s", flush=True)
     # HBM-bound kernels
     x = torch.randn(N, 4096, device=dev).to(BF)
     w = torch.ones(4096, dtype=BF, device=dev)

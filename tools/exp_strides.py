@@ -40,15 +40,12 @@ d = H * hd
 for pad in (0, 64, 128):
     qkv = view(S * L, 3 * d, pad)
     do = view(S * L, d, pad)
-    vt = ops.head_transpose(qkv, 2 * d, S, L, H, hd)
     o = torch.empty(S * L, d + pad, dtype=BF, device=dev)[:, :d]
-    _, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, out=o, vt=vt)
-    t_f = timeit(lambda: ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, out=o, vt=vt))
+    _, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, out=o)
+    t_f = timeit(lambda: ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, out=o))
     delta = torch.empty(S, H, L, dtype=torch.float32, device=dev)
     hip.call("rv_attn_delta", do, do.stride(0), o, o.stride(0), delta, S, L, H, hd)
-    qt, kt, dot = (ops.head_transpose(qkv, 0, S, L, H, hd), ops.head_transpose(qkv, d, S, L, H, hd),
-                   ops.head_transpose(do, 0, S, L, H, hd))
     dqkv = torch.empty(S * L, 3 * d + pad, dtype=BF, device=dev)[:, :3 * d]
-    t_b = timeit(lambda: hip.call("rv_attn_bwd", qkv, qkv.stride(0), 0, d, 2 * d, qt, kt, do, do.stride(0), dot, lse,
+    t_b = timeit(lambda: hip.call("rv_attn_bwd", qkv, qkv.stride(0), 0, d, 2 * d, do, do.stride(0), lse,
                                   delta, dqkv, dqkv.stride(0), S, L, H, hd, 1, 1.0 / math.sqrt(hd)))
     print(f"pad {pad}: fwd {t_f:.3f} ms  bwd {t_b:.3f} ms", flush=True)
