@@ -92,17 +92,23 @@ def cpu_baseline(L: int, seed: int = 0):
         O.dpo_train_step(batch, W, cfg, {}, lr=5e-7, step=1, sft_weight=0.0, dpo_weight=1.0)
         return time.time() - t0
 
-    t11 = run(1, 2)     # 1 LLM layer, 1 CLIP layer used (select_layer=-2)
-    t21 = run(2, 2)     # +1 LLM layer
-    t12 = run(1, 3)     # +1 CLIP layer
+    t11 = run(1, 2)     # 1 LLM layer, 1 CLIP layer used (select_layer = -2)
+    t21 = run(2, 2)     # + 1 LLM layer
     llm = max(t21 - t11, 1e-6)
-    clip = max(t12 - t11, 0.0)
+    # CLIP per-layer cost from a forward-only micro-timing (the tower is frozen): 2 images like trainers.py:190
+    cfgc1, cfgc2 = O.LlavaCfg(layers=0, vocab=64, clip_layers=2), O.LlavaCfg(layers=0, vocab=64, clip_layers=3)
+    Wc = {k: v for k, v in O.make_weights(cfgc2, seed=seed, bf16_round=False).items() if k.startswith(O.VT)}
+    px = torch.randn(2, 3, 336, 336)
+    with torch.no_grad():
+        t0 = time.time(); O.clip_vision_features(px, Wc, cfgc1); tc1 = time.time() - t0
+        t0 = time.time(); O.clip_vision_features(px, Wc, cfgc2); tc2 = time.time() - t0
+    clip = max(tc2 - tc1, 0.0)
     fixed = max(t11 - llm - clip, 0.0)
-    # the reference encodes the image twice per pair (trainers.py:190); the port does the same
     step = fixed + 32 * llm + 23 * clip
+    t12 = tc2
     return dict(value=1.0 / step, unit="pairs/s", cores=threads, kind="port",
                 sample=(f"oracle/dpo_oracle.py fwd+bwd+AdamW, fp32, 1 pair, L={L}, full 7B widths at depth "
-                        f"(1,1),(2,1),(1,2) LLM/CLIP layers: {t11:.1f}s,{t21:.1f}s,{t12:.1f}s -> per-layer "
+                        f"(1,1),(2,1) LLM/CLIP layers: {t11:.1f}s,{t21:.1f}s (+ CLIP forward micro-timing {t12:.2f}s) -> per-layer "
                         f"{llm:.2f}s LLM, {clip:.2f}s CLIP, fixed {fixed:.2f}s; extrapolated to 32/23 layers = "
                         f"{step:.1f}s per pair on {threads} threads of {cores} host cores"))
 
@@ -112,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs-per-gpu", type=int, default=4)
+    ap.add_argument("--pairs-per-gpu", type=int, default=8)
     ap.add_argument("--seq-len", type=int, default=2048, help="spliced length L (text length = L - 575)")
     ap.add_argument("--layers", type=int, default=32, help="debug only: anything but 32 is not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")

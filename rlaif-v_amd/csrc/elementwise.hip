@@ -120,14 +120,24 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   }
 }
 
-// out[c] (bf16) = sum_p partial[p][c]  (+ existing out if accumulate)
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int d,
-                                       bf16_t* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
-  float s = accumulate ? bf2f(out[c]) : 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(long)p * d + c];
-  out[c] = f2bf(s);
+// out[c] (bf16) = sum_p partial[p][c]  (+ existing out if accumulate).  Block = 32 columns x 8 partial slices
+// (fixed summation order -> deterministic); grid = d / 32 blocks instead of d / 256 single-column walkers.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int d,
+                                                              bf16_t* __restrict__ out, int accumulate) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (c < d)
+    for (int p = sl; p < nparts; p += 8) s += partial[(long)p * d + c];
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < d) {
+    float t = accumulate ? bf2f(out[c]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][cl];
+    out[c] = f2bf(t);
+  }
 }
 
 // ------------------------------------------------------------------ LayerNorm (CLIP, forward only)
@@ -638,7 +648,7 @@ int rv_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const int
                      (const bf16_t*)x, ldx, row_idx, (const bf16_t*)w, rstd, (const bf16_t*)dres, lddres,
                      (bf16_t*)dx, lddx, dw_partial, rows, d);
   RV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((d + 255) / 256), dim3(256), 0, STREAM(stream), dw_partial, nb, d,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, STREAM(stream), dw_partial, nb, d,
                      (bf16_t*)dw, dw_accumulate);
   RV_CHECK_LAUNCH();
   return 0;
