@@ -180,7 +180,15 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         pairs_per_s = B * world * args.steps / dt
-        fp = flops_per_pair(L, layers=args.layers)
+        fp_nominal = flops_per_pair(L, layers=args.layers)
+        # shared-prefix reuse: the prefix of each pair is computed once -> subtract its work once per pair
+        # (report the MFMA fraction on the FLOPs actually required)
+        plan = model.last_out.plan
+        shared = plan.shared_len or [0] * B
+        d_, f_, V_ = cfg.hidden, cfg.ffn, cfg.vocab
+        per_tok_linear = args.layers * (8 * d_ * d_ + 6 * d_ * f_) + 2 * d_ * V_
+        saved = sum(3.0 * p * (per_tok_linear + args.layers * 2 * d_ * p) for p in shared) / max(len(shared), 1)
+        fp = fp_nominal - saved
         step_tflops_per_gpu = fp * (pairs_per_s / world) / 1e12
         line = {
             "metric": "preference-pairs/sec (DPO step) LLaVA-1.5-7B bf16", "value": pairs_per_s, "unit": "pairs/s",
@@ -190,10 +198,12 @@ def main():
                                    f"seq_len={L}, {B} pairs/GPU, random-init weights",
                        "pairs_per_gpu": B, "global_batch_pairs": B * world, "seq_len": L, "llm_layers": args.layers,
                        "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0",
-                       "gradient_checkpointing": False},
+                       "gradient_checkpointing": False, "shared_prefix_reuse": bool(model.share_prefix)},
             "loss": float(loss), "max_memory_allocated_gb": torch.cuda.max_memory_allocated() / 2**30,
             "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / PEAK_BF16_TFLOPS,
-            "flops_per_pair": fp,
+            "flops_per_pair": fp, "flops_per_pair_reference_layout": fp_nominal,
+            "shared_prefix_tokens_per_pair": sum(shared) / max(len(shared), 1),
+            "tokens_per_step_per_gpu": plan.n_real_tokens,
         }
         if not args.no_gemm_timer:
             g = timer.summary()

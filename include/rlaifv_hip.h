@@ -77,13 +77,16 @@ int rv_row_coef(const float* coef, const int* seq_of_row, const float* weight, f
  *   out: [S*L][ldo] (head h at column h*hd); lse: [S][H][L] natural-log of sum exp(scale * q.k).
  *   causal=1: pure causal mask, no padding mask (muffin/train/trainers.py:199). hd in {64,128}.
  *   K/V tiles are staged by LDS-DMA and transposed on the fly (ds_read_b64_tr_b16): no side copies. */
+/*   seg_sh / seg_e1 (int32 [S], both NULL = plain causal): packed preference pairs.  Row s holds
+ *   [shared prefix | chosen branch | rejected branch]; queries at index >= seg_e1[s] (rejected branch) do not attend
+ *   keys in [seg_sh[s], seg_e1[s]) (the chosen branch): the image / prompt prefix is computed ONCE per pair. */
 int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
-                int L, int H, int hd, int causal, float scale, void* stream);
+                int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, void* stream);
 /* backward (hd = 128): delta = rv_attn_delta(dO, O).  Writes dQ, dK, dV into dqkv at the column offsets of
  * qkv.  Deterministic (no atomics): one kernel per 128-query block for dQ, one per 128-key block for dK/dV. */
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
                 const float* lse, const float* delta, void* dqkv, long lddq, int S, int L, int H, int hd, int causal,
-                float scale, void* stream);
+                float scale, const int* seg_sh, const int* seg_e1, void* stream);
 int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
                   void* stream);
 
@@ -96,9 +99,10 @@ int rv_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const int
                    void* dw, int dw_accumulate, int rows, int d, void* stream);
 int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int d,
                      float eps, void* stream);
-/* in-place half-split RoPE over n_heads_total adjacent heads (q then k), position = token % L
- * (position_ids are dropped: llava/model/language_model/llava_llama.py:94); backward = inverse rotation. */
-int rv_rope_inplace(void* x, long ld, const float* cos_tab, const float* sin_tab, long n_tok, int L,
+/* in-place half-split RoPE over n_heads_total adjacent heads (q then k); position = pos[token] when pos != NULL
+ * (packed pairs), else token % L (position_ids are dropped: llava/model/language_model/llava_llama.py:94);
+ * backward = inverse rotation. */
+int rv_rope_inplace(void* x, long ld, const float* cos_tab, const float* sin_tab, const int* pos, long n_tok, int L,
                     int n_heads_total, int hd, int backward, void* stream);
 int rv_swiglu_fwd(const void* gu, long ldgu, void* act, long lda, long rows, int f, void* stream);
 int rv_swiglu_bwd(const void* dact, long ldd, const void* gu, long ldgu, void* dgu, long lddgu, long rows, int f,

@@ -116,7 +116,9 @@ struct TileDma {
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                            int k_col0, int v_col0, bf16_t* __restrict__ out, long ldo,
-                                                           float* __restrict__ lse, int L, int H, float scale) {
+                                                           float* __restrict__ lse, int L, int H, float scale,
+                                                           const int* __restrict__ seg_sh,
+                                                           const int* __restrict__ seg_e1) {
   constexpr int KS = HD / 16, ET = HD / 32, TILE = 64 * HD * 2, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -125,6 +127,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   const int nqb = (L + 127) / 128;
   const int h = blockIdx.y, s = blockIdx.z;
   const long tok0 = (long)s * L;
+  // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
+  const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const float c = scale * LOG2E;
 
   TileDma<HD> dma;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         dma.issue(kbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE, wave);
         dma.issue(vbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE + TILE, wave);
       }
-      if (!(CAUSAL && k0 > q0w + 31)) {
+      if (!(CAUSAL && k0 > q0w + 31) && !(q0w >= e1 && k0 >= sh && k0 + 63 < e1)) {
         f32x16_t sacc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
           for (int r = 0; r < 16; ++r) {
             const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v = sacc[kt][r] * c;
-            if (key >= L || (CAUSAL && key > q)) v = -INFINITY;
+            if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) v = -INFINITY;
             sacc[kt][r] = v;
             tmax = fmaxf(tmax, v);
           }
@@ -246,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
                                                               long lddo, const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
-                                                              float scale) {
+                                                              float scale, const int* __restrict__ seg_sh,
+                                                              const int* __restrict__ seg_e1) {
   constexpr int HD = 128, KS = 8, ET = 4, TILE = 64 * HD * 2, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -255,6 +260,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
   const int nqb = (L + 127) / 128;
   const int h = blockIdx.y, s = blockIdx.z;
   const long tok0 = (long)s * L;
+  // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
+  const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const float c = scale * LOG2E;
 
   TileDma<HD> dma;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
         dma.issue(kbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE, wave);
         dma.issue(vbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE + TILE, wave);
       }
-      if (!(CAUSAL && k0 > q0w + 31)) {
+      if (!(CAUSAL && k0 > q0w + 31) && !(q0w >= e1 && k0 >= sh && k0 + 63 < e1)) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           f32x16_t sacc, pacc;
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
           for (int r = 0; r < 16; ++r) {
             const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float p = exp2f(sacc[r] * c - lse_q);
-            if (key >= L || (CAUSAL && key > q)) p = 0.f;
+            if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) p = 0.f;
             sacc[r] = p * (pacc[r] - delta_q);
           }
 #pragma unroll
@@ -374,7 +381,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, long lddq, int L, int H,
-                                                               float scale) {
+                                                               float scale, const int* __restrict__ seg_sh,
+                                                               const int* __restrict__ seg_e1) {
   constexpr int HD = 128, KS = 8, ET = 4;
   constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64]
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -384,6 +392,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
   const int fr = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, s = blockIdx.z;
   const long tok0 = (long)s * L;
+  // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
+  const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const int nkb = (L + 127) / 128;
   const float c = scale * LOG2E;
   const float* lse_base = lse + ((long)s * H + h) * L;
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
       const int qs0 = t * 64;
       if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
 
-      if (!(CAUSAL && qs0 + 63 < kv0w)) {
+      if (!(CAUSAL && qs0 + 63 < kv0w) && !(qs0 >= e1 && kv0w >= sh && kv0w + 31 < e1)) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           f32x16_t sacc, pacc;
@@ -498,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
             const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int qg = qs0 + ql;
             float p = exp2f(sacc[r] * c - lse_s[ql] * LOG2E);
-            if (qg >= L || key >= L || (CAUSAL && key > qg)) p = 0.f;
+            if (qg >= L || key >= L || (CAUSAL && key > qg) || (qg >= e1 && key >= sh && key < e1)) p = 0.f;
             sacc[r] = p;
             pacc[r] = p * (pacc[r] - delta_s[ql]);
           }
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 extern "C" {
 
 int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
-                int L, int H, int hd, int causal, float scale, void* stream) {
+                int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, void* stream) {
   RV_REQUIRE(hd == 64 || hd == 128, "rv_attn_fwd: head dim must be 64 or 128");
   RV_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0 && v_col0 % 8 == 0,
              "rv_attn_fwd: alignment");
@@ -559,7 +569,7 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   }
 #define LAUNCH_FWD(HD_, C_)                                                                                      \
   hipLaunchKernelGGL((attn_fwd2_kernel<HD_, C_>), grid, block, 4 * 64 * HD_ * 2, st, (const bf16_t*)qkv, ld, q_col0, \
-                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, scale)
+                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, scale, seg_sh, seg_e1)
   if (hd == 128) { if (causal) LAUNCH_FWD(128, true); else LAUNCH_FWD(128, false); }
   else { if (causal) LAUNCH_FWD(64, true); else LAUNCH_FWD(64, false); }
 #undef LAUNCH_FWD
@@ -569,8 +579,9 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
 
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
                 const float* lse, const float* delta, void* dqkv, long lddq, int S, int L, int H, int hd, int causal,
-                float scale, void* stream) {
+                float scale, const int* seg_sh, const int* seg_e1, void* stream) {
   RV_REQUIRE(hd == 128, "rv_attn_bwd: head dim must be 128");
+  RV_REQUIRE((seg_sh == nullptr) == (seg_e1 == nullptr), "rv_attn_bwd: seg_sh and seg_e1 go together");
   RV_REQUIRE(ld % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0, "rv_attn_bwd: alignment");
   if (S == 0 || L == 0) return 0;
   const int nb = (L + 127) / 128;
@@ -586,7 +597,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
     hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     attr_done = true;
   }
-#define BWD_ARGS (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, scale
+#define BWD_ARGS (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, scale, seg_sh, seg_e1
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_ARGS);
     RV_CHECK_LAUNCH();

@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------ RoPE (half-split layout), in place
 // x: [n_tok][ld]; rotates `n_heads_total` heads of width hd starting at column 0 (q then k are adjacent).
 __global__ void rope_kernel(bf16_t* __restrict__ x, long ld, const float* __restrict__ cs_cos,
-                            const float* __restrict__ cs_sin, long n_tok, int L, int n_heads_total, int hd,
-                            float sign) {
+                            const float* __restrict__ cs_sin, const int* __restrict__ pos_tab, long n_tok, int L,
+                            int n_heads_total, int hd, float sign) {
   const int half = hd >> 1, cpr = half >> 3;  // 16-byte chunks per half head
   const long total = n_tok * n_heads_total * cpr;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -188,7 +188,7 @@ __global__ void rope_kernel(bf16_t* __restrict__ x, long ld, const float* __rest
     const long t2 = i / cpr;
     const int h = (int)(t2 % n_heads_total);
     const long n = t2 / n_heads_total;
-    const int pos = (int)(n % L);
+    const int pos = pos_tab ? pos_tab[n] : (int)(n % L);
     bf16_t* p1 = x + n * ld + (long)h * hd + ch * 8;
     bf16_t* p2 = p1 + half;
     float a[8], b[8], o1[8], o2[8];
@@ -664,13 +664,13 @@ int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void
   return 0;
 }
 
-int rv_rope_inplace(void* x, long ld, const float* cos_tab, const float* sin_tab, long n_tok, int L,
+int rv_rope_inplace(void* x, long ld, const float* cos_tab, const float* sin_tab, const int* pos, long n_tok, int L,
                     int n_heads_total, int hd, int backward, void* stream) {
   RV_REQUIRE(hd % 16 == 0 && ld % 8 == 0, "rv_rope_inplace: hd%16, ld%8");
   const long total = n_tok * n_heads_total * (hd / 16);
   if (total == 0) return 0;
   hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, STREAM(stream), (bf16_t*)x, ld,
-                     cos_tab, sin_tab, n_tok, L, n_heads_total, hd, backward ? -1.f : 1.f);
+                     cos_tab, sin_tab, pos, n_tok, L, n_heads_total, hd, backward ? -1.f : 1.f);
   RV_CHECK_LAUNCH();
   return 0;
 }

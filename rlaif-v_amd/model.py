@@ -21,13 +21,14 @@ Data layout in HBM:
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from . import ops
-from .splice import SplicePlan, build_splice_plan
+from .splice import SplicePlan, build_packed_plan, build_splice_plan
 
 BF16 = torch.bfloat16
 VT = "model.vision_tower.vision_tower.vision_model."
@@ -210,6 +211,8 @@ class LlavaDPOModel:
         self.training = True
         self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.grad_ready_hook = None     # callable(name, start, end) fired when a slice of flat_g is final
+        # compute the prefix shared by the chosen and rejected sequence of a pair once (splice.build_packed_plan)
+        self.share_prefix = os.environ.get("RV_SHARE_PREFIX", "1") != "0"
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -343,7 +346,11 @@ class LlavaDPOModel:
         d, H, hd, f = cfg.hidden, cfg.heads, cfg.head_dim, cfg.ffn
         B = images.shape[0]
         ctx: dict = {}
-        plan = build_splice_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length).to(self.device)
+        if self.share_prefix and input_ids.shape[0] == 2 * B:
+            plan = build_packed_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length, cfg.pad_token_id)
+        else:
+            plan = build_splice_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length)
+        plan = plan.to(self.device)
         S, L = plan.S, plan.L
         N = S * L
         feats = self.encode_images(images, ctx if save_for_backward else None)
@@ -353,8 +360,8 @@ class LlavaDPOModel:
         for i in range(cfg.layers):
             xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
             qkv = ops.gemm_nt(xn, st.p(f"layers.{i}.wqkv"))
-            ops.rope_inplace(qkv, cos, sin, L, 2 * H, hd)
-            attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d)
+            ops.rope_inplace(qkv, cos, sin, L, 2 * H, hd, pos=plan.pos)
+            attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
             x_mid = ops.gemm_nt(attn, st.p(f"layers.{i}.wo"), residual=x)
             xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
             gu = ops.gemm_nt(xn2, st.p(f"layers.{i}.wgu"))
@@ -374,7 +381,7 @@ class LlavaDPOModel:
             logp = torch.empty(0, dtype=torch.float32, device=self.device)
             lse_v = logp
         w_rows = None
-        seq_logp, seq_cnt = ops.seq_sum(logp, plan.seq_off, S, weight=w_rows)
+        seq_logp, seq_cnt = ops.seq_sum(logp, plan.seq_off, plan.n_seq, weight=w_rows)
         out = StepOutput(loss=None, scalars=None, per_pair=None, seq_logp=seq_logp, seq_cnt=seq_cnt,
                          per_token_logp=logp, plan=plan)
         if save_for_backward:
@@ -432,9 +439,9 @@ class LlavaDPOModel:
             del dxn2
             dattn = ops.gemm_nt(dx_mid, st.pT(f"layers.{i}.wo"))
             wgrad(dx_mid, c["attn"], f"layers.{i}.wo")
-            dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, 2 * d)
+            dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
             del dattn
-            ops.rope_inplace(dqkv, cos, sin, L, 2 * H, hd, backward=True)
+            ops.rope_inplace(dqkv, cos, sin, L, 2 * H, hd, backward=True, pos=plan.pos)
             xn, _ = ops.rmsnorm_fwd(c["x"], st.p(f"layers.{i}.ln1"), cfg.rms_eps, want_rstd=False)
             dxn = ops.gemm_nt(dqkv, st.pT(f"layers.{i}.wqkv"))
             wgrad(dqkv, xn, f"layers.{i}.wqkv")

@@ -124,9 +124,10 @@ def rope_tables(L: int, hd: int, theta: float, device) -> Tuple[torch.Tensor, to
     return fr.cos().contiguous().to(device), fr.sin().contiguous().to(device)
 
 
-def rope_inplace(x: torch.Tensor, cos, sin, L: int, n_heads_total: int, hd: int, backward: bool = False):
+def rope_inplace(x: torch.Tensor, cos, sin, L: int, n_heads_total: int, hd: int, backward: bool = False,
+                 pos: Optional[torch.Tensor] = None):
     _chk2d(x, "x")
-    hip.call("rv_rope_inplace", x, x.stride(0), cos, sin, x.shape[0], L, n_heads_total, hd, int(backward))
+    hip.call("rv_rope_inplace", x, x.stride(0), cos, sin, pos, x.shape[0], L, n_heads_total, hd, int(backward))
     return x
 
 
@@ -162,18 +163,19 @@ def gelu_bwd(dy, x):
 
 # ------------------------------------------------------------------------------------- attention
 def attn_fwd(qkv: torch.Tensor, S: int, L: int, H: int, hd: int, causal: bool, q_col0: int, k_col0: int,
-             v_col0: int, out: Optional[torch.Tensor] = None):
+             v_col0: int, out: Optional[torch.Tensor] = None, seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Returns (out [S*L, H*hd], lse [S,H,L])."""
     _chk2d(qkv, "qkv")
     if out is None:
         out = torch.empty(S * L, H * hd, dtype=BF16, device=qkv.device)
     lse = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
     hip.call("rv_attn_fwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, out, out.stride(0), lse, S, L, H, hd,
-             int(causal), 1.0 / math.sqrt(hd))
+             int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None, seg[1] if seg else None)
     return out, lse
 
 
-def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv: Optional[torch.Tensor] = None):
+def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv: Optional[torch.Tensor] = None,
+             seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Returns dqkv with dQ/dK/dV written at the qkv column offsets."""
     _chk2d(qkv, "qkv"), _chk2d(o, "o"), _chk2d(do, "do")
     if dqkv is None:
@@ -181,7 +183,8 @@ def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv:
     delta = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
     hip.call("rv_attn_delta", do, do.stride(0), o, o.stride(0), delta, S, L, H, hd)
     hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, do, do.stride(0), lse, delta, dqkv,
-             dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd))
+             dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None,
+             seg[1] if seg else None)
     return dqkv
 
 

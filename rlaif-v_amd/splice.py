@@ -7,11 +7,21 @@ Mirrors ``LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal``
 int64/int32 index arithmetic on the CPU side of the batch (it replaces the reference's per-row
 Python loop with its ``.tolist()`` device syncs); the tables are then consumed by the HIP kernels
 ``rv_splice_fwd`` / ``rv_embed_bwd`` / ``rv_feat_grad`` / ``rv_rmsnorm_*`` (row gather).
+
+Two layouts:
+  * ``build_splice_plan``  - the reference layout: 2B rows (wins then rejects), right padded to L;
+  * ``build_packed_plan``  - one row per PAIR, ``[shared prefix | chosen branch | rejected branch]``.
+    The chosen and rejected sequences of a pair start with the same system prompt + image + question
+    (muffin/data/datasets.py:61-63), a causal model gives those positions identical hidden states in both
+    rows, so they are computed once: the rejected branch attends the shared prefix but not the chosen branch
+    (rv_attn_* ``seg_sh/seg_e1``) and keeps its own RoPE positions (``pos``).  Pads are dropped (they sit to
+    the right of every counted token and never influence a log-prob).  The per-sequence outputs are
+    mathematically identical to the reference layout.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -21,20 +31,26 @@ IMAGE_TOKEN_INDEX = -200
 
 @dataclass
 class SplicePlan:
-    S: int                     # sequences (2B: wins then rejects)
-    L: int                     # spliced, right-padded length
+    S: int                     # physical rows of the activation matrix
+    L: int                     # row length (right padded)
+    n_seq: int                 # logical sequences (2B: wins then rejects)
     src: torch.Tensor          # int32 [S*L]  >=0 embed row | -1 zero pad | <=-2 feature row (-2 - r)
-    labels: torch.Tensor       # int64 [S, L]  new labels (IGNORE_INDEX over image span and pads)
-    sel_idx: torch.Tensor      # int32 [n_sel] flat row n = s*L + l whose NEXT label is a target
-    tgt: torch.Tensor          # int32 [n_sel] that target id (labels[s, l+1])
-    seq_off: torch.Tensor      # int32 [S+1]   selected rows of sequence s are seq_off[s]..seq_off[s+1]
+    labels: Optional[torch.Tensor]   # int64 [S, L] new labels in the reference layout (None when packed)
+    sel_idx: torch.Tensor      # int32 [n_sel] flat row n whose NEXT label is a target, ordered by (sequence, position)
+    tgt: torch.Tensor          # int32 [n_sel] that target id
+    seq_off: torch.Tensor      # int32 [n_seq+1] selected rows of sequence s are seq_off[s]..seq_off[s+1]
     seq_of_row: torch.Tensor   # int32 [n_sel]
     uniq_ids: torch.Tensor     # int32 [U]     distinct embedded token ids
     seg_off: torch.Tensor      # int32 [U+1]
     pos_sorted: torch.Tensor   # int32 [n_text] flat rows grouped by token id (stable order)
     feat_src_a: torch.Tensor   # int32 [n_feat_rows] flat row fed by feature row r (first user) or -1
-    feat_src_b: torch.Tensor   # int32 [n_feat_rows] second user (the rejected sequence) or -1
+    feat_src_b: torch.Tensor   # int32 [n_feat_rows] second user or -1
     n_sel: int
+    pos: Optional[torch.Tensor] = None        # int32 [S*L] RoPE position of every row (packed layout only)
+    seg_sh: Optional[torch.Tensor] = None     # int32 [S] end of the shared prefix
+    seg_e1: Optional[torch.Tensor] = None     # int32 [S] end of the chosen branch
+    shared_len: Optional[List[int]] = None    # per pair (accounting)
+    n_real_tokens: int = 0                    # rows that carry a real token / image feature
 
     def to(self, device) -> "SplicePlan":
         kw = {}
@@ -42,15 +58,16 @@ class SplicePlan:
             kw[k] = v.to(device, non_blocking=True) if torch.is_tensor(v) else v
         return SplicePlan(**kw)
 
+    @property
+    def seg(self):
+        return (self.seg_sh, self.seg_e1) if self.seg_sh is not None else None
 
-def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
-                      max_len: Optional[int]) -> SplicePlan:
-    """input_ids/labels: int64 [S, T] (the collator's ``concatenated_*`` tensors).
-    ``n_images`` distinct images were encoded (one per pair); sequence row r uses image
-    ``cur_image_idx % n_images`` where cur_image_idx advances exactly like llava_arch.py:241-266
-    (one per image token, and one for a row without any image token)."""
-    input_ids = input_ids.cpu().long()
-    labels = labels.cpu().long()
+
+def _splice_rows(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
+                 max_len: Optional[int]) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """Per-row spliced sources / labels before padding (llava_arch.py:237-283).  Sequence row r uses image
+    ``cur_image_idx % n_images`` where cur_image_idx advances exactly like llava_arch.py:241-266 (one per image
+    token, and one for a row without any image token)."""
     S, T = input_ids.shape
     P = n_img_tokens
     rows_src, rows_lab = [], []
@@ -65,7 +82,6 @@ def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
         within = torch.arange(tok_of.numel()) - start[tok_of]              # offset inside an image span
         src_tok = ids[tok_of]
         out_is_img = is_img[tok_of]
-        # which image (in traversal order) each image slot belongs to
         img_rank = (torch.cumsum(is_img.long(), 0) - 1)[tok_of]            # 0-based within the row
         img_global = (cur_image_idx + img_rank) % max(n_images, 1)
         src = torch.where(out_is_img, -2 - (img_global * P + within), src_tok)
@@ -75,6 +91,49 @@ def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
             src, new_lab = src[:max_len], new_lab[:max_len]
         rows_src.append(src)
         rows_lab.append(new_lab)
+    return rows_src, rows_lab
+
+
+def _tables(flat: torch.Tensor, n_feat_rows: int):
+    """Embedding-backward segments and feature-gradient sources from the flat source table."""
+    text_rows = torch.nonzero(flat >= 0, as_tuple=True)[0]
+    text_ids = flat[text_rows]
+    order = torch.sort(text_ids, stable=True).indices
+    sorted_ids = text_ids[order]
+    pos_sorted = text_rows[order].to(torch.int32)
+    uniq, counts_u = torch.unique_consecutive(sorted_ids, return_counts=True)
+    seg_off = torch.zeros(uniq.numel() + 1, dtype=torch.int32)
+    seg_off[1:] = torch.cumsum(counts_u, 0).to(torch.int32)
+
+    feat_rows = torch.nonzero(flat <= -2, as_tuple=True)[0]
+    feat_ids = (-2 - flat[feat_rows])
+    a = torch.full((n_feat_rows,), -1, dtype=torch.int32)
+    b = torch.full((n_feat_rows,), -1, dtype=torch.int32)
+    if feat_rows.numel():
+        # users of a feature row appear in increasing flat order; with one image per sample there are at most
+        # two (the chosen and the rejected sequence of the pair; one when the image lies in the shared prefix)
+        order_f = torch.sort(feat_ids, stable=True).indices
+        fid_s, frow_s = feat_ids[order_f], feat_rows[order_f]
+        first = torch.ones_like(fid_s, dtype=torch.bool)
+        first[1:] = fid_s[1:] != fid_s[:-1]
+        second = torch.zeros_like(first)
+        second[1:] = (~first[1:]) & first[:-1]
+        if bool((~(first | second)).any()):
+            raise ValueError("an image feature row is used by more than two sequence positions; "
+                             "the DPO path expects one image per (chosen, rejected) pair")
+        a[fid_s[first]] = frow_s[first].to(torch.int32)
+        b[fid_s[second]] = frow_s[second].to(torch.int32)
+    return uniq.to(torch.int32), seg_off, pos_sorted, a, b
+
+
+def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
+                      max_len: Optional[int]) -> SplicePlan:
+    """Reference layout.  input_ids/labels: int64 [S, T] (the collator's ``concatenated_*`` tensors);
+    ``n_images`` distinct images were encoded (one per pair)."""
+    input_ids = input_ids.cpu().long()
+    labels = labels.cpu().long()
+    S = input_ids.shape[0]
+    rows_src, rows_lab = _splice_rows(input_ids, labels, n_img_tokens, n_images, max_len)
     L = max(int(x.numel()) for x in rows_src)                              # :286
     src_full = torch.full((S, L), -1, dtype=torch.int64)                   # zero-embedding right pad (:305-313)
     lab_full = torch.full((S, L), IGNORE_INDEX, dtype=torch.int64)
@@ -89,41 +148,80 @@ def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
     s_idx, l_idx = torch.nonzero(mask, as_tuple=True)                      # row-major order: by s then l
     sel = (s_idx * L + l_idx).to(torch.int32)
     tgt = nxt[mask].to(torch.int32)
-    cnt = mask.sum(1)
     seq_off = torch.zeros(S + 1, dtype=torch.int32)
-    seq_off[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+    seq_off[1:] = torch.cumsum(mask.sum(1), 0).to(torch.int32)
 
     flat = src_full.reshape(-1)
-    text_rows = torch.nonzero(flat >= 0, as_tuple=True)[0]
-    text_ids = flat[text_rows]
-    order = torch.sort(text_ids, stable=True).indices
-    sorted_ids = text_ids[order]
-    pos_sorted = text_rows[order].to(torch.int32)
-    uniq, counts_u = torch.unique_consecutive(sorted_ids, return_counts=True)
-    seg_off = torch.zeros(uniq.numel() + 1, dtype=torch.int32)
-    seg_off[1:] = torch.cumsum(counts_u, 0).to(torch.int32)
+    uniq, seg_off, pos_sorted, a, b = _tables(flat, max(n_images, 1) * n_img_tokens)
+    return SplicePlan(S=S, L=L, n_seq=S, src=flat.to(torch.int32), labels=lab_full, sel_idx=sel, tgt=tgt,
+                      seq_off=seq_off, seq_of_row=s_idx.to(torch.int32), uniq_ids=uniq, seg_off=seg_off,
+                      pos_sorted=pos_sorted, feat_src_a=a, feat_src_b=b, n_sel=int(sel.numel()),
+                      n_real_tokens=int(sum(x.numel() for x in rows_src)))
 
-    n_feat_rows = max(n_images, 1) * P
-    feat_rows = torch.nonzero(flat <= -2, as_tuple=True)[0]
-    feat_ids = (-2 - flat[feat_rows])
-    a = torch.full((n_feat_rows,), -1, dtype=torch.int32)
-    b = torch.full((n_feat_rows,), -1, dtype=torch.int32)
-    if feat_rows.numel():
-        # users of a feature row appear in increasing flat order; with one image per sample there are
-        # at most two (the chosen and the rejected sequence of the pair)
-        order_f = torch.sort(feat_ids, stable=True).indices
-        fid_s, frow_s = feat_ids[order_f], feat_rows[order_f]
-        first = torch.ones_like(fid_s, dtype=torch.bool)
-        first[1:] = fid_s[1:] != fid_s[:-1]
-        second = torch.zeros_like(first)
-        second[1:] = (~first[1:]) & first[:-1]
-        third_plus = ~(first | second)
-        if bool(third_plus.any()):
-            raise ValueError("an image feature row is used by more than two sequence positions; "
-                             "the DPO path expects one image per (chosen, rejected) pair")
-        a[fid_s[first]] = frow_s[first].to(torch.int32)
-        b[fid_s[second]] = frow_s[second].to(torch.int32)
 
-    return SplicePlan(S=S, L=L, src=flat.to(torch.int32), labels=lab_full, sel_idx=sel, tgt=tgt, seq_off=seq_off,
-                      seq_of_row=s_idx.to(torch.int32), uniq_ids=uniq.to(torch.int32), seg_off=seg_off,
-                      pos_sorted=pos_sorted, feat_src_a=a, feat_src_b=b, n_sel=int(sel.numel()))
+def build_packed_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
+                      max_len: Optional[int], pad_token_id: int = 0) -> SplicePlan:
+    """One row per pair: [shared prefix | chosen branch | rejected branch] (module docstring).
+    input_ids / labels: [2B, T], wins then rejects."""
+    input_ids = input_ids.cpu().long()
+    labels = labels.cpu().long()
+    S2 = input_ids.shape[0]
+    if S2 % 2:
+        raise ValueError("packed layout needs wins followed by the same number of rejects")
+    B = S2 // 2
+    rows_src, rows_lab = _splice_rows(input_ids, labels, n_img_tokens, n_images, max_len)
+    for r in range(S2):        # drop the collator's right padding (pad id with label -100 at the very end)
+        pad = (rows_src[r] == pad_token_id) & (rows_lab[r] == IGNORE_INDEX)
+        keep = int(torch.nonzero(~pad)[-1]) + 1 if bool((~pad).any()) else 1
+        rows_src[r], rows_lab[r] = rows_src[r][:keep], rows_lab[r][:keep]
+
+    def first_target(lab):
+        nz = torch.nonzero(lab != IGNORE_INDEX)
+        return int(nz[0]) if nz.numel() else int(lab.numel())
+
+    packed_src, packed_pos, shs, e1s = [], [], [], []
+    sel_rows: List[List[torch.Tensor]] = [[None] * B, [None] * B]          # [branch][pair] -> row offsets in the packed row
+    sel_tgts: List[List[torch.Tensor]] = [[None] * B, [None] * B]
+    for b in range(B):
+        cs, cl, rs, rl = rows_src[b], rows_lab[b], rows_src[B + b], rows_lab[B + b]
+        n = min(cs.numel(), rs.numel())
+        eq = (cs[:n] == rs[:n]) & (cl[:n] == rl[:n])
+        ne = torch.nonzero(~eq)
+        lcp = int(ne[0]) if ne.numel() else n
+        sh = max(0, min(lcp - 1, min(first_target(cl), first_target(rl)) - 1))
+        Lc, Lr = cs.numel(), rs.numel()
+        packed_src.append(torch.cat([cs, rs[sh:]]))
+        packed_pos.append(torch.cat([torch.arange(Lc), torch.arange(sh, Lr)]))
+        shs.append(sh)
+        e1s.append(Lc)
+        ci = torch.nonzero(cl[1:] != IGNORE_INDEX, as_tuple=True)[0]       # row i predicts label i+1
+        ri = torch.nonzero(rl[1:] != IGNORE_INDEX, as_tuple=True)[0]
+        assert (ri >= sh).all() and (ci >= sh).all() or sh == 0
+        sel_rows[0][b], sel_tgts[0][b] = ci, cl[1:][ci]
+        sel_rows[1][b], sel_tgts[1][b] = Lc + (ri - sh), rl[1:][ri]
+    L = max(int(x.numel()) for x in packed_src)
+    src_full = torch.full((B, L), -1, dtype=torch.int64)
+    pos_full = torch.zeros((B, L), dtype=torch.int64)
+    for b in range(B):
+        n = packed_src[b].numel()
+        src_full[b, :n] = packed_src[b]
+        pos_full[b, :n] = packed_pos[b]
+    sel, tgt, seq_of, counts = [], [], [], []
+    for br in range(2):
+        for b in range(B):
+            sel.append(b * L + sel_rows[br][b])
+            tgt.append(sel_tgts[br][b])
+            seq_of.append(torch.full((sel_rows[br][b].numel(),), br * B + b, dtype=torch.int64))
+            counts.append(sel_rows[br][b].numel())
+    sel = torch.cat(sel).to(torch.int32)
+    tgt = torch.cat(tgt).to(torch.int32)
+    seq_of = torch.cat(seq_of).to(torch.int32)
+    seq_off = torch.zeros(S2 + 1, dtype=torch.int32)
+    seq_off[1:] = torch.cumsum(torch.tensor(counts), 0).to(torch.int32)
+    flat = src_full.reshape(-1)
+    uniq, seg_off, pos_sorted, a, bb = _tables(flat, max(n_images, 1) * n_img_tokens)
+    return SplicePlan(S=B, L=L, n_seq=S2, src=flat.to(torch.int32), labels=None, sel_idx=sel, tgt=tgt, seq_off=seq_off,
+                      seq_of_row=seq_of, uniq_ids=uniq, seg_off=seg_off, pos_sorted=pos_sorted, feat_src_a=a,
+                      feat_src_b=bb, n_sel=int(sel.numel()), pos=pos_full.reshape(-1).to(torch.int32),
+                      seg_sh=torch.tensor(shs, dtype=torch.int32), seg_e1=torch.tensor(e1s, dtype=torch.int32),
+                      shared_len=shs, n_real_tokens=int(sum(x.numel() for x in packed_src)))

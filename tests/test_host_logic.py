@@ -106,6 +106,56 @@ def test_splice_plan_edges():
     assert torch.equal(p.labels, nl)
 
 
+def _unpack(p, b, B):
+    """Reconstruct (chosen, rejected) source / position rows of pair b from a packed plan."""
+    L = p.L
+    src = p.src.view(p.S, L)[b].long()
+    pos = p.pos.view(p.S, L)[b].long()
+    sh, e1 = int(p.seg_sh[b]), int(p.seg_e1[b])
+    n = int((src != -1).sum()) if bool((src == -1).any()) else L
+    n = max(n, e1)
+    chosen, cpos = src[:e1], pos[:e1]
+    rej, rpos = torch.cat([src[:sh], src[e1:n]]), torch.cat([pos[:sh], pos[e1:n]])
+    return chosen, cpos, rej, rpos, sh, e1
+
+
+@pytest.mark.parametrize("seed,max_len,common_answer", [(1, None, 0), (2, 50, 0), (3, None, 5), (4, 4096, 40)])
+def test_packed_plan_is_a_lossless_repacking(seed, max_len, common_answer):
+    from rlaif_v_amd.splice import build_packed_plan, build_splice_plan, _splice_rows
+    cfg = O.tiny_cfg()
+    B = 3
+    b = O.make_synthetic_batch(cfg, B, 44, 13, seed=seed)
+    ids, lab = b["concatenated_input_ids"].clone(), b["concatenated_labels"].clone()
+    if common_answer:      # chosen / rejected share the first answer tokens: those rows carry targets of BOTH sequences
+        T = ids.shape[1]
+        k = min(common_answer, T - 13)
+        ids[B:, 13:13 + k] = ids[:B, 13:13 + k]
+        lab[B:, 13:13 + k] = torch.where(lab[B:, 13:13 + k] != -100, ids[B:, 13:13 + k], lab[B:, 13:13 + k])
+    ref = build_splice_plan(ids, lab, cfg.n_patches, B, max_len)
+    p = build_packed_plan(ids, lab, cfg.n_patches, B, max_len, cfg.pad_token_id)
+    assert p.S == B and p.n_seq == 2 * B and p.labels is None
+    rows_src, rows_lab = _splice_rows(ids, lab, cfg.n_patches, B, max_len)
+    for bi in range(B):
+        chosen, cpos, rej, rpos, sh, e1 = _unpack(p, bi, B)
+        for got, gpos, r in ((chosen, cpos, bi), (rej, rpos, B + bi)):
+            full = rows_src[r]
+            assert torch.equal(got, full[:got.numel()])                 # same tokens, only right padding dropped
+            rest, rest_lab = full[got.numel():], rows_lab[r][got.numel():]
+            assert bool(((rest == cfg.pad_token_id) & (rest_lab == -100)).all())
+            assert torch.equal(gpos, torch.arange(got.numel()))         # RoPE positions of the reference layout
+        # nothing with a target (as input row) lives in the shared part
+        assert sh <= min(int(torch.nonzero(rows_lab[bi] != -100)[0]), int(torch.nonzero(rows_lab[B + bi] != -100)[0])) - 1 \
+            or sh == 0
+    # same targets in the same (sequence, position) order, same per-sequence counts
+    assert torch.equal(p.tgt, ref.tgt) and torch.equal(p.seq_off, ref.seq_off) and torch.equal(p.seq_of_row, ref.seq_of_row)
+    # each selected packed row holds the same source token as the reference row it replaces
+    assert torch.equal(p.src[p.sel_idx.long()], ref.src[ref.sel_idx.long()])
+    assert torch.equal(p.pos[p.sel_idx.long()].long(), ref.sel_idx.long() % ref.L)
+    assert p.n_real_tokens < ref.n_real_tokens
+    if common_answer == 0 and max_len is None:
+        assert all(s == 13 - 1 + cfg.n_patches - 1 for s in p.shared_len)   # whole prompt minus its last token
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_collator_matches_reference_golden(golden_dir, seed):
     from rlaif_v_amd.data import DataCollatorForDPODataset

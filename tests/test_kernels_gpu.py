@@ -300,6 +300,53 @@ def test_attn_bwd(ops, causal, L):
         close(dqkv[:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"attn bwd d{nm} L{L} causal={causal}")
 
 
+def _packed_mask(L, sh, e1, dev):
+    i = torch.arange(L, device=dev)[:, None]
+    j = torch.arange(L, device=dev)[None, :]
+    ok = (j <= i) & ~((i >= e1) & (j >= sh) & (j < e1))
+    return torch.where(ok, 0.0, float("-inf"))
+
+
+@pytest.mark.parametrize("L,segs", [(200, [(40, 120), (0, 64)]), (333, [(130, 260), (129, 131)]), (64, [(10, 30), (63, 64)])])
+def test_attn_packed_pairs_fwd_bwd(ops, L, segs):
+    """[shared | chosen | rejected] rows: rejected-branch queries must not see chosen-branch keys."""
+    dev = _dev()
+    S, H, hd = len(segs), 2, 128
+    qkv = rnd(S * L, 3 * H * hd, seed=L, dev=dev, scale=0.7)
+    do = rnd(S * L, H * hd, seed=L + 1, dev=dev)
+    sh = torch.tensor([a for a, _ in segs], dtype=torch.int32, device=dev)
+    e1 = torch.tensor([b for _, b in segs], dtype=torch.int32, device=dev)
+    out, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, H * hd, 2 * H * hd, seg=(sh, e1))
+    dqkv = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, True, 0, H * hd, 2 * H * hd, seg=(sh, e1))
+    qf = qkv.float().requires_grad_(True)
+    q, k, v = [qf[:, i * H * hd:(i + 1) * H * hd].view(S, L, H, hd).transpose(1, 2) for i in range(3)]
+    mask = torch.stack([_packed_mask(L, a, b, dev) for a, b in segs])[:, None]          # [S,1,L,L]
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + mask
+    ro = torch.softmax(sc, -1) @ v
+    close(out, ro.detach().transpose(1, 2).reshape(S * L, H * hd), rel=2e-2, what="packed attn fwd")
+    torch.testing.assert_close(lse, torch.logsumexp(sc, -1).detach(), rtol=1e-3, atol=2e-3)
+    ro.transpose(1, 2).reshape(S * L, H * hd).backward(do.float())
+    for i, nm in enumerate("qkv"):
+        sl = slice(i * H * hd, (i + 1) * H * hd)
+        close(dqkv[:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"packed attn bwd d{nm}")
+
+
+def test_rope_position_table(ops):
+    dev = _dev()
+    n, H, hd, L = 150, 2, 128, 64
+    buf = rnd(n, 2 * H * hd, seed=2, dev=dev)
+    orig = buf.clone()
+    pos = torch.randint(0, L, (n,), generator=torch.Generator().manual_seed(0)).to(torch.int32).to(dev)
+    cos, sin = ops.rope_tables(L, hd, 10000.0, dev)
+    ops.rope_inplace(buf, cos, sin, L, 2 * H, hd, pos=pos)
+    xf = orig.float().view(n, 2 * H, hd)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32, device=dev) / hd))
+    fr = pos[:, None].float() * inv[None]
+    c, s_ = torch.cat([fr, fr], -1).cos()[:, None], torch.cat([fr, fr], -1).sin()[:, None]
+    rot = torch.cat([-xf[..., hd // 2:], xf[..., :hd // 2]], -1)
+    close(buf, (xf * c + rot * s_).view(n, 2 * H * hd), what="rope pos table")
+
+
 # ------------------------------------------------------------------------------------------- LM head / loss
 def test_lmhead_logp_fwd_bwd(ops):
     dev = _dev()

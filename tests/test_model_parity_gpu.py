@@ -24,10 +24,11 @@ def _need_gpu():
         pytest.skip("needs a GPU")
 
 
-def _build(cfg_dict, seed):
+def _build(cfg_dict, seed, share_prefix=True):
     from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
     cfg = LlavaConfig(**cfg_dict)
     model = LlavaDPOModel(cfg)
+    model.share_prefix = share_prefix
     W = O.make_weights(O.LlavaCfg(**cfg_dict), seed=seed)
     model.load_state_dict(W)
     return model, W
@@ -43,24 +44,30 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
+@pytest.mark.parametrize("share_prefix", [False, True])
 @pytest.mark.parametrize("name", CASES)
-def test_forward_matches_reference_golden(golden_dir, name, monkeypatch):
+def test_forward_matches_reference_golden(golden_dir, name, monkeypatch, share_prefix):
     _need_gpu()
     g = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
     monkeypatch.setenv("SFT_weight", str(g["sft_weight"]))
     monkeypatch.setenv("DPO_weight", "1.0")
-    model, _ = _build(g["cfg"], g["seed"])
+    model, _ = _build(g["cfg"], g["seed"], share_prefix)
     tr = _trainer(model, g["dpo_use_average"])
     cfg = O.LlavaCfg(**g["cfg"])
     batch = O.make_synthetic_batch(cfg, g["n_pairs"], g["text_len"], g["prompt_len"], seed=g["seed"])
     loss = tr.compute_loss(model, dict(batch))
     out = model.last_out
     # ---- integer indexing: bit exact
-    assert torch.equal(out.plan.labels.cpu(), g["labels"])
     mask = g["labels"][:, 1:] != -100
     s_idx, l_idx = torch.nonzero(mask, as_tuple=True)
-    assert torch.equal(out.plan.sel_idx.cpu().long(), s_idx * g["labels"].shape[1] + l_idx)
+    if not share_prefix:
+        assert torch.equal(out.plan.labels.cpu(), g["labels"])
+        assert torch.equal(out.plan.sel_idx.cpu().long(), s_idx * g["labels"].shape[1] + l_idx)
+    else:
+        assert out.plan.S == g["n_pairs"] and max(out.plan.shared_len) > 0      # really packed
     assert torch.equal(out.plan.tgt.cpu().long(), g["labels"][:, 1:][mask])
+    assert torch.equal(out.plan.seq_of_row.cpu().long(), s_idx)
+    assert out.seq_cnt.cpu().tolist() == mask.sum(1).float().tolist()
     # ---- floating point
     ref_tok = g["per_token_logps"][mask]
     err_tok = (out.per_token_logp.cpu() - ref_tok).abs().max().item()
@@ -76,13 +83,14 @@ def test_forward_matches_reference_golden(golden_dir, name, monkeypatch):
     torch.testing.assert_close(out.per_pair[2].cpu(), g["rejected_rewards"], rtol=2e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("share_prefix", [False, True])
 @pytest.mark.parametrize("name", CASES[:2])
-def test_backward_matches_reference_golden(golden_dir, name, monkeypatch):
+def test_backward_matches_reference_golden(golden_dir, name, monkeypatch, share_prefix):
     _need_gpu()
     g = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
     monkeypatch.setenv("SFT_weight", str(g["sft_weight"]))
     monkeypatch.setenv("DPO_weight", "1.0")
-    model, _ = _build(g["cfg"], g["seed"])
+    model, _ = _build(g["cfg"], g["seed"], share_prefix)
     tr = _trainer(model, g["dpo_use_average"])
     cfg = O.LlavaCfg(**g["cfg"])
     batch = O.make_synthetic_batch(cfg, g["n_pairs"], g["text_len"], g["prompt_len"], seed=g["seed"])
@@ -151,7 +159,7 @@ def test_full_width_shallow_vs_oracle():
         W[k].requires_grad_(True)
     ref = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)
     out = model.last_out
-    assert torch.equal(out.plan.labels.cpu(), ref["labels"])
+    assert out.plan.S == 1 and out.plan.shared_len[0] > 0            # packed pair (default layout)
     err = (out.seq_logp.cpu() - ref["log_prob"].detach()).abs()
     print("full-width shallow: seq logp", out.seq_logp.tolist(), "ref", ref["log_prob"].tolist())
     assert bool((err <= 1e-3 * ref["log_prob"].detach().abs() + 5e-2).all())

@@ -47,5 +47,5 @@ for pad in (0, 64, 128):
     hip.call("rv_attn_delta", do, do.stride(0), o, o.stride(0), delta, S, L, H, hd)
     dqkv = torch.empty(S * L, 3 * d + pad, dtype=BF, device=dev)[:, :3 * d]
     t_b = timeit(lambda: hip.call("rv_attn_bwd", qkv, qkv.stride(0), 0, d, 2 * d, do, do.stride(0), lse,
-                                  delta, dqkv, dqkv.stride(0), S, L, H, hd, 1, 1.0 / math.sqrt(hd)))
+                                  delta, dqkv, dqkv.stride(0), S, L, H, hd, 1, 1.0 / math.sqrt(hd), None, None))
     print(f"pad {pad}: fwd {t_f:.3f} ms  bwd {t_b:.3f} ms", flush=True)
