@@ -49,7 +49,8 @@ class GemmTimer:
             s.record()
             r = orig(a, b, out=out, **kw)
             e.record()
-            recs.append((s, e, 2.0 * a.shape[0] * b.shape[0] * a.shape[1]))
+            recs.append((s, e, 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
+                         2.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[0])))
             return r
 
         ops.gemm_nt = timed
@@ -60,18 +61,20 @@ class GemmTimer:
             s.record()
             r = orig_tn(p, q, out=out, **kw)
             e.record()
-            recs.append((s, e, 2.0 * p.shape[0] * p.shape[1] * q.shape[1]))
+            recs.append((s, e, 2.0 * p.shape[0] * p.shape[1] * q.shape[1],
+                         2.0 * (p.shape[0] * p.shape[1] + q.shape[0] * q.shape[1] + p.shape[1] * q.shape[1])))
             return r
 
         ops.gemm_tn = timed_tn
         self._restore = lambda: (setattr(ops, "gemm_nt", orig), setattr(ops, "gemm_tn", orig_tn))
 
     def summary(self):
-        tot_ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        tot_fl = sum(f for _, _, f in self.records)
+        tot_ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        tot_fl = sum(r[2] for r in self.records)
+        alg_bytes = sum(r[3] for r in self.records)
         n = len(self.records)
         return dict(launches=n, total_ms=tot_ms, avg_ms=tot_ms / max(n, 1), tflops=tot_fl / max(tot_ms, 1e-9) / 1e9,
-                    flops=tot_fl)
+                    flops=tot_fl, alg_bytes=alg_bytes)
 
 
 def cpu_baseline(L: int, seed: int = 0):
@@ -207,9 +210,18 @@ def main():
         }
         if not args.no_gemm_timer:
             g = timer.summary()
+            traffic = None
+            try:       # HBM bytes per GEMM launch from the committed PMC passes (profiles/, separate rocprofv3 runs)
+                with open(os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
+                    traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
+            except Exception:
+                pass
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256_kernel / gemm_tn_256_kernel (256x256x32 ping-pong; all rv_gemm_nt_bf16 + rv_gemm_tn_bf16 launches)",
                                 "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                                "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+                                "traffic_note": "HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
+                                                "WRITE_SIZE, separate passes (profiles/r01_pmc_hbm_traffic.json); algorithmic "
+                                                "operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
                                 "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
                                 "gemm_ms_per_step": g["total_ms"] / args.steps}
         if world == 1 and not args.no_cpu_baseline:

@@ -54,6 +54,30 @@ __device__ __forceinline__ void mfma_agpr_zero(f32x16_t& acc) {
 // Row-operand reads are ds_read_b128 (32 rows x one chunk); chunk swizzles (see qtile_off for 256-byte rows):
 //   128-byte rows (head dim 64): chunk ^ f(row), f = ((x&1)<<2)|(x>>1) with x = (row>>1)&7.
 // =============================================================================================
+// Block -> (x, head, sequence).  Workgroups of one (sequence, head) share its K/V (1.8 MB at L = 3.5 k); the
+// dispatcher puts block b on XCD b % 8, so the plain (x, h, s) grid spreads every (s, h) over all 8 private L2s
+// and each K/V tile is re-fetched from HBM by every query block (PMC: 6.8 GB per forward launch = 6 TB/s, the
+// kernels were HBM bound).  Here the nx blocks of an (s, h) occupy consecutive slots of ONE XCD.
+__device__ __forceinline__ void attn_block_coords(int nx, int H, int S, int& x, int& h, int& s) {
+  const int id = blockIdx.x, HS = H * S;
+  const int mode = nx >> 16;      // experiment switch packed into the high bits by the launcher
+  nx &= 0xffff;
+  int hs;
+  if (mode == 1 && (HS & 7) == 0) {        // the nx blocks of an (s,h) on consecutive slots of one XCD
+    const int xcd = id & 7, j = id >> 3;
+    hs = (j / nx) * 8 + xcd;
+    x = j % nx;
+  } else if (mode == 2) {                  // (s,h) fastest: an (s,h) always lands on the same XCD, x spread in time
+    hs = id % HS;
+    x = id / HS;
+  } else {                                 // x fastest (plain)
+    hs = id / nx;
+    x = id % nx;
+  }
+  h = hs % H;
+  s = hs / H;
+}
+
 template <int HD>
 __device__ __forceinline__ uint32_t kvtile_off(int row, int c) {
   if (HD == 128) return (uint32_t)(row * 256 + ((c ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4));
@@ -116,7 +140,7 @@ struct TileDma {
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                            int k_col0, int v_col0, bf16_t* __restrict__ out, long ldo,
-                                                           float* __restrict__ lse, int L, int H, float scale,
+                                                           float* __restrict__ lse, int L, int H, int nx, float scale,
                                                            const int* __restrict__ seg_sh,
                                                            const int* __restrict__ seg_e1) {
   constexpr int KS = HD / 16, ET = HD / 32, TILE = 64 * HD * 2, STAGE = 2 * TILE;
@@ -125,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, half = lane >> 5;
   const int nqb = (L + 127) / 128;
-  const int h = blockIdx.y, s = blockIdx.z;
+  int bx, h, s;
+  attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
   const long tok0 = (long)s * L;
   // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
@@ -143,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-    const int qb = (pass == 0) ? (int)blockIdx.x : (nqb - 1 - (int)blockIdx.x);
-    if (pass == 1 && qb <= (int)blockIdx.x) break;
+    const int qb = (pass == 0) ? bx : (nqb - 1 - bx);
+    if (pass == 1 && qb <= bx) break;
     const int q0 = qb * 128, q0w = q0 + wave * 32;
     const int q = q0w + fr;
 
@@ -250,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
                                                               long lddo, const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
-                                                              float scale, const int* __restrict__ seg_sh,
+                                                              int nx, float scale, const int* __restrict__ seg_sh,
                                                               const int* __restrict__ seg_e1) {
   constexpr int HD = 128, KS = 8, ET = 4, TILE = 64 * HD * 2, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -258,7 +283,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, half = lane >> 5;
   const int nqb = (L + 127) / 128;
-  const int h = blockIdx.y, s = blockIdx.z;
+  int bx, h, s;
+  attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
   const long tok0 = (long)s * L;
   // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
@@ -276,8 +302,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-    const int qb = (pass == 0) ? (int)blockIdx.x : (nqb - 1 - (int)blockIdx.x);
-    if (pass == 1 && qb <= (int)blockIdx.x) break;
+    const int qb = (pass == 0) ? bx : (nqb - 1 - bx);
+    if (pass == 1 && qb <= bx) break;
     const int q0 = qb * 128, q0w = q0 + wave * 32;
     const int q = q0w + fr, qc = min(q, L - 1);
 
@@ -381,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, long lddq, int L, int H,
-                                                               float scale, const int* __restrict__ seg_sh,
+                                                               int nx, float scale, const int* __restrict__ seg_sh,
                                                                const int* __restrict__ seg_e1) {
   constexpr int HD = 128, KS = 8, ET = 4;
   constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64]
@@ -390,7 +416,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, half = lane >> 5;
-  const int h = blockIdx.y, s = blockIdx.z;
+  int bx, h, s;
+  attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
   const long tok0 = (long)s * L;
   // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
@@ -457,8 +484,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-    const int kvb = (pass == 0) ? (int)blockIdx.x : (nkb - 1 - (int)blockIdx.x);
-    if (pass == 1 && kvb <= (int)blockIdx.x) break;
+    const int kvb = (pass == 0) ? bx : (nkb - 1 - bx);
+    if (pass == 1 && kvb <= bx) break;
     const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
     const int key = kv0w + fr, keyc = min(key, L - 1);
 
@@ -559,7 +586,11 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
              "rv_attn_fwd: alignment");
   if (S == 0 || L == 0) return 0;
   const int nb = (L + 127) / 128;
-  dim3 grid(causal ? (nb + 1) / 2 : nb, H, S), block(256);
+  static int map_mode = -1;
+  if (map_mode < 0) { const char* e = getenv("RV_ATTN_MAP"); map_mode = e ? atoi(e) : 1; }
+  const int nxr = causal ? (nb + 1) / 2 : nb;
+  const int nx = nxr | (map_mode << 16);
+  dim3 grid(nxr * H * S), block(256);
   hipStream_t st = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
@@ -569,7 +600,7 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   }
 #define LAUNCH_FWD(HD_, C_)                                                                                      \
   hipLaunchKernelGGL((attn_fwd2_kernel<HD_, C_>), grid, block, 4 * 64 * HD_ * 2, st, (const bf16_t*)qkv, ld, q_col0, \
-                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, scale, seg_sh, seg_e1)
+                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1)
   if (hd == 128) { if (causal) LAUNCH_FWD(128, true); else LAUNCH_FWD(128, false); }
   else { if (causal) LAUNCH_FWD(64, true); else LAUNCH_FWD(64, false); }
 #undef LAUNCH_FWD
@@ -585,7 +616,11 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   RV_REQUIRE(ld % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0, "rv_attn_bwd: alignment");
   if (S == 0 || L == 0) return 0;
   const int nb = (L + 127) / 128;
-  dim3 grid(causal ? (nb + 1) / 2 : nb, H, S), block(256);
+  static int map_mode = -1;
+  if (map_mode < 0) { const char* e = getenv("RV_ATTN_MAP"); map_mode = e ? atoi(e) : 1; }
+  const int nxr = causal ? (nb + 1) / 2 : nb;
+  const int nx = nxr | (map_mode << 16);
+  dim3 grid(nxr * H * S), block(256);
   hipStream_t st = (hipStream_t)stream;
   constexpr int DQ_LDS = 4 * 64 * 256;
   constexpr int DKV_LDS = 2 * (2 * 64 * 256 + 512);
@@ -597,7 +632,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
     hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     attr_done = true;
   }
-#define BWD_ARGS (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, scale, seg_sh, seg_e1
+#define BWD_ARGS (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, nx, scale, seg_sh, seg_e1
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_ARGS);
     RV_CHECK_LAUNCH();
