@@ -14,17 +14,17 @@ void rv_set_error(const char* msg) {
 // -1 (default) = pick 2 when the problem fills the chip with 256x256 tiles, else 1.
 static int g_default_variant = -1;
 
-template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3>
+template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3, int SPLIT = 0>
 static int launch_gemm256(const GemmShape& g, const Epi& epi, hipStream_t st) {
   constexpr int LDS = (DMA_IN_MSEG ? DIST + 1 : 4) * G2_STAGE_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_nt_256_kernel<Epi, DMA_IN_MSEG, ABLATE, DIST>,
+    hipFuncSetAttribute((const void*)gemm_nt_256_kernel<Epi, DMA_IN_MSEG, ABLATE, DIST, SPLIT>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
-  hipLaunchKernelGGL((gemm_nt_256_kernel<Epi, DMA_IN_MSEG, ABLATE, DIST>), dim3(tiles_m * tiles_n), dim3(G2_THREADS),
+  hipLaunchKernelGGL((gemm_nt_256_kernel<Epi, DMA_IN_MSEG, ABLATE, DIST, SPLIT>), dim3(tiles_m * tiles_n), dim3(G2_THREADS),
                      LDS, st, g, epi);
   RV_CHECK_LAUNCH();
   return 0;
@@ -82,6 +82,8 @@ static int dispatch(const GemmShape& g, const Epi& epi, int variant, void* strea
   }
   if (variant == 101) return launch_gemm256<Epi, true, 1>(g, epi, (hipStream_t)stream);   // ablation: no DMA
   if (variant == 102) return launch_gemm256<Epi, true, 2>(g, epi, (hipStream_t)stream);   // ablation: stale ds_reads
+  if (variant == 103) return launch_gemm256<Epi, true, 3>(g, epi, (hipStream_t)stream);   // ablation: L2-resident DMA
+  if (variant == 6) return launch_gemm256<Epi, true, 0, 3, 1>(g, epi, (hipStream_t)stream);
   if (variant == 5) return launch_gemm256x64<Epi>(g, epi, (hipStream_t)stream);
   if (variant == 4) return launch_gemm256<Epi, true, 0, 4>(g, epi, (hipStream_t)stream);
   if (variant == 3) return launch_gemm256<Epi, true>(g, epi, (hipStream_t)stream);
@@ -104,7 +106,7 @@ extern "C" {
 const char* rv_last_error(void) { return g_err; }
 
 int rv_set_gemm_variant(int variant) {
-  RV_REQUIRE(variant >= -1 && variant <= 5, "rv_set_gemm_variant: -1 (auto), 0..5");
+  RV_REQUIRE(variant >= -1 && variant <= 6, "rv_set_gemm_variant: -1 (auto), 0..6");
   g_default_variant = variant;
   return 0;
 }

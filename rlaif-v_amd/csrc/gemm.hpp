@@ -177,9 +177,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, E
 // matrix pipe) instead of tile p+2 at the end of L-seg(p): the load segment shrinks to the 12 ds_reads.
 // WAR for stage (p+3)%4 = (p-1)%4: G0 issues after instance 2p = G1.Y(p-1), G1 after 2p+1 = G0.Y(p); both groups
 // retired their L-seg(p-1) reads before X(p-1).  RAW and the counted vmcnt(4) are unchanged.
-// ABLATE (debug/profiling only, results are wrong): 1 = no LDS-DMA in the main loop, 2 = no ds_reads in the loop.
+// ABLATE (debug/profiling only, results are wrong): 1 = no LDS-DMA in the main loop, 2 = no ds_reads in the loop,
+// 3 = DMA always re-reads K tile 0 (same instruction stream, every load an L2 hit).
 // DIST = prefetch distance in K tiles when DMA_IN_MSEG (ring of DIST+1 stages: 3 -> 128 KiB, 4 -> 160 KiB).
-template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3>
+// SPLIT = 1 (with DMA_IN_MSEG, DIST 3): pieces 0,1 of tile p+3 are issued at the end of L-seg(p), pieces 2,3 inside
+// M-seg(p) - a VMEM issue stalls the in-order wave for ~60 cycles and starves the matrix pipe, so half of them move
+// to the segment that is not using it.
+template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3, int SPLIT = 0>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g, Epi epi) {
   constexpr int NST = DMA_IN_MSEG ? DIST + 1 : 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
 
   auto issue_piece = [&](int t, int j) {   // j: 0 = A piece 0, 1 = B piece 0, 2 = A piece 1, 3 = B piece 1
     uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
-    const long koff = (long)t * G2_BK;
+    const long koff = (ABLATE == 3) ? 0 : (long)t * G2_BK;
     const int i = j >> 1;
     if ((j & 1) == 0)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
@@ -270,7 +274,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
       for (int t = 0; t < 4; ++t) af[ks][t] = *(const bf16x8_t*)(st + a_off[ks] + t * 2048);
     }
     if (!DMA_IN_MSEG && p + 2 < nt && ABLATE != 1) issue(p + 2);
-    {
+    if (SPLIT) {
+      if (p + DIST < nt) {
+        issue_piece(p + DIST, 0);
+        issue_piece(p + DIST, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile p+2 (4) + the two pieces just issued
+      } else if (p + 2 < nt) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {
       // tiles newer than p+1 that are already in flight (each = 4 DMA pieces of this wave)
       const int newer = (ABLATE == 1) ? 0 : min((DMA_IN_MSEG ? DIST : 2) - 1, nt - 2 - p);
       if (newer >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -294,9 +308,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
           constexpr int dummy = 0;
           (void)dummy;
           const int k = (ks * 4 + tm) * 2 + tn;
-          if (DMA_IN_MSEG && (k & 3) == 1) {
+          if (DMA_IN_MSEG && !SPLIT && (k & 3) == 1) {
             __builtin_amdgcn_sched_barrier(0);
             if (dma) issue_piece(p + DIST, k >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (DMA_IN_MSEG && SPLIT && (k & 7) == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (dma) issue_piece(p + DIST, 2 + (k >> 3));
             __builtin_amdgcn_sched_barrier(0);
           }
         }

@@ -46,17 +46,18 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
 class BucketedAllReduce(GradReducer):
     """Asynchronous bucketed SUM all-reduce over a flat gradient buffer."""
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 400 << 20):
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 400 << 20, force: bool = False):
         self.flat = flat_grad
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force          # issue the collectives even in a 1-rank group (exercises the RCCL path in tests)
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self._pending: Optional[Tuple[int, int]] = None
         self._works: List = []
         self.launched: List[Tuple[int, int]] = []      # (start, end) of every collective of the current step
 
     def _launch(self, start: int, end: int):
-        if self.world_size == 1 or end <= start:
+        if (self.world_size == 1 and not self.force) or end <= start:
             return
         self.launched.append((start, end))
         self._works.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group,

@@ -145,7 +145,8 @@ class LLaVA15DPOTrainer:
         self.args = args or TrainingArguments()
         self.train_dataset, self.eval_dataset, self.data_collator = train_dataset, eval_dataset, data_collator
         self.reducer = reducer or GradReducer()
-        self.model.grad_ready_hook = self.reducer.on_bucket_ready if self.reducer.world_size > 1 else None
+        self.model.grad_ready_hook = self.reducer.on_bucket_ready \
+            if (self.reducer.world_size > 1 or getattr(self.reducer, "force", False)) else None
         self.state = dict(global_step=0, log_history=[])
         self._clip = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._pending_metrics: Optional[torch.Tensor] = None

@@ -1,0 +1,49 @@
+"""RCCL path on the real device: a 1-rank NCCL(=RCCL) group with the collectives forced on, so the asynchronous
+bucketed all-reduce of the bf16 gradient buffer, its overlap with backward and the optimizer's wait are exercised
+on an MI355X (the 8-GPU run itself belongs to the driver).  Results must equal the run without a process group."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dpo_oracle as O  # noqa: E402
+
+
+def test_training_step_with_rccl_bucket_reduce():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.distributed as dist
+    from rlaif_v_amd.dist import BucketedAllReduce, init_process_group_from_env
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = O.tiny_cfg()
+        W = O.make_weights(cfg, seed=9)
+        batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=9)
+        losses, masters = [], []
+        for with_pg in (False, True):
+            model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)))
+            model.load_state_dict(W)
+            red = BucketedAllReduce(model.store.flat_g, bucket_bytes=1 << 20, force=True) if with_pg else None
+            tr = LLaVA15DPOTrainer(model=model, args=TrainingArguments(learning_rate=1e-3, warmup_ratio=0.0,
+                                                                       lr_scheduler_type="constant"), reducer=red)
+            for _ in range(2):
+                loss = tr.training_step(dict(batch))
+            if with_pg:
+                m = tr.pop_metrics()
+                assert "rewards_train/accuracies" in m and len(m) == 8
+            torch.cuda.synchronize()
+            losses.append(float(loss))
+            masters.append(model.store.flat_master.clone())
+        assert losses[0] == losses[1]
+        assert torch.equal(masters[0], masters[1])        # SUM over one rank == identity, bit for bit
+    finally:
+        dist.destroy_process_group()

@@ -17,9 +17,9 @@ for (M, N, K) in [(16384, 4096, 4096), (8192, 8192, 8192), (16384, 22016, 4096)]
     ref = ops.gemm_nt(a, b, variant=1)
     res = {}
     for rnd in range(3):
-        for name, v, aa, bb in [("v3", 3, a, b), ("v4 dist4", 4, a, b), ("v5 bk64", 5, a, b), ("no-DMA", 101, a, b)]:
+        for name, v, aa, bb in [("v3", 3, a, b), ("v6 split", 6, a, b), ("v2 Lseg", 2, a, b), ("no-DMA", 101, a, b)]:
             res.setdefault(name, []).append(timeit(lambda: ops.gemm_nt(aa, bb, out=c, variant=v)))
-            if v in (4, 5) and rnd == 0:
+            if v in (4, 5, 6) and rnd == 0:
                 print(f"v{v} exact:", torch.equal(c, ref))
     for name, v in res.items():
         ms = sorted(v)[1]
