@@ -339,14 +339,30 @@ class LlavaDPOModel:
 
     # ------------------------------------------------------------------ forward
     def forward_logps(self, input_ids: torch.Tensor, labels: torch.Tensor, images: torch.Tensor,
-                      save_for_backward: bool = True) -> StepOutput:
+                      save_for_backward: bool = True, all_rows: bool = False) -> StepOutput:
         """Everything of get_beta_and_logps up to ``get_batch_logps``: returns per-sequence log-prob sums
-        and counts (muffin/eval/muffin_inference_logp.py:82-115) without materialising logits."""
+        and counts (muffin/eval/muffin_inference_logp.py:82-115) without materialising logits.
+        ``all_rows`` (forward only, reference layout): evaluate EVERY position like
+        ``get_batch_logps(return_all=True)`` does - masked positions get the log-prob of token id 0, exactly what
+        the reference stores in its ``logps`` parquet column."""
         cfg, st = self.cfg, self.store
         d, H, hd, f = cfg.hidden, cfg.heads, cfg.head_dim, cfg.ffn
         B = images.shape[0]
         ctx: dict = {}
-        if self.share_prefix and input_ids.shape[0] == 2 * B:
+        w_rows = None
+        if all_rows:
+            if save_for_backward:
+                raise ValueError("all_rows is a forward-only mode")
+            plan = build_splice_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length)
+            nxt = plan.labels[:, 1:]
+            S_, Lm1 = nxt.shape
+            plan.sel_idx = (torch.arange(S_)[:, None] * plan.L + torch.arange(Lm1)[None]).reshape(-1).to(torch.int32)
+            plan.tgt = torch.where(nxt != -100, nxt, torch.zeros_like(nxt)).reshape(-1).to(torch.int32)
+            plan.seq_off = (torch.arange(S_ + 1) * Lm1).to(torch.int32)
+            plan.seq_of_row = torch.arange(S_).repeat_interleave(Lm1).to(torch.int32)
+            plan.n_sel = int(plan.sel_idx.numel())
+            w_rows = (nxt != -100).reshape(-1).to(torch.float32).to(self.device)     # loss_mask of get_batch_logps
+        elif self.share_prefix and input_ids.shape[0] == 2 * B:
             plan = build_packed_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length, cfg.pad_token_id)
         else:
             plan = build_splice_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length)
@@ -380,7 +396,6 @@ class LlavaDPOModel:
             rstd_f = torch.empty(0, dtype=torch.float32, device=self.device)
             logp = torch.empty(0, dtype=torch.float32, device=self.device)
             lse_v = logp
-        w_rows = None
         seq_logp, seq_cnt = ops.seq_sum(logp, plan.seq_off, plan.n_seq, weight=w_rows)
         out = StepOutput(loss=None, scalars=None, per_pair=None, seq_logp=seq_logp, seq_cnt=seq_cnt,
                          per_token_logp=logp, plan=plan)

@@ -173,3 +173,47 @@ def test_full_width_shallow_vs_oracle():
         rel = abs(float(grads[k].double().norm()) - float(W[k].grad.double().norm())) / float(W[k].grad.double().norm())
         print(f"  grad {k}: cos {c:.5f} norm rel err {rel:.3e}")
         assert c >= 0.99 and rel <= 5e-2, (k, c, rel)
+
+
+def test_reference_logp_precompute(tmp_path, golden_dir):
+    """inference_logp path (forward only, every position): values in the reference's `logps` column format."""
+    _need_gpu()
+    import json
+    import pandas as pd
+    from rlaif_v_amd.inference_logp import inference_logp
+    g = torch.load(os.path.join(golden_dir, "tiny_b2.pt"), weights_only=False)
+    cfg = O.LlavaCfg(**g["cfg"])
+    model, W = _build(g["cfg"], g["seed"])
+    batch = O.make_synthetic_batch(cfg, g["n_pairs"], g["text_len"], g["prompt_len"], seed=g["seed"])
+    B = g["n_pairs"]
+
+    class DS(torch.utils.data.Dataset):
+        data = [dict(question=f"q{i}", chosen="c", rejected="r", idx=i) for i in range(B)]
+
+        def __len__(self):
+            return B
+
+        def __getitem__(self, i):
+            def trim(ids, lab):
+                n = int((lab != -100).nonzero()[-1]) + 1
+                return ids[:n], lab[:n]
+            wi, wl = trim(batch["win_input_ids"][i], batch["win_labels"][i])
+            ri, rl = trim(batch["rej_input_ids"][i], batch["rej_labels"][i])
+            return dict(input_ids=ri, labels=rl, image=batch["images"][i]), dict(input_ids=wi, labels=wl, image=batch["images"][i])
+
+    logps = inference_logp(model, None, DS(), str(tmp_path), batch_size=2)
+    with torch.no_grad():
+        ref = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)
+    for i in range(B):
+        win_lp, win_avg, win_tok, rej_lp, rej_avg, rej_tok = logps[i]
+        assert abs(win_lp - float(ref["log_prob"][i])) <= 1e-3 * abs(float(ref["log_prob"][i])) + 5e-2
+        assert abs(rej_lp - float(ref["log_prob"][B + i])) <= 1e-3 * abs(float(ref["log_prob"][B + i])) + 5e-2
+        assert abs(win_avg - float(ref["average_log_prob"][i])) <= 5e-3
+        # every position, incl. masked ones (log-prob of token id 0 there), in the reference's per-token layout
+        n = len(win_tok)
+        torch.testing.assert_close(torch.tensor(win_tok), ref["per_token_logps"][i, :n], rtol=0, atol=3e-2)
+    files = sorted(os.listdir(tmp_path))
+    assert files == [f"RLAIF-V-Dataset-withlogp_000-{B}.parquet"]
+    df = pd.read_parquet(os.path.join(tmp_path, files[0]))
+    rec = json.loads(df.iloc[0]["logps"])["logps"]
+    assert len(rec) == 6 and abs(rec[0] - logps[0][0]) < 1e-6 and list(df.columns) == ["question", "chosen", "rejected", "idx", "logps"]
