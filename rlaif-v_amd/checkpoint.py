@@ -1,0 +1,119 @@
+"""HF-layout checkpoint I/O.
+
+The reference saves ``trainer.model.state_dict()`` through HF's ``_save`` (muffin/train/train_llava15.py:102-112) and
+loads released checkpoints with ``from_pretrained`` (llava/model/builder.py:26-167).  Here the same key names
+(``model.layers.N.self_attn.q_proj.weight`` ..., ``model.mm_projector.*``,
+``model.vision_tower.vision_tower.vision_model.*``, ``lm_head.weight``) are written as sharded safetensors with the
+standard ``model.safetensors.index.json`` + ``config.json``, so the output loads in the reference's chat / eval code,
+and a released LLaVA-1.5 checkpoint directory (safetensors or ``pytorch_model*.bin``) loads into ``LlavaDPOModel``.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+
+def hf_config_dict(cfg) -> Dict:
+    """LlavaConfig (HF ``llava_llama``) fields of the checkpoint's config.json."""
+    return {
+        "architectures": ["LlavaLlamaForCausalLM"], "model_type": "llava_llama",
+        "hidden_size": cfg.hidden, "intermediate_size": cfg.ffn, "num_hidden_layers": cfg.layers,
+        "num_attention_heads": cfg.heads, "num_key_value_heads": cfg.heads, "vocab_size": cfg.vocab,
+        "rms_norm_eps": cfg.rms_eps, "rope_theta": cfg.rope_theta, "max_position_embeddings": 4096,
+        "pad_token_id": cfg.pad_token_id, "bos_token_id": 1, "eos_token_id": 2, "hidden_act": "silu",
+        "torch_dtype": "bfloat16", "tie_word_embeddings": False, "use_cache": True,
+        "mm_vision_tower": "openai/clip-vit-large-patch14-336", "mm_projector_type": "mlp2x_gelu",
+        "mm_hidden_size": cfg.clip_hidden, "mm_vision_select_layer": cfg.select_layer,
+        "mm_vision_select_feature": "patch", "mm_patch_merge_type": "flat", "image_aspect_ratio": "pad",
+        "tokenizer_model_max_length": cfg.model_max_length, "tokenizer_padding_side": "right",
+        "mm_use_im_start_end": False, "mm_use_im_patch_token": False, "use_mm_proj": True,
+    }
+
+
+def config_from_hf(d: Dict, **overrides):
+    from .model import LlavaConfig
+    kw = dict(hidden=d["hidden_size"], layers=d["num_hidden_layers"], heads=d["num_attention_heads"],
+              ffn=d["intermediate_size"], vocab=d["vocab_size"], rms_eps=d.get("rms_norm_eps", 1e-5),
+              rope_theta=d.get("rope_theta", 10000.0), clip_hidden=d.get("mm_hidden_size", 1024),
+              select_layer=d.get("mm_vision_select_layer", -2),
+              model_max_length=d.get("tokenizer_model_max_length", 2048), pad_token_id=d.get("pad_token_id") or 0)
+    if d.get("num_key_value_heads", d["num_attention_heads"]) != d["num_attention_heads"]:
+        raise NotImplementedError("grouped-query attention checkpoints are not supported (LLaVA-1.5 uses MHA)")
+    kw.update(overrides)
+    return LlavaConfig(**kw)
+
+
+def save_state_dict_sharded(sd: Dict[str, torch.Tensor], output_dir: str, cfg=None,
+                            max_shard_bytes: int = 5 << 30) -> Dict:
+    """Write ``sd`` (CPU tensors, HF names) as model-XXXXX-of-YYYYY.safetensors + index (+ config.json)."""
+    from safetensors.torch import save_file
+    os.makedirs(output_dir, exist_ok=True)
+    shards, cur, cur_bytes = [], {}, 0
+    for k in sd:                                     # keep the caller's (layer) order inside shards
+        t = sd[k].detach().contiguous().cpu()
+        nbytes = t.numel() * t.element_size()
+        if cur and cur_bytes + nbytes > max_shard_bytes:
+            shards.append(cur)
+            cur, cur_bytes = {}, 0
+        cur[k] = t
+        cur_bytes += nbytes
+    if cur:
+        shards.append(cur)
+    index = {"metadata": {"total_size": sum(v.numel() * v.element_size() for s in shards for v in s.values())},
+             "weight_map": {}}
+    for i, shard in enumerate(shards):
+        name = "model.safetensors" if len(shards) == 1 else f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+        save_file(shard, os.path.join(output_dir, name), metadata={"format": "pt"})
+        for k in shard:
+            index["weight_map"][k] = name
+    if len(shards) > 1:
+        with open(os.path.join(output_dir, "model.safetensors.index.json"), "w") as f:
+            json.dump(index, f, indent=2)
+    if cfg is not None:
+        with open(os.path.join(output_dir, "config.json"), "w") as f:
+            json.dump(hf_config_dict(cfg), f, indent=2)
+    return index
+
+
+def load_state_dict_dir(ckpt_dir: str) -> Dict[str, torch.Tensor]:
+    """All tensors of an HF checkpoint directory (safetensors shards preferred, else pytorch_model*.bin)."""
+    sd: Dict[str, torch.Tensor] = {}
+    st_files = sorted(glob.glob(os.path.join(ckpt_dir, "*.safetensors")))
+    if st_files:
+        from safetensors.torch import load_file
+        for f in st_files:
+            sd.update(load_file(f))
+        return sd
+    bin_files = sorted(glob.glob(os.path.join(ckpt_dir, "pytorch_model*.bin")))
+    if not bin_files:
+        raise FileNotFoundError(f"no *.safetensors or pytorch_model*.bin under {ckpt_dir}")
+    for f in bin_files:
+        sd.update(torch.load(f, map_location="cpu", weights_only=True))
+    return sd
+
+
+def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30):
+    """Trainable part (LLM + projector) + the frozen CLIP tower under the reference's key names."""
+    sd = model.state_dict()
+    sd.update(model.clip_state_dict())
+    return save_state_dict_sharded(sd, output_dir, model.cfg, max_shard_bytes)
+
+
+def from_pretrained(ckpt_dir: str, device="cuda:0", with_optimizer: bool = True, **cfg_overrides):
+    """Build a LlavaDPOModel from an HF LLaVA-1.5 checkpoint directory (vision tower weights may live in the same
+    directory - as our own save_pretrained writes them - or in ``vision_tower_dir``)."""
+    from .model import LlavaDPOModel
+    vt_dir = cfg_overrides.pop("vision_tower_dir", None)
+    with open(os.path.join(ckpt_dir, "config.json")) as f:
+        cfg = config_from_hf(json.load(f), **cfg_overrides)
+    sd = load_state_dict_dir(ckpt_dir)
+    if vt_dir is not None:
+        vt = load_state_dict_dir(vt_dir)
+        sd.update({("model.vision_tower.vision_tower." + k if not k.startswith("model.") else k): v for k, v in vt.items()})
+    model = LlavaDPOModel(cfg, device=device, with_optimizer=with_optimizer)
+    model.load_state_dict(sd)
+    return model

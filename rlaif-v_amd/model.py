@@ -218,6 +218,7 @@ class LlavaDPOModel:
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         """HF-named fp32/bf16 CPU tensors (the reference's checkpoint layout, 4.35 CLIP key names)."""
         cfg, st = self.cfg, self.store
+        self._clip_raw = {k: v.detach().to(BF16).cpu() for k, v in sd.items() if k.startswith(VT)}
         for name, (key, r0, n) in st.hf_slices(cfg).items():
             st.p(key)[r0:r0 + n].copy_(sd[name].to(BF16))
         st.sync_master_from_params()
@@ -284,6 +285,10 @@ class LlavaDPOModel:
         for name, (key, r0, n) in self.store.hf_slices(self.cfg).items():
             out[name] = self.store.p(key)[r0:r0 + n].detach().cpu().clone()
         return out
+
+    def clip_state_dict(self) -> Dict[str, torch.Tensor]:
+        """The frozen tower under its checkpoint key names (kept from load_state_dict; empty after init_random)."""
+        return dict(getattr(self, "_clip_raw", {}))
 
     def grads_state_dict(self) -> Dict[str, torch.Tensor]:
         out = {}

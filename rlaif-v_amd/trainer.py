@@ -258,8 +258,11 @@ class LLaVA15DPOTrainer:
         """HF-layout weights (safe_save_model_for_hf_trainer, train_llava15.py:102-112)."""
         if int(os.environ.get("RANK", "0")) != 0:
             return
-        os.makedirs(output_dir, exist_ok=True)
-        torch.save(state_dict or self.model.state_dict(), os.path.join(output_dir, "pytorch_model.bin"))
+        from .checkpoint import save_pretrained, save_state_dict_sharded
+        if state_dict is None:
+            save_pretrained(self.model, output_dir)          # sharded safetensors + index + config.json, HF names
+        else:
+            save_state_dict_sharded(state_dict, output_dir, self.model.cfg)
 
     def save_state(self):
         if int(os.environ.get("RANK", "0")) != 0:

@@ -194,3 +194,26 @@ def test_param_store_layout_and_schedules():
     d, f, V = big.hidden, big.ffn, big.vocab
     n = 2 * V * d + 32 * (4 * d * d + 3 * d * f + 2 * d) + d + (d * 1024 + d) + (d * d + d)
     assert n == 6_759_272_448 or n > 6.7e9
+
+
+def test_checkpoint_roundtrip_hf_layout(tmp_path):
+    from rlaif_v_amd.checkpoint import (config_from_hf, hf_config_dict, load_state_dict_dir, save_state_dict_sharded)
+    from rlaif_v_amd.model import LlavaConfig
+    import json
+    cfg = LlavaConfig(**O.asdict(O.tiny_cfg()))
+    sd = {k: v.to(torch.bfloat16) for k, v in O.make_weights(O.tiny_cfg(), seed=3).items()}
+    index = save_state_dict_sharded(sd, str(tmp_path), cfg, max_shard_bytes=1 << 20)     # forces several shards
+    files = sorted(os.listdir(tmp_path))
+    assert "config.json" in files and "model.safetensors.index.json" in files and sum(f.endswith(".safetensors") for f in files) > 2
+    assert set(index["weight_map"]) == set(sd)
+    back = load_state_dict_dir(str(tmp_path))
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    cfg2 = config_from_hf(json.load(open(tmp_path / "config.json")), clip_layers=cfg.clip_layers, clip_heads=cfg.clip_heads,
+                          clip_ffn=cfg.clip_ffn, image_size=cfg.image_size)
+    assert cfg2 == cfg
+    assert hf_config_dict(cfg)["model_type"] == "llava_llama"
+    # legacy .bin checkpoints load too
+    os.makedirs(tmp_path / "bin")
+    torch.save(sd, tmp_path / "bin" / "pytorch_model.bin")
+    back2 = load_state_dict_dir(str(tmp_path / "bin"))
+    assert all(torch.equal(back2[k], sd[k]) for k in sd)

@@ -217,3 +217,29 @@ def test_reference_logp_precompute(tmp_path, golden_dir):
     df = pd.read_parquet(os.path.join(tmp_path, files[0]))
     rec = json.loads(df.iloc[0]["logps"])["logps"]
     assert len(rec) == 6 and abs(rec[0] - logps[0][0]) < 1e-6 and list(df.columns) == ["question", "chosen", "rejected", "idx", "logps"]
+
+
+def test_checkpoint_save_load_resume(tmp_path):
+    """save_pretrained (HF names, safetensors) -> from_pretrained gives the same model; optimizer resume continues
+    bit-identically (muffin/train/train_llava15.py:102-112, :326-331)."""
+    _need_gpu()
+    from rlaif_v_amd.checkpoint import from_pretrained, save_pretrained
+    cfg = O.tiny_cfg()
+    model, W = _build(O.asdict(cfg), seed=4)
+    tr = _trainer(model, learning_rate=1e-3, warmup_ratio=0.0, lr_scheduler_type="constant", output_dir=str(tmp_path))
+    batch = O.make_synthetic_batch(cfg, 2, 36, 12, seed=4)
+    tr.training_step(dict(batch))
+    tr.save_checkpoint(str(tmp_path / "checkpoint-1"))
+    save_pretrained(model, str(tmp_path / "hf"))
+    m2 = from_pretrained(str(tmp_path / "hf"), clip_layers=cfg.clip_layers, clip_heads=cfg.clip_heads,
+                         clip_ffn=cfg.clip_ffn, image_size=cfg.image_size)
+    sd1, sd2 = model.state_dict(), m2.state_dict()
+    assert set(sd1) == set(sd2) and all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+    assert all(torch.equal(model.clip[k], m2.clip[k]) for k in model.clip)
+    # resume: optimizer state + master weights restored -> the next step is bit-identical
+    tr2 = _trainer(m2, learning_rate=1e-3, warmup_ratio=0.0, lr_scheduler_type="constant")
+    tr2.load_checkpoint(str(tmp_path / "checkpoint-1"))
+    l1 = tr.training_step(dict(batch))
+    l2 = tr2.training_step(dict(batch))
+    assert float(l1) == float(l2) and torch.equal(model.store.flat_master, m2.store.flat_master)
+    assert tr2.state["global_step"] == 2
