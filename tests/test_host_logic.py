@@ -217,3 +217,56 @@ def test_checkpoint_roundtrip_hf_layout(tmp_path):
     torch.save(sd, tmp_path / "bin" / "pytorch_model.bin")
     back2 = load_state_dict_dir(str(tmp_path / "bin"))
     assert all(torch.equal(back2[k], sd[k]) for k in sd)
+
+
+def test_sample_encoding_matches_reference_golden(golden_dir, tmp_path):
+    """preprocess_v1 / tokenizer_image_token / encode_multimodal_preference_sample vs the reference's own functions
+    (tests/golden/make_preprocess_golden.py), then the parquet -> RLAIFVDataset -> DPODataset -> collator chain."""
+    import json
+    import sys
+    sys.path.insert(0, golden_dir)
+    from toy_tokenizer import SAMPLES, ToyTokenizer
+    from rlaif_v_amd.dataset import (DPODataset, encode_multimodal_preference_sample, llava_v1_prompt, preprocess_v1,
+                                      tokenizer_image_token)
+    from rlaif_v_amd.data import DataCollatorForDPODataset
+    gold = torch.load(os.path.join(golden_dir, "preprocess.pt"), weights_only=False)
+    tok = ToyTokenizer()
+    cfg = dict(image_processor=lambda img: torch.full((3, 4, 4), float(img)), keep_image_tag=True, is_multimodal=True)
+    for i, s in enumerate(SAMPLES):
+        src = dict(image=i, question={"from": "human", "value": f"<image>\n{s['question']}"},
+                   chosen={"from": "gpt", "value": s["chosen"]}, rejected={"from": "gpt", "value": s["rejected"]},
+                   ref_win_logp=-1.0 - i, ref_rej_logp=-2.0 - i, ref_win_avg_logp=-0.1, ref_rej_avg_logp=-0.2,
+                   ref_win_per_token_logp=[0.0, -1.0], ref_rej_per_token_logp=[-2.0])
+        rej, win = encode_multimodal_preference_sample(src, tok, cfg)
+        for got, ref in ((rej, gold[i]["rej"]), (win, gold[i]["win"])):
+            assert set(got) == set(ref)
+            for k, v in ref.items():
+                if torch.is_tensor(v):
+                    assert torch.equal(got[k], v), k
+                else:
+                    assert got[k] == v, k
+        assert int((win["input_ids"] == -200).sum()) == 1
+    p = llava_v1_prompt([{"from": "human", "value": "<image>\nhi"}, {"from": "gpt", "value": "yo"}])
+    assert p.endswith("USER: <image>\nhi ASSISTANT: yo</s>")
+    assert tokenizer_image_token("a <image> b", tok).count(-200) == 1
+
+    # parquet rows (reference schema incl. the JSON logps column) -> dataset -> collator
+    import pandas as pd
+    from PIL import Image
+    import io
+    rows = []
+    for i, s in enumerate(SAMPLES):
+        buf = io.BytesIO()
+        Image.new("RGB", (8, 8), (10 * i, 20, 30)).save(buf, format="PNG")
+        n_w, n_r = 60, 60
+        rows.append(dict(image={"bytes": buf.getvalue()}, question=s["question"], chosen=s["chosen"], rejected=s["rejected"],
+                         origin_dataset="toy", origin_split="train", idx=i, image_path=f"{i}.png",
+                         logps=json.dumps({"logps": [-5.0 - i, -0.5, [0.0] * n_w, -6.0 - i, -0.6, [0.0] * n_r]})))
+    pd.DataFrame(rows).to_parquet(tmp_path / "RLAIF-V-Dataset-withlogp_000-3.parquet")
+    ds = DPODataset(tok, str(tmp_path), dict(image_processor=lambda im: torch.zeros(3, 4, 4), is_multimodal=True))
+    assert len(ds) == 3
+    batch = DataCollatorForDPODataset(tok, beta=0.1, mod_token_weight=1.0)([ds[i] for i in range(3)])
+    assert batch["images"].shape == (3, 3, 4, 4) and batch["ref_win_logp"].tolist() == [-5.0, -6.0, -7.0]
+    assert batch["concatenated_input_ids"].shape[0] == 6 and (batch["concatenated_input_ids"] == -200).sum() == 6
+    with pytest.raises(FileNotFoundError):
+        DPODataset(tok, str(tmp_path / "empty"), {})
