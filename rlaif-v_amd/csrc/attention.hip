@@ -98,17 +98,11 @@ struct TrOffsets {
         off[u][et] = kvtile_off<HD>(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
                      (uint32_t)((s16 & 1) * 8);
   }
-  // 8 contraction rows row0 + {4*half + 0..3, 8 + 4*half + 0..3} of column et*32 + (lane&31); row0 % 16 == 0
-  __device__ __forceinline__ bf16x8_t read(const uint8_t* tile, int row0, int et) const {
-    typedef __attribute__((ext_vector_type(4))) short s4_t;
-    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s4_t*)(tile + off[0][et] + row0 * (HD * 2)));
-    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s4_t*)(tile + off[1][et] + row0 * (HD * 2)));
-    bf16x8_t v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return v;
+  // 8 contraction rows row0 + {4*half + 0..3, 8 + 4*half + 0..3} of column et*32 + (lane&31); row0 % 16 == 0.
+  // Inline-asm reads (common.hpp ds_tr16_b64_asm): the CALLER waits lgkmcnt and fences before the first use.
+  __device__ __forceinline__ bf16x8_t read(uint32_t tile_addr, int row0, int et) const {
+    return __builtin_shufflevector(ds_tr16_b64_asm(tile_addr + off[0][et], row0 * (HD * 2)),
+                                   ds_tr16_b64_asm(tile_addr + off[1][et], row0 * (HD * 2)), 0, 1, 2, 3, 4, 5, 6, 7);
   }
 };
 
@@ -210,42 +204,57 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
             sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
           }
         }
-        float tmax = -INFINITY;
+        // The tile needs element masks only when it touches the sequence end, the causal diagonal of this wave
+        // or the chosen-branch window of a packed pair; interior tiles (the vast majority) skip ~200 VALU ops.
+        const bool need_mask = (k0 + 63 >= L) || (CAUSAL && k0 + 63 > q0w) ||
+                               (q0w + 31 >= e1 && k0 + 63 >= sh && k0 < e1);
+        if (need_mask) {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) sacc[kt][r] = -INFINITY;
+            }
+        }
+        float tmax = -INFINITY;                      // raw-score maximum (c > 0 keeps the order)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = sacc[kt][r] * c;
-            if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) v = -INFINITY;
-            sacc[kt][r] = v;
-            tmax = fmaxf(tmax, v);
-          }
+          for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kt][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run, tmax * c);
+        const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);   // row still empty
+        const float neg_m = (m_new == -INFINITY) ? 0.f : -m_new;     // a fully masked row keeps p = exp2(-inf) = 0
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float p = exp2f(sacc[kt][r] - m_new);
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c, neg_m));   // one v_fma + one v_exp
             sacc[kt][r] = p;
             psum += p;
           }
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                // the running maximum rarely moves after the first tiles
 #pragma unroll
-        for (int e = 0; e < ET; ++e)
+          for (int e = 0; e < ET; ++e)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
+            for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
+        }
+        const uint32_t vs_addr = lds_addr_of(Vs);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const bf16x8_t pf = pack_frag(sacc[kk >> 1], (kk & 1) * 8);
+          bf16x8_t vfr[ET];
 #pragma unroll
-          for (int e = 0; e < ET; ++e)
-            o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tro.read(Vs, kk * 16, e), pf, o[e], 0, 0, 0);
+          for (int e = 0; e < ET; ++e) vfr[e] = tro.read(vs_addr, kk * 16, e);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < ET; ++e) o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[e], pf, o[e], 0, 0, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -351,19 +360,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
             const bf16x8_t vf = *(const bf16x8_t*)(Vs + boff[ks] + kt * 32 * HD * 2);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
           }
+          const bool need_mask = (k0 + 63 >= L) || (CAUSAL && k0 + 63 > q0w) ||
+                                 (q0w + 31 >= e1 && k0 + 63 >= sh && k0 < e1);
+          if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) sacc[r] = -INFINITY;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float p = exp2f(sacc[r] * c - lse_q);
-            if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) p = 0.f;
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse_q));   // masked: exp2(-inf) = 0
             sacc[r] = p * (pacc[r] - delta_q);
           }
+          const uint32_t ks_addr = lds_addr_of(Ks);
 #pragma unroll
           for (int k2 = 0; k2 < 2; ++k2) {
             const bf16x8_t df = pack_frag(sacc, k2 * 8);
+            bf16x8_t kfr[ET];
 #pragma unroll
-            for (int e = 0; e < ET; ++e)
-              dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tro.read(Ks, kt * 32 + k2 * 16, e), df, dq[e], 0, 0, 0);
+            for (int e = 0; e < ET; ++e) kfr[e] = tro.read(ks_addr, kt * 32 + k2 * 16, e);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < ET; ++e) dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[e], df, dq[e], 0, 0, 0);
           }
         }
       }
@@ -470,16 +491,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     for (int et = 0; et < ET; ++et)
       toff[u][et] = qtile_off(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
                     (uint32_t)((s16 & 1) * 8);
-  auto tr8 = [&](const uint8_t* tile, int row0, int et) -> bf16x8_t {   // row0 = qt*32 + k2*16 (multiple of 16)
-    typedef __attribute__((ext_vector_type(4))) short s4_t;
-    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s4_t*)(tile + toff[0][et] + row0 * 256));
-    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s4_t*)(tile + toff[1][et] + row0 * 256));
-    bf16x8_t v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return v;
+  auto tr8 = [&](uint32_t tile_addr, int row0, int et) -> bf16x8_t {   // row0 = qt*32 + k2*16; asm reads: caller waits
+    return __builtin_shufflevector(ds_tr16_b64_asm(tile_addr + toff[0][et], row0 * 256),
+                                   ds_tr16_b64_asm(tile_addr + toff[1][et], row0 * 256), 0, 1, 2, 3, 4, 5, 6, 7);
   };
 
   const int npass = CAUSAL ? 2 : 1;
@@ -530,12 +544,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
             const bf16x8_t df = *(const bf16x8_t*)(dOs + boff[ks] + qt * 8192);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], pacc, 0, 0, 0);
           }
+          const int qsub = qs0 + qt * 32;                      // first query of this 32-row sub-tile
+          const bool need_mask = (qsub + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qsub) ||
+                                 (qsub + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
+          if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int qg = qsub + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (qg >= L || key >= L || (CAUSAL && key > qg) || (qg >= e1 && key >= sh && key < e1)) sacc[r] = -INFINITY;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int qg = qs0 + ql;
-            float p = exp2f(sacc[r] * c - lse_s[ql] * LOG2E);
-            if (qg >= L || key >= L || (CAUSAL && key > qg) || (qg >= e1 && key >= sh && key < e1)) p = 0.f;
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -LOG2E * lse_s[ql]));
             sacc[r] = p;
             pacc[r] = p * (pacc[r] - delta_s[ql]);
           }
@@ -544,10 +566,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
             const bf16x8_t pf = pack_frag(sacc, k2 * 8);
             const bf16x8_t dsf = pack_frag(pacc, k2 * 8);
             const int row0 = qt * 32 + k2 * 16;
+            bf16x8_t dotf[ET], qtf[ET];
 #pragma unroll
             for (int e = 0; e < ET; ++e) {
-              mfma_agpr(dv[e], tr8(dOs, row0, e), pf);
-              mfma_agpr(dk[e], tr8(Qs, row0, e), dsf);
+              dotf[e] = tr8(lds_addr_of(dOs), row0, e);
+              qtf[e] = tr8(lds_addr_of(Qs), row0, e);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < ET; ++e) {
+              mfma_agpr(dv[e], dotf[e], pf);
+              mfma_agpr(dk[e], qtf[e], dsf);
             }
           }
         }

@@ -58,6 +58,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// ds_read_b64_tr_b16 through inline asm.  The clang builtin makes hipcc put `s_waitcnt vmcnt(0)` in front of the
+// first transposing read of a loop body (it treats it as a consumer of every LDS-DMA in flight), which drains the
+// global_load_lds prefetch the ping-pong / double-buffer schedules rely on.  An asm read is invisible to that
+// bookkeeping: the CALLER must `s_waitcnt lgkmcnt(..)` + __builtin_amdgcn_sched_barrier(0) before the first use.
+// Two reads into adjacent register pairs form one 8 x bf16 MFMA operand without any move.
+typedef __attribute__((ext_vector_type(4))) short bf16x4s_t;
+__device__ __forceinline__ bf16x4s_t ds_tr16_b64_asm(uint32_t lds_addr, int imm_offset) {
+  bf16x4s_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(imm_offset) : "memory");
+  return v;
+}
+__device__ __forceinline__ bf16x8_t ds_tr16_pair_asm(uint32_t lds_addr, int off_lo, int off_hi) {
+  return __builtin_shufflevector(ds_tr16_b64_asm(lds_addr, off_lo), ds_tr16_b64_asm(lds_addr, off_hi), 0, 1, 2, 3, 4,
+                                 5, 6, 7);
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)p; }
+
 // Error plumbing for the C ABI (no exceptions across the boundary).
 void rv_set_error(const char* msg);
 #define RV_CHECK_LAUNCH()                                   \

@@ -463,7 +463,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256x64_kernel(GemmShape
 // read hit 4 different quarters of the 256-byte bank row); applied on the DMA source address.
 // Rows r >= R of the last tile are redirected to a zero row (zero_row: >= 512 zero bytes in HBM).
 // =============================================================================================
-typedef __attribute__((ext_vector_type(4))) short bf16x4s_t;
 __device__ bf16_t g_zero_row[256];   // 512 zero bytes: DMA source for contraction rows beyond R
 
 template <class Epi>
@@ -529,15 +528,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
 #pragma unroll
   for (int t = 0; t < 4; ++t) p_blk[t] = lane_part + (uint32_t)((((wi * 4 + t) ^ (s16 >> 2))) << 6);
 
-  auto tr8 = [&](const uint8_t* st, uint32_t off) -> bf16x8_t {
-    const bf16x4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4s_t*)(st + off));
-    const bf16x4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4s_t*)(st + off + 2048));
-    bf16x8_t v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return v;
-  };
-
   f32x16_t acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -562,12 +552,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   for (int p = 0; p < nt; ++p) {
     const uint8_t* st = smem + (p % NST) * G2_STAGE_BYTES;
     bf16x8_t qf[2][2], pf[2][4];
+    const uint32_t sta = lds_addr_of(st);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t a0 = sta + q_blk[t];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) qf[ks][t] = tr8(st, q_blk[t] + ks * 8192);
+      for (int ks = 0; ks < 2; ++ks) qf[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
+    }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) pf[ks][t] = tr8(st, p_blk[t] + ks * 8192);
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t a0 = sta + p_blk[t];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) pf[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
     }
     {
       const int newer = min(DIST - 1, nt - 2 - p);

@@ -307,7 +307,8 @@ def _packed_mask(L, sh, e1, dev):
     return torch.where(ok, 0.0, float("-inf"))
 
 
-@pytest.mark.parametrize("L,segs", [(200, [(40, 120), (0, 64)]), (333, [(130, 260), (129, 131)]), (64, [(10, 30), (63, 64)])])
+@pytest.mark.parametrize("L,segs", [(200, [(40, 120), (0, 64)]), (333, [(130, 260), (129, 131)]), (64, [(10, 30), (63, 64)]),
+                                    (300, [(0, 40), (0, 100)])])
 def test_attn_packed_pairs_fwd_bwd(ops, L, segs):
     """[shared | chosen | rejected] rows: rejected-branch queries must not see chosen-branch keys."""
     dev = _dev()
