@@ -2,6 +2,7 @@
 #include "gemm.hpp"
 #include "rlaifv_hip.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -13,6 +14,7 @@ void rv_set_error(const char* msg) {
 // variants: 0 = 128x128x64 register staging, 1 = 128x128x64 global_load_lds, 2 = 256x256x32 ping-pong,
 // -1 (default) = pick 2 when the problem fills the chip with 256x256 tiles, else 1.
 static int g_default_variant = -1;
+static int g_group = 0;     // experiment knob: RV_GEMM_GROUP
 
 template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3, int SPLIT = 0>
 static int launch_gemm256(const GemmShape& g, const Epi& epi, hipStream_t st) {
@@ -75,6 +77,8 @@ static int launch_gemm(const GemmShape& g, const Epi& epi, hipStream_t st) {
 
 template <class Epi>
 static int dispatch(const GemmShape& g, const Epi& epi, int variant, void* stream) {
+  static bool env_done = false;
+  if (!env_done) { const char* e = getenv("RV_GEMM_GROUP"); if (e) g_group = atoi(e); env_done = true; }
   if (variant < 0) variant = g_default_variant;
   if (variant < 0) {
     const long t256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
@@ -117,7 +121,7 @@ int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
                     const void* bias, const void* residual, long ldr, int act, float alpha, int variant,
                     void* stream) {
   if (M == 0 || N == 0) return 0;
-  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb};
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
   if (check_shape(g, "rv_gemm_nt_bf16")) return 1;
   RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_bf16: ldc/ldr must be multiples of 4");
   EpiStore epi{(bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, alpha};
@@ -139,7 +143,7 @@ int rv_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, void* C, l
 int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                            int variant, void* stream) {
   if (M == 0 || N == 0) return 0;
-  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb};
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
   if (check_shape(g, "rv_gemm_nt_bf16_f32out")) return 1;
   RV_REQUIRE(ldc % 4 == 0, "rv_gemm_nt_bf16_f32out: ldc must be a multiple of 4");
   EpiStoreF32 epi{C, ldc};
@@ -149,7 +153,7 @@ int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, flo
 int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, int M, int V, int K,
                        float* pmax, float* psum, float* tgt_logit, int variant, void* stream) {
   if (M == 0) return 0;
-  GemmShape g{(const bf16_t*)h, (const bf16_t*)W, M, V, K, ldh, ldw};
+  GemmShape g{(const bf16_t*)h, (const bf16_t*)W, M, V, K, ldh, ldw, g_group};
   if (check_shape(g, "rv_lmhead_logp_fwd")) return 1;
   RV_REQUIRE(V % 64 == 0, "rv_lmhead_logp_fwd: vocabulary must be a multiple of 64");
   EpiLogpFwd epi{tgt, pmax, psum, tgt_logit};
@@ -159,7 +163,7 @@ int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const i
 int rv_lmhead_logp_bwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, const float* lse,
                        const float* coef, void* dlogits, long ldd, int M, int V, int K, int variant, void* stream) {
   if (M == 0) return 0;
-  GemmShape g{(const bf16_t*)h, (const bf16_t*)W, M, V, K, ldh, ldw};
+  GemmShape g{(const bf16_t*)h, (const bf16_t*)W, M, V, K, ldh, ldw, g_group};
   if (check_shape(g, "rv_lmhead_logp_bwd")) return 1;
   RV_REQUIRE(ldd % 4 == 0, "rv_lmhead_logp_bwd: ldd must be a multiple of 4");
   EpiLogpBwd epi{tgt, lse, coef, (bf16_t*)dlogits, ldd};
