@@ -544,6 +544,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
             const bf16x8_t df = *(const bf16x8_t*)(dOs + boff[ks] + qt * 8192);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], pacc, 0, 0, 0);
           }
+          // transposed fragments of the FIRST 16 queries are requested now: they do not depend on P / dS, so their
+          // LDS latency hides under the exp / mask VALU work below (one wave per SIMD: nothing else would hide it)
+          const uint32_t dos_addr = lds_addr_of(dOs), qs_addr = lds_addr_of(Qs);
+          bf16x8_t dotf0[ET], qtf0[ET], dotf1[ET], qtf1[ET];
+#pragma unroll
+          for (int e = 0; e < ET; ++e) {
+            dotf0[e] = tr8(dos_addr, qt * 32, e);
+            qtf0[e] = tr8(qs_addr, qt * 32, e);
+          }
           const int qsub = qs0 + qt * 32;                      // first query of this 32-row sub-tile
           const bool need_mask = (qsub + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qsub) ||
                                  (qsub + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
@@ -561,25 +570,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
             sacc[r] = p;
             pacc[r] = p * (pacc[r] - delta_s[ql]);
           }
+          const bf16x8_t pf0 = pack_frag(sacc, 0), dsf0 = pack_frag(pacc, 0);
+          const bf16x8_t pf1 = pack_frag(sacc, 8), dsf1 = pack_frag(pacc, 8);
+          // second 16 queries, in two batches of 8 asm reads (lgkmcnt is a 4-bit counter: at most 15 can be counted)
 #pragma unroll
-          for (int k2 = 0; k2 < 2; ++k2) {
-            const bf16x8_t pf = pack_frag(sacc, k2 * 8);
-            const bf16x8_t dsf = pack_frag(pacc, k2 * 8);
-            const int row0 = qt * 32 + k2 * 16;
-            bf16x8_t dotf[ET], qtf[ET];
+          for (int e = 0; e < ET; ++e) dotf1[e] = tr8(dos_addr, qt * 32 + 16, e);
+          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // everything older than the 8 reads just issued
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < ET; ++e) {
-              dotf[e] = tr8(lds_addr_of(dOs), row0, e);
-              qtf[e] = tr8(lds_addr_of(Qs), row0, e);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < ET; ++e) {
-              mfma_agpr(dv[e], dotf[e], pf);
-              mfma_agpr(dk[e], qtf[e], dsf);
-            }
+          for (int e = 0; e < ET; ++e) {
+            mfma_agpr(dv[e], dotf0[e], pf0);
+            mfma_agpr(dk[e], qtf0[e], dsf0);
           }
+#pragma unroll
+          for (int e = 0; e < ET; ++e) qtf1[e] = tr8(qs_addr, qt * 32 + 16, e);
+          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // dotf1 landed
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < ET; ++e) mfma_agpr(dv[e], dotf1[e], pf1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < ET; ++e) mfma_agpr(dk[e], qtf1[e], dsf1);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -12,7 +12,7 @@ import re
 from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "librlaifv_hip.so")
+_LIB_PATH = os.environ.get("RV_HIP_LIB") or os.path.join(_HERE, "librlaifv_hip.so")   # RV_HIP_LIB: A/B experiments only
 _HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "rlaifv_hip.h"))
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
