@@ -38,6 +38,23 @@ int rv_set_gemm_variant(int variant);
 int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* bias, const void* residual, long ldr, int act, float alpha, int variant,
                     void* stream);
+/* Fused LoRA GEMM (peft LoraLayer.forward as used by muffin/train/train_llava15_lora.py:304-318):
+ *   C[m][n] = sum_{k<K} A[m][k] B[n][k] + sum_{q<K2} A2[m][c0(n)+q] B2[n][q] (+ residual[m][n]),
+ *   c0(n) = group_cols ? (n / group_cols) * K2 : 0.
+ * The adapter contribution is two extra steps of the SAME K loop (operand tiles fetched from A2/B2), so
+ * the base output is never re-read.  Forward: A = x, B = W, A2 = t = (alpha/r) x A_lora^T [M, G*r], B2 = stacked
+ * lora_B [N, r], group_cols = rows of one fused projection (q|k|v, gate|up).  Input gradient: A = dy, B = W^T,
+ * A2 = dt [M, G*r], B2 = stacked lora_A^T [N, G*r], group_cols = 0.  K2 multiple of 64; group_cols multiple of 128. */
+int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                         long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
+                         const void* residual, long ldr, void* stream);
+
+/* Split-K form of rv_gemm_tn_bf16 for skinny outputs (LoRA weight gradients: I or J = r): `splits` chunks of the
+ * contraction rows are reduced by separate workgroups into fp32 slabs (workspace: splits*I*J floats, caller owned)
+ * which a second pass sums in a fixed order: C = bf16(alpha * sum).  Deterministic. */
+int rv_gemm_tn_bf16_splitk(const void* P, long ldp, const void* Q, long ldq, void* C, long ldc, int R, int I, int J,
+                           float alpha, int splits, float* workspace, void* stream);
+
 /* Weight-gradient contraction over the ROW index of both operands (no transposed copies in HBM):
  *   C[i][j] = alpha * sum_r P[r][i] * Q[r][j] + residual[i][j]      P [R][I], Q [R][J], C [I][J]; I, J % 8 == 0
  * e.g. dW = dY^T X (autograd of nn.Linear); operands are transposed on the fly by ds_read_b64_tr_b16. */
@@ -109,6 +126,10 @@ int rv_swiglu_bwd(const void* dact, long ldd, const void* gu, long ldgu, void* d
                   void* stream);
 int rv_gelu_fwd(const void* x, void* y, long n, void* stream);
 int rv_gelu_bwd(const void* dy, const void* x, void* dx, long n, void* stream);
+/* Dropout of the LoRA branch input (peft lora_dropout, muffin/train/train_llava15_lora.py:114,309): element e is kept
+ * iff hash(seed, e) >= p * 2^32 and scaled by 1/(1-p); the same (seed, n) regenerates the same mask in backward.
+ * y = dropped x (may alias x, may be NULL); acc (optional) += dropped x (gradient accumulation).  Contiguous, n % 8 == 0. */
+int rv_dropout(const void* x, void* y, void* acc, long n, float p, int seed, void* stream);
 
 /* ---- data movement */
 int rv_transpose(const void* in, long ld_in, void* out, long ldo, int R, int C, void* stream);

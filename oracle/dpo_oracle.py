@@ -348,8 +348,66 @@ def rotate_half(x):
     return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
 
 
+LORA_TARGETS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+                "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+
+
+def lora_linear(x: torch.Tensor, W: Dict[str, torch.Tensor], name: str, lora_scale: Optional[float],
+                masks: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """peft 0.10 `lora.Linear.forward` (third-party, absent offline; pinned by pyproject.toml:16-23, configured at
+    muffin/train/train_llava15_lora.py:304-318): result = base(x) + lora_B(lora_A(dropout(x))) * (lora_alpha / r).
+    Dropout is the identity unless ``masks[name]`` (an explicit keep/(1-p) multiplier of x's shape) is supplied -
+    that is how a test replays the exact mask a device kernel drew."""
+    y = F.linear(x, W[name + ".weight"])
+    a = W.get(name + ".lora_A.weight") if lora_scale is not None else None
+    if a is not None:
+        xa = x * masks[name].view_as(x) if masks is not None and name in masks else x
+        y = y + lora_scale * F.linear(F.linear(xa, a), W[name + ".lora_B.weight"])
+    return y
+
+
+def make_lora_weights(cfg: LlavaCfg, r: int, seed: int = 1, b_std: Optional[float] = 0.02,
+                      bf16_round: bool = True) -> Dict[str, torch.Tensor]:
+    """Adapter tensors under peft's module names.  peft initialises lora_A with kaiming_uniform(a=sqrt(5)) and lora_B
+    with zeros (`LoraLayer.reset_lora_parameters`); b_std=None reproduces that, a float draws B ~ N(0, b_std) so that
+    parity tests exercise a non-trivial adapter."""
+    g = torch.Generator().manual_seed(seed)
+    d, f = cfg.hidden, cfg.ffn
+    dims = {"self_attn.q_proj": (d, d), "self_attn.k_proj": (d, d), "self_attn.v_proj": (d, d), "self_attn.o_proj": (d, d),
+            "mlp.gate_proj": (f, d), "mlp.up_proj": (f, d), "mlp.down_proj": (d, f)}
+    out: Dict[str, torch.Tensor] = {}
+    for i in range(cfg.layers):
+        for t in LORA_TARGETS:
+            o, n_in = dims[t]
+            bound = 1.0 / math.sqrt(n_in)                       # kaiming_uniform_(a=sqrt(5)) on [r, n_in]
+            a = (torch.rand(r, n_in, generator=g) * 2 - 1) * bound
+            b = torch.zeros(o, r) if b_std is None else torch.randn(o, r, generator=g) * b_std
+            if bf16_round:
+                a, b = a.bfloat16().float(), b.bfloat16().float()
+            out[f"model.layers.{i}.{t}.lora_A.weight"] = a
+            out[f"model.layers.{i}.{t}.lora_B.weight"] = b
+    return out
+
+
+def merge_lora(W: Dict[str, torch.Tensor], lora_scale: float) -> Dict[str, torch.Tensor]:
+    """peft merge_and_unload (llava/model/builder.py:81-85): W' = W + scale * B @ A; adapter keys dropped."""
+    out = {k: v for k, v in W.items() if ".lora_" not in k}
+    for k, a in W.items():
+        if k.endswith(".lora_A.weight"):
+            base = k[:-len(".lora_A.weight")]
+            out[base + ".weight"] = W[base + ".weight"] + lora_scale * (W[base + ".lora_B.weight"] @ a)
+    return out
+
+
+def lora_trainable_names(W: Dict[str, torch.Tensor]) -> List[str]:
+    """LoRA run: adapters + the projector, which initialize_vision_modules re-enables after peft froze it
+    (llava/model/llava_arch.py:90-93 'In case it is frozen by LoRA'); saved as non_lora_trainables.bin."""
+    return [k for k in W if ".lora_" in k or "mm_projector" in k]
+
+
 def llama_hidden(embeds: torch.Tensor, W: Dict[str, torch.Tensor], cfg: LlavaCfg,
-                 n_layers: Optional[int] = None) -> torch.Tensor:
+                 n_layers: Optional[int] = None, lora_scale: Optional[float] = None,
+                 lora_masks: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """Decoder stack + final norm.  positions = arange(L) (position_ids dropped at
     llava_llama.py:94), pure causal mask, no pad mask (trainers.py:199)."""
     S, L, d = embeds.shape
@@ -360,24 +418,24 @@ def llama_hidden(embeds: torch.Tensor, W: Dict[str, torch.Tensor], cfg: LlavaCfg
     for i in range(cfg.layers if n_layers is None else n_layers):
         p = f"model.layers.{i}."
         h = rms_norm(x, W[p + "input_layernorm.weight"], cfg.rms_eps)
-        q = F.linear(h, W[p + "self_attn.q_proj.weight"]).view(S, L, H, hd).transpose(1, 2)
-        k = F.linear(h, W[p + "self_attn.k_proj.weight"]).view(S, L, H, hd).transpose(1, 2)
-        v = F.linear(h, W[p + "self_attn.v_proj.weight"]).view(S, L, H, hd).transpose(1, 2)
+        q = lora_linear(h, W, p + "self_attn.q_proj", lora_scale, lora_masks).view(S, L, H, hd).transpose(1, 2)
+        k = lora_linear(h, W, p + "self_attn.k_proj", lora_scale, lora_masks).view(S, L, H, hd).transpose(1, 2)
+        v = lora_linear(h, W, p + "self_attn.v_proj", lora_scale, lora_masks).view(S, L, H, hd).transpose(1, 2)
         q = q * cos + rotate_half(q) * sin
         k = k * cos + rotate_half(k) * sin
         att = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + causal
         att = torch.softmax(att.float(), dim=-1).to(q.dtype)
         a = (att @ v).transpose(1, 2).reshape(S, L, d)
-        x = x + F.linear(a, W[p + "self_attn.o_proj.weight"])
+        x = x + lora_linear(a, W, p + "self_attn.o_proj", lora_scale, lora_masks)
         h = rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-        g = F.linear(h, W[p + "mlp.gate_proj.weight"])
-        u = F.linear(h, W[p + "mlp.up_proj.weight"])
-        x = x + F.linear(F.silu(g) * u, W[p + "mlp.down_proj.weight"])
+        g = lora_linear(h, W, p + "mlp.gate_proj", lora_scale, lora_masks)
+        u = lora_linear(h, W, p + "mlp.up_proj", lora_scale, lora_masks)
+        x = x + lora_linear(F.silu(g) * u, W, p + "mlp.down_proj", lora_scale, lora_masks)
     return rms_norm(x, W["model.norm.weight"], cfg.rms_eps)
 
 
-def llama_logits(embeds, W, cfg):
-    return F.linear(llama_hidden(embeds, W, cfg), W["lm_head.weight"]).float()
+def llama_logits(embeds, W, cfg, lora_scale: Optional[float] = None, lora_masks=None):
+    return F.linear(llama_hidden(embeds, W, cfg, lora_scale=lora_scale, lora_masks=lora_masks), W["lm_head.weight"]).float()
 
 
 # --------------------------------------------------------------------------------------------
@@ -417,7 +475,8 @@ def compute_weighted_logp(per_token_logp, labels, token_weight, use_average):
 
 def dpo_step_forward(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg: LlavaCfg,
                      dpo_use_average: bool = False, sft_weight: Optional[float] = None,
-                     dpo_weight: Optional[float] = None) -> Dict[str, torch.Tensor]:
+                     dpo_weight: Optional[float] = None, lora_scale: Optional[float] = None,
+                     lora_masks: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """get_beta_and_logps (trainers.py:161-275, is_llava15 branch) + compute_loss
     (trainers.py:281-311).  Images are encoded for [images, images] like the reference
     (trainers.py:190); rows i and B+i of the features are identical."""
@@ -427,7 +486,7 @@ def dpo_step_forward(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg: 
     embeds, new_labels = prepare_inputs_labels_for_multimodal(
         batch["concatenated_input_ids"], batch["concatenated_labels"], feats,
         W["model.embed_tokens.weight"], cfg.model_max_length)
-    logits = llama_logits(embeds, W, cfg)
+    logits = llama_logits(embeds, W, cfg, lora_scale=lora_scale, lora_masks=lora_masks)
     per_token, log_prob, avg = get_batch_logps(logits, new_labels, return_all=True)
     cat = avg if dpo_use_average else log_prob
     B = batch["win_input_ids"].shape[0]
@@ -515,7 +574,7 @@ def dpo_train_step(batch, W: Dict[str, torch.Tensor], cfg: LlavaCfg, opt_state, 
                    **kw):
     """One full optimisation step on CPU: forward, autograd backward, clip, AdamW.  This is the
     <=30-line shim loop of SURVEY.md section 8c around the reference functions."""
-    names = trainable_names(cfg)
+    names = lora_trainable_names(W) if kw.get("lora_scale") is not None else trainable_names(cfg)
     for k in names:
         W[k].requires_grad_(True)
         W[k].grad = None

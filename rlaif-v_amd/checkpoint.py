@@ -103,9 +103,61 @@ def save_pretrained(model, output_dir: str, max_shard_bytes: int = 5 << 30):
     return save_state_dict_sharded(sd, output_dir, model.cfg, max_shard_bytes)
 
 
-def from_pretrained(ckpt_dir: str, device="cuda:0", with_optimizer: bool = True, **cfg_overrides):
+def save_lora_adapter(model, output_dir: str, base_model_name_or_path: str = ""):
+    """What the LoRA entry point leaves in a checkpoint directory (safe_save_model_for_hf_trainer of
+    muffin/train/train_llava15_lora.py:184-197 + script/train/llava15_train_lora.sh:51-70): the peft adapter
+    (adapter_model.safetensors + adapter_config.json), non_lora_trainables.bin (the projector) and config.json - the
+    layout llava/model/builder.py:52-85 loads and merges."""
+    from safetensors.torch import save_file
+    if model.lora is None:
+        raise ValueError("save_lora_adapter: the model has no adapters")
+    os.makedirs(output_dir, exist_ok=True)
+    sd = {k: v.contiguous() for k, v in model.lora_state_dict().items()}
+    save_file(sd, os.path.join(output_dir, "adapter_model.safetensors"), metadata={"format": "pt"})
+    lc = model.lora
+    with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
+        json.dump({"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": lc.r, "lora_alpha": lc.lora_alpha,
+                   "lora_dropout": lc.lora_dropout, "bias": lc.bias, "target_modules": sorted(lc.target_modules),
+                   "base_model_name_or_path": base_model_name_or_path, "inference_mode": True,
+                   "fan_in_fan_out": False, "init_lora_weights": True, "modules_to_save": None}, f, indent=2)
+    torch.save(model.non_lora_trainables(), os.path.join(output_dir, "non_lora_trainables.bin"))
+    with open(os.path.join(output_dir, "config.json"), "w") as f:
+        json.dump(hf_config_dict(model.cfg), f, indent=2)
+
+
+def load_lora_adapter(model, adapter_dir: str, merge: bool = False):
+    """llava/model/builder.py:52-85: non_lora_trainables.bin into the base model, then the adapter; ``merge`` applies
+    peft's merge_and_unload (W += (alpha/r) B A) on the device."""
+    from safetensors.torch import load_file
+    nl = os.path.join(adapter_dir, "non_lora_trainables.bin")
+    if os.path.exists(nl):
+        extra = torch.load(nl, map_location="cpu", weights_only=True)
+        for k, v in extra.items():
+            k = k[len("base_model.model."):] if k.startswith("base_model.model.") else k       # builder.py:76-78
+            if k in model.store.offsets:
+                model.store.p(k).copy_(v.to(torch.bfloat16))
+    f_st = os.path.join(adapter_dir, "adapter_model.safetensors")
+    sd = load_file(f_st) if os.path.exists(f_st) else torch.load(os.path.join(adapter_dir, "adapter_model.bin"),
+                                                                map_location="cpu", weights_only=True)
+    model.load_lora_state_dict(sd, strict=True)
+    model.store.refresh_transposes()
+    if merge:
+        model.merge_lora()
+    return model
+
+
+def lora_config_from_dir(adapter_dir: str):
+    from .model import LoraConfig
+    with open(os.path.join(adapter_dir, "adapter_config.json")) as f:
+        d = json.load(f)
+    return LoraConfig(r=d["r"], lora_alpha=d["lora_alpha"], lora_dropout=d.get("lora_dropout", 0.0),
+                      bias=d.get("bias", "none"), target_modules=tuple(d["target_modules"]))
+
+
+def from_pretrained(ckpt_dir: str, device="cuda:0", with_optimizer: bool = True, lora=None, **cfg_overrides):
     """Build a LlavaDPOModel from an HF LLaVA-1.5 checkpoint directory (vision tower weights may live in the same
-    directory - as our own save_pretrained writes them - or in ``vision_tower_dir``)."""
+    directory - as our own save_pretrained writes them - or in ``vision_tower_dir``).  ``lora``: a LoraConfig wraps
+    the loaded base model with fresh adapters (get_peft_model, train_llava15_lora.py:304-318)."""
     from .model import LlavaDPOModel
     vt_dir = cfg_overrides.pop("vision_tower_dir", None)
     with open(os.path.join(ckpt_dir, "config.json")) as f:
@@ -114,6 +166,6 @@ def from_pretrained(ckpt_dir: str, device="cuda:0", with_optimizer: bool = True,
     if vt_dir is not None:
         vt = load_state_dict_dir(vt_dir)
         sd.update({("model.vision_tower.vision_tower." + k if not k.startswith("model.") else k): v for k, v in vt.items()})
-    model = LlavaDPOModel(cfg, device=device, with_optimizer=with_optimizer)
+    model = LlavaDPOModel(cfg, device=device, with_optimizer=with_optimizer, lora=lora)
     model.load_state_dict(sd)
     return model

@@ -45,19 +45,31 @@ static int launch_gemm256x64(const GemmShape& g, const Epi& epi, hipStream_t st)
   return 0;
 }
 
-template <class Epi>
-static int launch_gemm_tn(const bf16_t* P, long ldp, const bf16_t* Q, long ldq, int R, int I, int J, const Epi& epi,
-                          hipStream_t st) {
+static int g_tn_dist = 3;   // prefetch distance of the TN kernel (RV_GEMM_TN_DIST = 3 | 4; measured equal, 3 = 128 KiB LDS)
+
+template <class Epi, int DIST>
+static int launch_gemm_tn_d(const bf16_t* P, long ldp, const bf16_t* Q, long ldq, int R, int I, int J, const Epi& epi,
+                            hipStream_t st, int splits, int r_chunk, long split_stride) {
+  constexpr int LDS = (DIST + 1) * G2_STAGE_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_tn_256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_tn_256_kernel<Epi, DIST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   const int tiles_i = (I + 255) / 256, tiles_j = (J + 255) / 256;
-  hipLaunchKernelGGL((gemm_tn_256_kernel<Epi>), dim3(tiles_i * tiles_j), dim3(G2_THREADS), G2_LDS_BYTES, st, P, ldp, Q,
-                     ldq, R, I, J, epi);
+  hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST>), dim3(tiles_i * tiles_j, splits), dim3(G2_THREADS), LDS, st, P,
+                     ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride);
   RV_CHECK_LAUNCH();
   return 0;
+}
+
+template <class Epi>
+static int launch_gemm_tn(const bf16_t* P, long ldp, const bf16_t* Q, long ldq, int R, int I, int J, const Epi& epi,
+                          hipStream_t st, int splits = 1, int r_chunk = 0, long split_stride = 0) {
+  static bool env_done = false;
+  if (!env_done) { const char* e = getenv("RV_GEMM_TN_DIST"); if (e && atoi(e) == 4) g_tn_dist = 4; env_done = true; }
+  if (g_tn_dist == 3) return launch_gemm_tn_d<Epi, 3>(P, ldp, Q, ldq, R, I, J, epi, st, splits, r_chunk, split_stride);
+  return launch_gemm_tn_d<Epi, 4>(P, ldp, Q, ldq, R, I, J, epi, st, splits, r_chunk, split_stride);
 }
 
 template <int STAGE, class Epi>
@@ -73,6 +85,57 @@ static int launch_gemm(const GemmShape& g, const Epi& epi, hipStream_t st) {
                      epi);
   RV_CHECK_LAUNCH();
   return 0;
+}
+
+// GEMMs with a second contraction segment (GemmShape::A2/B2/K2): the 256x256 ping-pong kernel when the problem
+// fills the chip and the column groups are tile aligned, else the 128x128 kernel.
+template <class Epi>
+static int dispatch_ext(const GemmShape& g, const Epi& epi, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const long t256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
+  if (t256 >= 192 && g.group_cols % G2_BN == 0) {
+    constexpr int LDS = 4 * G2_STAGE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)gemm_nt_256_kernel<Epi, true, 0, 3, 0, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_256_kernel<Epi, true, 0, 3, 0, true>),
+                       dim3(((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN)), dim3(G2_THREADS), LDS, st, g, epi);
+    RV_CHECK_LAUNCH();
+    return 0;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<1, Epi, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        GEMM_LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<1, Epi, true>),
+                     dim3(((g.M + GEMM_BM - 1) / GEMM_BM) * ((g.N + GEMM_BN - 1) / GEMM_BN)), dim3(GEMM_THREADS),
+                     GEMM_LDS_BYTES, st, g, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[i][j] = bf16(alpha * sum_s ws[s][i][j])   (deterministic second pass of the split-K TN GEMM)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int I, int J, float alpha,
+                                     bf16_t* __restrict__ out, long ldc) {
+  const long n4 = (long)I * J / 4;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+    const long e = q * 4;
+    float4 a = *(const float4*)(ws + e);
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = *(const float4*)(ws + (long)s * I * J + e);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const long i = e / J, j = e % J;
+    uint2 o;
+    o.x = pack2bf(a.x * alpha, a.y * alpha);
+    o.y = pack2bf(a.z * alpha, a.w * alpha);
+    *(uint2*)(out + i * ldc + j) = o;
+  }
 }
 
 template <class Epi>
@@ -138,6 +201,46 @@ int rv_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, void* C, l
   RV_REQUIRE((((uintptr_t)P | (uintptr_t)Q) & 15) == 0, "rv_gemm_tn_bf16: P/Q must be 16-byte aligned");
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
   return launch_gemm_tn((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, R, I, J, epi, (hipStream_t)stream);
+}
+
+int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                         long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
+                         const void* residual, long ldr, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group,
+              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols};
+  if (check_shape(g, "rv_gemm_nt_lora_bf16")) return 1;
+  RV_REQUIRE(K2 > 0 && K2 % GEMM_BK == 0, "rv_gemm_nt_lora_bf16: K2 must be a positive multiple of 64");
+  RV_REQUIRE(lda2 % 8 == 0 && ldb2 % 8 == 0 && ((((uintptr_t)A2 | (uintptr_t)B2) & 15) == 0),
+             "rv_gemm_nt_lora_bf16: A2/B2 must be 16-byte aligned with leading dimensions multiples of 8");
+  RV_REQUIRE(group_cols == 0 || (group_cols % GEMM_BN == 0 && N % group_cols == 0),
+             "rv_gemm_nt_lora_bf16: group_cols must be 0 or a multiple of 128 that divides N");
+  RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_lora_bf16: ldc/ldr must be multiples of 4");
+  EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, 1.0f};
+  return dispatch_ext(g, epi, stream);
+}
+
+int rv_gemm_tn_bf16_splitk(const void* P, long ldp, const void* Q, long ldq, void* C, long ldc, int R, int I, int J,
+                           float alpha, int splits, float* workspace, void* stream) {
+  if (I == 0 || J == 0) return 0;
+  RV_REQUIRE(R > 0 && splits >= 1 && splits <= 1024, "rv_gemm_tn_bf16_splitk: R > 0, 1 <= splits <= 1024");
+  RV_REQUIRE(I % 8 == 0 && J % 8 == 0, "rv_gemm_tn_bf16_splitk: I and J must be multiples of 8");
+  RV_REQUIRE(ldp % 8 == 0 && ldq % 8 == 0 && ldc % 4 == 0, "rv_gemm_tn_bf16_splitk: bad leading dimension");
+  RV_REQUIRE((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)workspace) & 15) == 0,
+             "rv_gemm_tn_bf16_splitk: P/Q/workspace must be 16-byte aligned");
+  RV_REQUIRE(workspace != nullptr, "rv_gemm_tn_bf16_splitk: workspace of splits*I*J floats required");
+  int r_chunk = ((R + splits - 1) / splits + 31) / 32 * 32;
+  splits = (R + r_chunk - 1) / r_chunk;            // no empty chunk
+  EpiStoreF32 epi{workspace, (long)J};
+  if (launch_gemm_tn((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, R, I, J, epi, (hipStream_t)stream, splits, r_chunk,
+                     (long)I * J))
+    return 1;
+  const long n4 = (long)I * J / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, splits, I, J, alpha,
+                     (bf16_t*)C, ldc);
+  RV_CHECK_LAUNCH();
+  return 0;
 }
 
 int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,

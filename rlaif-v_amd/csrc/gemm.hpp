@@ -24,14 +24,22 @@ struct GemmShape {
   int M, N, K;
   long lda, ldb;
   int group;     // row tiles per scheduling group (tile order inside an XCD chunk); 0 = kernel default
+  // Optional second contraction segment (kernels instantiated with EXT = true; the fused LoRA GEMM):
+  //   D[m][n] += sum_{q < K2} A2[m][c0(n) + q] * B2[n][q],   c0(n) = group_cols ? (n / group_cols) * K2 : 0
+  // i.e. the K loop simply runs K2 / BK further steps whose tiles come from (A2, B2).  group_cols must be a
+  // multiple of the N tile so that c0 is uniform per workgroup.
+  const bf16_t* A2; const bf16_t* B2;
+  long lda2, ldb2;
+  int K2, group_cols;
 };
 
 __device__ __forceinline__ uint32_t gemm_lds_off(int row, int kc) {
   return (uint32_t)(row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int STAGE, class Epi>
+template <int STAGE, class Epi, bool EXT = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, Epi epi) {
+  static_assert(!EXT || STAGE == 1, "the second K segment is implemented for the LDS-DMA staging only");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -81,12 +89,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, E
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = g.K / GEMM_BK;
+  const int nt1 = g.K / GEMM_BK;
+  const int nt = nt1 + (EXT ? g.K2 / GEMM_BK : 0);
+  const int a2_col0 = (EXT && g.group_cols > 0) ? (n0 / g.group_cols) * g.K2 : 0;
   u32x4_t ra_[4], rb_[4];
 
   auto issue = [&](int t, int buf) {
     const long koff = (long)t * GEMM_BK;
-    if (STAGE == 1) {
+    if (EXT && t >= nt1) {     // wave-uniform: tiles of the second segment, addresses rebuilt on the fly
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const long ko = (long)(t - nt1) * GEMM_BK + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+        const bf16_t* sa = g.A2 + (long)min(m0 + row, g.M - 1) * g.lda2 + a2_col0 + ko;
+        const bf16_t* sb = g.B2 + (long)min(n0 + row, g.N - 1) * g.ldb2 + ko;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                         (__attribute__((address_space(3))) void*)(As(buf) + st_off[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                         (__attribute__((address_space(3))) void*)(Bs(buf) + st_off[i]), 16, 0, 0);
+      }
+    } else if (STAGE == 1) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
@@ -184,7 +206,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, E
 // SPLIT = 1 (with DMA_IN_MSEG, DIST 3): pieces 0,1 of tile p+3 are issued at the end of L-seg(p), pieces 2,3 inside
 // M-seg(p) - a VMEM issue stalls the in-order wave for ~60 cycles and starves the matrix pipe, so half of them move
 // to the segment that is not using it.
-template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3, int SPLIT = 0>
+template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3, int SPLIT = 0, bool EXT = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g, Epi epi) {
   constexpr int NST = DMA_IN_MSEG ? DIST + 1 : 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -214,12 +236,23 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
     b_src[i] = g.B + (long)min(n0 + row, g.N - 1) * g.ldb + kc * 8;
   }
   const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
+  const int nt1 = g.K / G2_BK;
+  const int nt = nt1 + (EXT ? g.K2 / G2_BK : 0);
+  const int a2_col0 = (EXT && g.group_cols > 0) ? (n0 / g.group_cols) * g.K2 : 0;
 
   auto issue_piece = [&](int t, int j) {   // j: 0 = A piece 0, 1 = B piece 0, 2 = A piece 1, 3 = B piece 1
     uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
     const long koff = (ABLATE == 3) ? 0 : (long)t * G2_BK;
     const int i = j >> 1;
-    if ((j & 1) == 0)
+    if (EXT && t >= nt1) {     // wave-uniform: second K segment, addresses rebuilt on the fly (2 of ~130 steps)
+      const int row = (wave * 2 + i) * 16 + (lane >> 2);
+      const long ko = (long)(t - nt1) * G2_BK + (((lane & 3) ^ ((row >> 2) & 3)) << 3);
+      const bf16_t* src = (j & 1) == 0 ? g.A2 + (long)min(m0 + row, g.M - 1) * g.lda2 + a2_col0 + ko
+                                       : g.B2 + (long)min(n0 + row, g.N - 1) * g.ldb2 + ko;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + ((j & 1) ? 16384 : 0) + piece0 + i * 1024),
+                                       16, 0, 0);
+    } else if ((j & 1) == 0)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
                                        (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
     else
@@ -249,7 +282,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = g.K / G2_BK;
   issue(0);
   if (nt > 1) issue(1);
   if (DMA_IN_MSEG && nt > 2) issue(2);
@@ -286,8 +318,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     } else {
-      // tiles newer than p+1 that are already in flight (each = 4 DMA pieces of this wave)
-      const int newer = (ABLATE == 1) ? 0 : min((DMA_IN_MSEG ? DIST : 2) - 1, nt - 2 - p);
+      // tiles newer than p+1 that are already in flight HERE (each = 4 DMA pieces of this wave): with DMA_IN_MSEG
+      // tile p+DIST is only issued in the M segment that follows, so they are p+2 .. p+DIST-1; otherwise p+2.
+      // (An earlier revision counted DIST-1 and thereby waited for tile p only - results then depended on the DMA
+      // beating the consumer by three iterations, which a memory-bound launch mix can break.)
+      const int newer = (ABLATE == 1) ? 0 : min(DMA_IN_MSEG ? DIST - 2 : 1, nt - 2 - p);
       if (newer >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -466,12 +501,20 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256x64_kernel(GemmShape
 // =============================================================================================
 __device__ bf16_t g_zero_row[256];   // 512 zero bytes: DMA source for contraction rows beyond R
 
-template <class Epi>
+template <class Epi, int DIST = 3>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t* __restrict__ P, long ldp,
                                                                     const bf16_t* __restrict__ Q, long ldq, int R,
-                                                                    int I, int J, Epi epi) {
+                                                                    int I, int J, Epi epi, int r_chunk,
+                                                                    long split_stride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr int NST = 4, DIST = 3;
+  constexpr int NST = DIST + 1;
+  if (gridDim.y > 1) {   // split-K: workgroup row y reduces contraction rows [y*r_chunk, (y+1)*r_chunk) into its own slab
+    const long r0 = (long)blockIdx.y * r_chunk;
+    P += r0 * ldp;
+    Q += r0 * ldq;
+    R = (int)min((long)r_chunk, (long)R - r0);
+    epi.C += (long)blockIdx.y * split_stride;
+  }
   const bf16_t* zero_row = g_zero_row;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -541,9 +584,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   issue(0);
   if (nt > 1) issue(1);
   if (nt > 2) issue(2);
+  if (DIST > 3 && nt > 3) issue(3);
   {
     const int issued = min(nt, DIST);
-    if (issued == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (issued >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (issued == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (issued == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -567,7 +612,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
       for (int ks = 0; ks < 2; ++ks) pf[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
     }
     {
-      const int newer = min(DIST - 1, nt - 2 - p);
+      const int newer = min(DIST - 2, nt - 2 - p);   // tiles p+2 .. p+DIST-1 (p+DIST is issued after this wait)
       if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -76,6 +76,37 @@ class LlavaConfig:
         return ops.round_up(3 * self.patch * self.patch, 64)
 
 
+@dataclass
+class LoraConfig:
+    """peft.LoraConfig as built by the reference's LoRA entry point (muffin/train/train_llava15_lora.py:304-318,
+    flag defaults :111-116): every nn.Linear of the language model except lm_head (find_all_linear_names, :120-134)."""
+    r: int = 64
+    lora_alpha: int = 16
+    lora_dropout: float = 0.05
+    bias: str = "none"
+    target_modules: Tuple[str, ...] = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+    def __post_init__(self):
+        if set(self.target_modules) != {"q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"}:
+            raise NotImplementedError("LoRA is applied to all seven decoder projections (find_all_linear_names)")
+        if self.bias != "none":
+            raise NotImplementedError("lora_bias other than 'none' (the reference's default) is not supported")
+
+    @property
+    def scaling(self) -> float:
+        return self.lora_alpha / self.r
+
+    @property
+    def r_pad(self) -> int:
+        """Stored rank: r rounded up to the GEMM K step (64); the padding rows/columns are zero and stay zero."""
+        return ops.round_up(self.r, 64)
+
+
+# fused projection -> (store suffix, peft module names in stacking order)
+LORA_GROUPS = {"qkv": ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), "o": ("self_attn.o_proj",),
+               "gu": ("mlp.gate_proj", "mlp.up_proj"), "down": ("mlp.down_proj",)}
+
+
 def _is_decay(name: str) -> bool:
     return not (name.endswith("bias") or "norm" in name)
 
@@ -83,20 +114,38 @@ def _is_decay(name: str) -> bool:
 class ParamStore:
     """Flat parameter / gradient / optimizer-state buffers with named views."""
 
-    def __init__(self, cfg: LlavaConfig, device, with_optimizer: bool = True):
+    def __init__(self, cfg: LlavaConfig, device, with_optimizer: bool = True, lora: Optional[LoraConfig] = None):
         d, f, V, cd = cfg.hidden, cfg.ffn, cfg.vocab, cfg.clip_hidden
-        # (key, shape, needs transposed copy)  in backward-completion order; fused keys map to HF names
-        decay: List[Tuple[str, Tuple[int, ...], bool]] = [("lm_head.weight", (V, d), True)]
+        Entry = Tuple[str, Tuple[int, ...], bool]        # (key, shape, needs transposed copy); fused keys map to HF names
+        self.lora = lora
+        proj_w: List[Entry] = [("model.mm_projector.2.weight", (d, d), True), ("model.mm_projector.0.weight", (d, cd), False)]
+        proj_b: List[Entry] = [("model.mm_projector.2.bias", (d,), False), ("model.mm_projector.0.bias", (d,), False)]
+        base_w: List[Entry] = [("lm_head.weight", (V, d), True)]
         for i in reversed(range(cfg.layers)):
-            decay += [(f"layers.{i}.wdown", (d, f), True), (f"layers.{i}.wgu", (2 * f, d), True),
-                      (f"layers.{i}.wo", (d, d), True), (f"layers.{i}.wqkv", (3 * d, d), True)]
-        decay += [("model.embed_tokens.weight", (V, d), False),
-                  ("model.mm_projector.2.weight", (d, d), True), ("model.mm_projector.0.weight", (d, cd), False)]
-        nodecay: List[Tuple[str, Tuple[int, ...], bool]] = [("model.norm.weight", (d,), False)]
+            base_w += [(f"layers.{i}.wdown", (d, f), True), (f"layers.{i}.wgu", (2 * f, d), True),
+                       (f"layers.{i}.wo", (d, d), True), (f"layers.{i}.wqkv", (3 * d, d), True)]
+        base_w += [("model.embed_tokens.weight", (V, d), False)]
+        norms: List[Entry] = [("model.norm.weight", (d,), False)]
         for i in reversed(range(cfg.layers)):
-            nodecay += [(f"layers.{i}.ln2", (d,), False), (f"layers.{i}.ln1", (d,), False)]
-        nodecay += [("model.mm_projector.2.bias", (d,), False), ("model.mm_projector.0.bias", (d,), False)]
-        self.entries = decay + nodecay
+            norms += [(f"layers.{i}.ln2", (d,), False), (f"layers.{i}.ln1", (d,), False)]
+        if lora is None:
+            # full fine-tune: everything trainable, laid out in backward-completion order
+            frozen: List[Entry] = []
+            decay = base_w + proj_w
+            nodecay = norms + proj_b
+        else:
+            # LoRA: base language model frozen; adapters (backward-completion order) + projector trainable
+            rp = lora.r_pad
+            frozen = base_w + norms
+            decay = []
+            for i in reversed(range(cfg.layers)):
+                decay += [(f"layers.{i}.lora_down.B", (d, rp), True), (f"layers.{i}.lora_down.A", (rp, f), True),
+                          (f"layers.{i}.lora_gu.B", (2 * f, rp), True), (f"layers.{i}.lora_gu.A", (2 * rp, d), True),
+                          (f"layers.{i}.lora_o.B", (d, rp), True), (f"layers.{i}.lora_o.A", (rp, d), True),
+                          (f"layers.{i}.lora_qkv.B", (3 * d, rp), True), (f"layers.{i}.lora_qkv.A", (3 * rp, d), True)]
+            decay += proj_w
+            nodecay = proj_b
+        self.entries = frozen + decay + nodecay
         self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         off = 0
         for k, shp, _ in self.entries:
@@ -104,16 +153,19 @@ class ParamStore:
             assert n % 8 == 0, (k, shp)
             self.offsets[k] = (off, shp)
             off += n
-            if k == decay[-1][0]:
-                self.n_decay = off
         self.n_total = off
+        self.t0 = sum(math.prod(shp) for _, shp, _ in frozen)            # first trainable element of flat_p
+        self.n_decay = sum(math.prod(shp) for _, shp, _ in decay)        # trainable elements with weight decay
+        self.n_train = self.n_total - self.t0
+        self.trainable = {k for k, _, _ in decay + nodecay}
         self.device = device
         self.flat_p = torch.zeros(self.n_total, dtype=BF16, device=device)
-        self.flat_g = torch.zeros(self.n_total, dtype=BF16, device=device)
+        self.train_p = self.flat_p[self.t0:]                             # the slice the optimizer owns
+        self.flat_g = torch.zeros(self.n_train, dtype=BF16, device=device)
         if with_optimizer:
-            self.flat_master = torch.zeros(self.n_total, dtype=torch.float32, device=device)
-            self.flat_m = torch.zeros(self.n_total, dtype=torch.float32, device=device)
-            self.flat_v = torch.zeros(self.n_total, dtype=torch.float32, device=device)
+            self.flat_master = torch.zeros(self.n_train, dtype=torch.float32, device=device)
+            self.flat_m = torch.zeros(self.n_train, dtype=torch.float32, device=device)
+            self.flat_v = torch.zeros(self.n_train, dtype=torch.float32, device=device)
         else:
             self.flat_master = self.flat_m = self.flat_v = None
         # transposed copies: W [out, in] -> W^T [in, out]   (out is a multiple of 64 for every entry)
@@ -125,12 +177,18 @@ class ParamStore:
                 self.t_offsets[k] = (toff, (shp[1], shp[0]))
                 toff += shp[0] * shp[1]
         self.flat_pT = torch.zeros(toff, dtype=BF16, device=device)
-        # gradient buckets for data parallelism: contiguous slices in the order backward finishes them
-        self.buckets: Dict[str, Tuple[int, int]] = {"lm_head": self.grad_range("lm_head.weight", "lm_head.weight")}
-        for i in reversed(range(cfg.layers)):
-            self.buckets[f"layer{i}"] = self.grad_range(f"layers.{i}.wdown", f"layers.{i}.wqkv")
-        self.buckets["embed_proj"] = self.grad_range("model.embed_tokens.weight", "model.mm_projector.0.weight")
-        self.buckets["nodecay"] = (self.n_decay, self.n_total)
+        # gradient buckets for data parallelism: contiguous slices of flat_g in the order backward finishes them
+        self.buckets: Dict[str, Tuple[int, int]] = {}
+        if lora is None:
+            self.buckets["lm_head"] = self.grad_range("lm_head.weight", "lm_head.weight")
+            for i in reversed(range(cfg.layers)):
+                self.buckets[f"layer{i}"] = self.grad_range(f"layers.{i}.wdown", f"layers.{i}.wqkv")
+            self.buckets["embed_proj"] = self.grad_range("model.embed_tokens.weight", "model.mm_projector.0.weight")
+        else:
+            for i in reversed(range(cfg.layers)):
+                self.buckets[f"layer{i}"] = self.grad_range(f"layers.{i}.lora_down.B", f"layers.{i}.lora_qkv.A")
+            self.buckets["embed_proj"] = self.grad_range("model.mm_projector.2.weight", "model.mm_projector.0.weight")
+        self.buckets["nodecay"] = (self.n_decay, self.n_train)
 
     def bucket_schedule(self) -> List[Tuple[str, int, int]]:
         """(name, start, end) in the order LlavaDPOModel.backward fires grad_ready_hook; covers flat_g exactly."""
@@ -142,6 +200,9 @@ class ParamStore:
 
     def g(self, key: str) -> torch.Tensor:
         off, shp = self.offsets[key]
+        if key not in self.trainable:
+            raise KeyError(f"{key} is frozen: it has no gradient slot")
+        off -= self.t0
         return self.flat_g[off:off + math.prod(shp)].view(*shp)
 
     def pT(self, key: str) -> torch.Tensor:
@@ -149,17 +210,20 @@ class ParamStore:
         return self.flat_pT[off:off + shp[0] * shp[1]].view(*shp)
 
     def grad_range(self, first_key: str, last_key: str) -> Tuple[int, int]:
+        """[start, end) inside flat_g (offsets relative to the first trainable element)."""
         a = self.offsets[first_key][0]
         off, shp = self.offsets[last_key]
-        return a, off + math.prod(shp)
+        return a - self.t0, off + math.prod(shp) - self.t0
 
-    def refresh_transposes(self):
+    def refresh_transposes(self, trainable_only: bool = False):
+        """W^T copies; after an optimizer step only the trainable ones moved (LoRA: 160 MB instead of 13 GB)."""
         for k in self.t_offsets:
-            ops.transpose(self.p(k), out=self.pT(k))
+            if not trainable_only or k in self.trainable:
+                ops.transpose(self.p(k), out=self.pT(k))
 
     def sync_master_from_params(self):
         if self.flat_master is not None:
-            self.flat_master.copy_(self.flat_p)      # bf16 -> fp32 (device copy, plumbing)
+            self.flat_master.copy_(self.train_p)     # bf16 -> fp32 (device copy, plumbing)
 
     # ---- HF state-dict mapping ------------------------------------------------------------
     def hf_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int]]:
@@ -183,6 +247,23 @@ class ParamStore:
         return m
 
 
+    def lora_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int, int]]:
+        """peft adapter name (without the 'base_model.model.' prefix) -> (store key, first row, n rows, n cols)."""
+        m: Dict[str, Tuple[str, int, int, int]] = {}
+        if self.lora is None:
+            return m
+        r, rp, d, f = self.lora.r, self.lora.r_pad, cfg.hidden, cfg.ffn
+        out_rows = {"qkv": d, "o": d, "gu": f, "down": d}
+        in_cols = {"qkv": d, "o": d, "gu": d, "down": f}
+        for i in range(cfg.layers):
+            for grp, mods in LORA_GROUPS.items():
+                for gi, mod in enumerate(mods):
+                    p = f"model.layers.{i}.{mod}."
+                    m[p + "lora_A.weight"] = (f"layers.{i}.lora_{grp}.A", gi * rp, r, in_cols[grp])
+                    m[p + "lora_B.weight"] = (f"layers.{i}.lora_{grp}.B", gi * out_rows[grp], out_rows[grp], r)
+        return m
+
+
 @dataclass
 class StepOutput:
     """What one DPO forward produced (all device tensors; nothing is synced to the host)."""
@@ -201,12 +282,15 @@ class LlavaDPOModel:
     ``get_beta_and_logps`` (muffin/train/trainers.py:161-275): images -> CLIP (frozen) -> projector ->
     splice -> Llama stack -> fused LM-head log-probs -> DPO loss, plus the matching backward."""
 
-    def __init__(self, cfg: LlavaConfig, device="cuda:0", with_optimizer: bool = True):
+    def __init__(self, cfg: LlavaConfig, device="cuda:0", with_optimizer: bool = True,
+                 lora: Optional[LoraConfig] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("LlavaDPOModel needs an MI355X (HIP) device; there is no CPU fallback")
         self.cfg = cfg
         self.device = torch.device(device)
-        self.store = ParamStore(cfg, self.device, with_optimizer)
+        self.lora = lora
+        self.store = ParamStore(cfg, self.device, with_optimizer, lora)
+        self._dropout_step = 0          # advances once per forward: seeds the LoRA dropout masks
         self.clip: Dict[str, torch.Tensor] = {}
         self.training = True
         self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -221,6 +305,8 @@ class LlavaDPOModel:
         self._clip_raw = {k: v.detach().to(BF16).cpu() for k, v in sd.items() if k.startswith(VT)}
         for name, (key, r0, n) in st.hf_slices(cfg).items():
             st.p(key)[r0:r0 + n].copy_(sd[name].to(BF16))
+        if self.lora is not None:
+            self.load_lora_state_dict(sd, strict=False, _refresh=False)
         st.sync_master_from_params()
         st.refresh_transposes()
         cd, Kp = cfg.clip_hidden, cfg.patch_k
@@ -245,18 +331,23 @@ class LlavaDPOModel:
             c[f"{i}.fc1.w"], c[f"{i}.fc1.b"] = dev(sd[p + "mlp.fc1.weight"]), dev(sd[p + "mlp.fc1.bias"])
             c[f"{i}.fc2.w"], c[f"{i}.fc2.b"] = dev(sd[p + "mlp.fc2.weight"]), dev(sd[p + "mlp.fc2.bias"])
 
-    def init_random(self, seed: int = 0, std: float = 0.02):
+    def init_random(self, seed: int = 0, std: float = 0.02, lora_b_std: Optional[float] = None):
         """HF-default style random init directly on the device (no checkpoints exist offline)."""
         cfg, st = self.cfg, self.store
         g = torch.Generator(device=self.device).manual_seed(seed)
-        n = st.n_total
         chunk = 1 << 26
-        for a in range(0, st.n_decay, chunk):
-            b = min(st.n_decay, a + chunk)
-            st.flat_p[a:b] = (torch.randn(b - a, device=self.device, generator=g) * std).to(BF16)
-        st.flat_p[st.n_decay:n] = 1.0
-        for k in ("model.mm_projector.2.bias", "model.mm_projector.0.bias"):
-            st.p(k).zero_()
+        for k, shp, _ in st.entries:
+            off, n = st.offsets[k][0], math.prod(shp)
+            if ".lora_" in k or k.endswith("bias"):
+                continue                                        # adapters: reset_lora_parameters below; biases stay 0
+            if len(shp) == 1:
+                st.flat_p[off:off + n] = 1.0                    # norm gains
+                continue
+            for a in range(off, off + n, chunk):
+                b = min(off + n, a + chunk)
+                st.flat_p[a:b] = (torch.randn(b - a, device=self.device, generator=g) * std).to(BF16)
+        if self.lora is not None:
+            self.reset_lora_parameters(seed + 1, lora_b_std)
         st.sync_master_from_params()
         st.refresh_transposes()
         cd, Kp = cfg.clip_hidden, cfg.patch_k
@@ -286,6 +377,70 @@ class LlavaDPOModel:
             out[name] = self.store.p(key)[r0:r0 + n].detach().cpu().clone()
         return out
 
+    # ---- LoRA adapters (peft naming, muffin/train/train_llava15_lora.py:152-197) ----------------
+    def reset_lora_parameters(self, seed: int = 1, b_std: Optional[float] = None):
+        """peft LoraLayer.reset_lora_parameters: lora_A ~ kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)),
+        lora_B = 0 (b_std: draw B ~ N(0, b_std) instead - tests and benchmarks that want a non-trivial adapter)."""
+        st, g = self.store, torch.Generator(device=self.device).manual_seed(seed)
+        for name, (key, r0, n, ncol) in st.lora_slices(self.cfg).items():
+            view = st.p(key)[r0:r0 + n, :ncol]
+            if name.endswith("lora_A.weight"):
+                bound = 1.0 / math.sqrt(ncol)
+                view.copy_(((torch.rand(n, ncol, device=self.device, generator=g) * 2 - 1) * bound).to(BF16))
+            elif b_std is None:
+                view.zero_()
+            else:
+                view.copy_((torch.randn(n, ncol, device=self.device, generator=g) * b_std).to(BF16))
+
+    def load_lora_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True, _refresh: bool = True):
+        """Adapter tensors under peft names, with or without the 'base_model.model.' prefix / '.default' infix."""
+        st = self.store
+        norm = {k.replace("base_model.model.", "").replace(".default.", "."): v for k, v in sd.items() if ".lora_" in k}
+        found = 0
+        for name, (key, r0, n, ncol) in st.lora_slices(self.cfg).items():
+            if name in norm:
+                st.p(key)[r0:r0 + n, :ncol].copy_(norm[name].to(BF16))
+                found += 1
+            elif strict:
+                raise KeyError(f"adapter tensor {name} missing")
+        if found == 0 and not strict:
+            self.reset_lora_parameters()
+        if _refresh:
+            st.sync_master_from_params()
+            st.refresh_transposes(trainable_only=True)
+
+    def lora_state_dict(self, grads: bool = False) -> Dict[str, torch.Tensor]:
+        """What get_peft_state_maybe_zero_3(named_parameters(), 'none') collects: 'base_model.model.<module>.lora_X.weight'."""
+        st, out = self.store, {}
+        for name, (key, r0, n, ncol) in st.lora_slices(self.cfg).items():
+            src = st.g(key) if grads else st.p(key)
+            t = src[r0:r0 + n, :ncol].detach()
+            out["base_model.model." + name] = t.float().cpu() if grads else t.cpu().clone()
+        return out
+
+    def non_lora_trainables(self) -> Dict[str, torch.Tensor]:
+        """get_peft_state_non_lora_maybe_zero_3: the trainable non-adapter tensors = the projector."""
+        return {"base_model.model." + k: self.store.p(k).detach().cpu().clone() for k in self.store.trainable
+                if "mm_projector" in k}
+
+    def merge_lora(self):
+        """peft merge_and_unload (llava/model/builder.py:81-85): W += (alpha/r) B A for every adapted projection, on
+        the device; the adapters are zeroed afterwards (B = 0 makes them the identity)."""
+        if self.lora is None:
+            return
+        st, cfg, rp, sc = self.store, self.cfg, self.lora.r_pad, self.lora.scaling
+        rows = {"qkv": cfg.hidden, "o": cfg.hidden, "gu": cfg.ffn, "down": cfg.hidden}
+        for i in range(cfg.layers):
+            for grp, mods in LORA_GROUPS.items():
+                W, B, AT = st.p(f"layers.{i}.w{grp}"), st.p(f"layers.{i}.lora_{grp}.B"), st.pT(f"layers.{i}.lora_{grp}.A")
+                for gi in range(len(mods)):
+                    r0 = gi * rows[grp]
+                    Wg = W[r0:r0 + rows[grp]]
+                    ops.gemm_nt(B[r0:r0 + rows[grp]], AT[:, gi * rp:(gi + 1) * rp], out=Wg, residual=Wg, alpha=sc)
+                B.zero_()
+        st.sync_master_from_params()
+        st.refresh_transposes()
+
     def clip_state_dict(self) -> Dict[str, torch.Tensor]:
         """The frozen tower under its checkpoint key names (kept from load_state_dict; empty after init_random)."""
         return dict(getattr(self, "_clip_raw", {}))
@@ -293,7 +448,10 @@ class LlavaDPOModel:
     def grads_state_dict(self) -> Dict[str, torch.Tensor]:
         out = {}
         for name, (key, r0, n) in self.store.hf_slices(self.cfg).items():
-            out[name] = self.store.g(key)[r0:r0 + n].detach().float().cpu()
+            if key in self.store.trainable:
+                out[name] = self.store.g(key)[r0:r0 + n].detach().float().cpu()
+        for name, t in self.lora_state_dict(grads=True).items():
+            out[name.replace("base_model.model.", "")] = t
         return out
 
     def train(self, mode: bool = True):
@@ -342,6 +500,61 @@ class LlavaDPOModel:
             ctx.update(f_clip=f_clip, z1=z1, h1=h1)
         return feats
 
+    # ------------------------------------------------------------------ decoder projections (+ LoRA)
+    _GROUP_COLS = {"qkv": "hidden", "o": None, "gu": "ffn", "down": None}
+
+    def _proj_fwd(self, x: torch.Tensor, i: int, grp: str, residual: Optional[torch.Tensor] = None,
+                  drop_slot: int = 0):
+        """y = x W^T (+ residual); with adapters  y = x W^T + t B^T,  t = (alpha/r) dropout(x) A^T  (peft
+        lora.Linear.forward) - the adapter term rides in the same K loop (rv_gemm_nt_lora_bf16).  Returns (y, t, xd)."""
+        st = self.store
+        W = st.p(f"layers.{i}.w{grp}")
+        if self.lora is None:
+            return ops.gemm_nt(x, W, residual=residual), None, None
+        xd = None
+        if self.training and self.lora.lora_dropout > 0.0:
+            xd = ops.dropout(x, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
+        t = ops.gemm_nt(x if xd is None else xd, st.p(f"layers.{i}.lora_{grp}.A"), alpha=self.lora.scaling)
+        gc = self._GROUP_COLS[grp]
+        y = ops.gemm_nt_lora(x, W, t, st.p(f"layers.{i}.lora_{grp}.B"), group_cols=getattr(self.cfg, gc) if gc else 0,
+                             residual=residual)
+        return y, t, xd
+
+    def _dropout_seed(self, layer: int, slot: int) -> int:
+        return (self._cur_drop_step * 1000003 + layer * 8 + slot) & 0x7FFFFFFF
+
+    def _proj_bwd(self, dy: torch.Tensor, xin: torch.Tensor, t: Optional[torch.Tensor], i: int, grp: str,
+                  drop_slot: int = 0) -> torch.Tensor:
+        """Input gradient of _proj_fwd; writes the weight gradients that exist (full fine-tune: dW = dy^T x by the TN
+        GEMM; LoRA: dA = dt^T x_d, dB = dy^T t by the split-K TN GEMM, base weight frozen)."""
+        st = self.store
+        wkey = f"layers.{i}.w{grp}"
+        if self.lora is None:
+            dx = ops.gemm_nt(dy, st.pT(wkey))
+            ops.gemm_tn(dy, xin, out=st.g(wkey))
+            return dx
+        rp, sc = self.lora.r_pad, self.lora.scaling
+        akey, bkey = f"layers.{i}.lora_{grp}.A", f"layers.{i}.lora_{grp}.B"
+        G = len(LORA_GROUPS[grp])
+        og = dy.shape[1] // G
+        BT = st.pT(bkey)                                              # [rp, G*og]
+        dt = torch.empty(dy.shape[0], G * rp, dtype=BF16, device=self.device)
+        for g in range(G):                                            # dt_g = (alpha/r) dy_g B_g
+            ops.gemm_nt(dy[:, g * og:(g + 1) * og], BT[:, g * og:(g + 1) * og], out=dt[:, g * rp:(g + 1) * rp], alpha=sc)
+        if self.training and self.lora.lora_dropout > 0.0:
+            # dropout sits on the adapter branch only: dx = dy W + mask * (dt A) / (1 - p)
+            dx = ops.gemm_nt(dy, st.pT(wkey))
+            dxa = ops.gemm_nt(dt, st.pT(akey))
+            ops.dropout(dxa, self.lora.lora_dropout, self._dropout_seed(i, drop_slot), out=None, accumulate_into=dx)
+            xin = ops.dropout(xin, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
+        else:
+            dx = ops.gemm_nt_lora(dy, st.pT(wkey), dt, st.pT(akey), group_cols=0)
+        ops.gemm_tn_skinny(dt, xin, out=st.g(akey))
+        gB = st.g(bkey)
+        for g in range(G):
+            ops.gemm_tn_skinny(dy[:, g * og:(g + 1) * og], t[:, g * rp:(g + 1) * rp], out=gB[g * og:(g + 1) * og])
+        return dx
+
     # ------------------------------------------------------------------ forward
     def forward_logps(self, input_ids: torch.Tensor, labels: torch.Tensor, images: torch.Tensor,
                       save_for_backward: bool = True, all_rows: bool = False) -> StepOutput:
@@ -355,6 +568,8 @@ class LlavaDPOModel:
         B = images.shape[0]
         ctx: dict = {}
         w_rows = None
+        self._dropout_step += 1
+        self._cur_drop_step = ctx["dropout_step"] = self._dropout_step
         if all_rows:
             if save_for_backward:
                 raise ValueError("all_rows is a forward-only mode")
@@ -380,16 +595,17 @@ class LlavaDPOModel:
         layers_ctx = []
         for i in range(cfg.layers):
             xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
-            qkv = ops.gemm_nt(xn, st.p(f"layers.{i}.wqkv"))
+            qkv, t_qkv, _ = self._proj_fwd(xn, i, "qkv", drop_slot=0)
             ops.rope_inplace(qkv, cos, sin, L, 2 * H, hd, pos=plan.pos)
             attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
-            x_mid = ops.gemm_nt(attn, st.p(f"layers.{i}.wo"), residual=x)
+            x_mid, t_o, _ = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
             xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
-            gu = ops.gemm_nt(xn2, st.p(f"layers.{i}.wgu"))
+            gu, t_gu, _ = self._proj_fwd(xn2, i, "gu", drop_slot=2)
             act = ops.swiglu_fwd(gu)
-            x_next = ops.gemm_nt(act, st.p(f"layers.{i}.wdown"), residual=x_mid)
+            x_next, t_down, _ = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3)
             if save_for_backward:
-                layers_ctx.append(dict(x=x, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, gu=gu))
+                layers_ctx.append(dict(x=x, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, gu=gu,
+                                       t_qkv=t_qkv, t_o=t_o, t_gu=t_gu, t_down=t_down))
             x = x_next
         n_sel = plan.n_sel
         n_pad = max(64, ops.round_up(n_sel, 64))
@@ -419,10 +635,16 @@ class LlavaDPOModel:
         cos, sin = self._rope(L)
         hook = self.grad_ready_hook
 
-        def wgrad(dy: torch.Tensor, xin: torch.Tensor, key: str, rows: Optional[Tuple[int, int]] = None):
+        lora = self.lora is not None
+        self._cur_drop_step = ctx.get("dropout_step", 0)
+        scratch_dw = torch.empty(d, dtype=BF16, device=self.device) if lora else None   # gains are frozen under LoRA
+
+        def wgrad(dy: torch.Tensor, xin: torch.Tensor, key: str):
             """dW[key] = dy^T @ xin: TN GEMM (operands transposed on the fly by ds_read_b64_tr_b16)."""
-            tgt = st.g(key) if rows is None else st.g(key)[rows[0]:rows[1]]
-            ops.gemm_tn(dy, xin, out=tgt)
+            ops.gemm_tn(dy, xin, out=st.g(key))
+
+        def gain_grad(key: str) -> torch.Tensor:
+            return scratch_dw if lora else st.g(key)
 
         # ---- LM head + final norm
         n_sel = plan.n_sel
@@ -431,52 +653,50 @@ class LlavaDPOModel:
             rc = ops.row_coef(coef, plan.seq_of_row, ctx["w_rows"])
             dlog = ops.lmhead_logp_bwd(ctx["hsel"], st.p("lm_head.weight"), plan.tgt, ctx["lse_v"], rc, n_sel)
             dh = ops.gemm_nt(dlog, st.pT("lm_head.weight"))
-            wgrad(dlog, ctx["hsel"], "lm_head.weight")
+            if not lora:
+                wgrad(dlog, ctx["hsel"], "lm_head.weight")
             del dlog
             ops.rmsnorm_bwd(dh[:n_sel], ctx["x_final"], st.p("model.norm.weight"), ctx["rstd_f"],
-                            st.g("model.norm.weight"), row_idx=plan.sel_idx, dx=dx)
-        else:
+                            gain_grad("model.norm.weight"), row_idx=plan.sel_idx, dx=dx)
+        elif not lora:
             st.g("lm_head.weight").zero_()
             st.g("model.norm.weight").zero_()
-        if hook:
+        if hook and not lora:
             hook("lm_head", *st.buckets["lm_head"])
 
         # ---- decoder layers, last to first
         for i in reversed(range(cfg.layers)):
             c = ctx["layers"][i]
             act = ops.swiglu_fwd(c["gu"])
-            dact = ops.gemm_nt(dx, st.pT(f"layers.{i}.wdown"))
-            wgrad(dx, act, f"layers.{i}.wdown")
+            dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3)
             del act
             dgu = ops.swiglu_bwd(dact, c["gu"])
             del dact
             xn2, _ = ops.rmsnorm_fwd(c["x_mid"], st.p(f"layers.{i}.ln2"), cfg.rms_eps, want_rstd=False)
-            dxn2 = ops.gemm_nt(dgu, st.pT(f"layers.{i}.wgu"))
-            wgrad(dgu, xn2, f"layers.{i}.wgu")
+            dxn2 = self._proj_bwd(dgu, xn2, c["t_gu"], i, "gu", drop_slot=2)
             del dgu, xn2
-            dx_mid = ops.rmsnorm_bwd(dxn2, c["x_mid"], st.p(f"layers.{i}.ln2"), c["rstd2"], st.g(f"layers.{i}.ln2"),
+            dx_mid = ops.rmsnorm_bwd(dxn2, c["x_mid"], st.p(f"layers.{i}.ln2"), c["rstd2"], gain_grad(f"layers.{i}.ln2"),
                                      dres=dx)
             del dxn2
-            dattn = ops.gemm_nt(dx_mid, st.pT(f"layers.{i}.wo"))
-            wgrad(dx_mid, c["attn"], f"layers.{i}.wo")
+            dattn = self._proj_bwd(dx_mid, c["attn"], c["t_o"], i, "o", drop_slot=1)
             dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
             del dattn
             ops.rope_inplace(dqkv, cos, sin, L, 2 * H, hd, backward=True, pos=plan.pos)
             xn, _ = ops.rmsnorm_fwd(c["x"], st.p(f"layers.{i}.ln1"), cfg.rms_eps, want_rstd=False)
-            dxn = ops.gemm_nt(dqkv, st.pT(f"layers.{i}.wqkv"))
-            wgrad(dqkv, xn, f"layers.{i}.wqkv")
+            dxn = self._proj_bwd(dqkv, xn, c["t_qkv"], i, "qkv", drop_slot=0)
             del dqkv, xn
-            dx = ops.rmsnorm_bwd(dxn, c["x"], st.p(f"layers.{i}.ln1"), c["rstd1"], st.g(f"layers.{i}.ln1"),
+            dx = ops.rmsnorm_bwd(dxn, c["x"], st.p(f"layers.{i}.ln1"), c["rstd1"], gain_grad(f"layers.{i}.ln1"),
                                  dres=dx_mid)
             del dxn, dx_mid
             ctx["layers"][i] = None          # free this layer's activations
             if hook:
                 hook(f"layer{i}", *st.buckets[f"layer{i}"])
 
-        # ---- embedding (deterministic segmented sum) and projector
-        ge = st.g("model.embed_tokens.weight")
-        ge.zero_()
-        ops.embed_bwd(plan.uniq_ids, plan.seg_off, plan.pos_sorted, dx, ge)
+        # ---- embedding (deterministic segmented sum; frozen under LoRA) and projector
+        if not lora:
+            ge = st.g("model.embed_tokens.weight")
+            ge.zero_()
+            ops.embed_bwd(plan.uniq_ids, plan.seg_off, plan.pos_sorted, dx, ge)
         dfeat = ops.feat_grad(plan.feat_src_a, plan.feat_src_b, dx, d)
         ops.colsum(dfeat, out=st.g("model.mm_projector.2.bias"))
         wgrad(dfeat, ctx["h1"], "model.mm_projector.2.weight")

@@ -63,6 +63,55 @@ def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def gemm_nt_lora(a: torch.Tensor, b: torch.Tensor, a2: torch.Tensor, b2: torch.Tensor, group_cols: int = 0,
+                 out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a @ b^T + a2[:, c0(n) : c0(n)+K2] @ b2^T (+ residual): the fused LoRA GEMM (rv_gemm_nt_lora_bf16).
+    K2 = b2.shape[1]; c0(n) = (n // group_cols) * K2 when group_cols > 0 (fused q|k|v, gate|up), else 0."""
+    _chk2d(a, "a"), _chk2d(b, "b"), _chk2d(a2, "a2"), _chk2d(b2, "b2")
+    M, K = a.shape
+    N, K2 = b2.shape
+    if b.shape != (N, K) or a2.shape[0] != M:
+        raise ValueError(f"gemm_nt_lora: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} a2{tuple(a2.shape)} b2{tuple(b2.shape)}")
+    groups = N // group_cols if group_cols else 1
+    if a2.shape[1] != groups * K2:
+        raise ValueError(f"gemm_nt_lora: a2 must have {groups} x {K2} columns, got {a2.shape[1]}")
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    hip.call("rv_gemm_nt_lora_bf16", a, a.stride(0), b, b.stride(0), a2, a2.stride(0), b2, b2.stride(0), K2,
+             int(group_cols), out, out.stride(0), M, N, K, residual, residual.stride(0) if residual is not None else 0)
+    return out
+
+
+_SPLITK_WS = {}
+
+
+def gemm_tn_skinny(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None, alpha: float = 1.0,
+                   splits: int = 0) -> torch.Tensor:
+    """gemm_tn for outputs with few 256x256 tiles (LoRA weight gradients): split-K over the token rows so the whole
+    chip works on it; deterministic fp32 second pass (rv_gemm_tn_bf16_splitk)."""
+    _chk2d(p, "p"), _chk2d(q, "q")
+    R, I = p.shape
+    Rq, J = q.shape
+    if R != Rq:
+        raise ValueError(f"gemm_tn_skinny: row mismatch {R} vs {Rq}")
+    if out is None:
+        out = torch.empty(I, J, dtype=BF16, device=p.device)
+    _chk2d(out, "out")
+    tiles = ((I + 255) // 256) * ((J + 255) // 256)
+    if splits <= 0:
+        splits = max(1, min(256 // tiles, (R + 511) // 512))
+    key = (p.device, torch.cuda.current_stream(p.device).cuda_stream)
+    need = splits * I * J
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=p.device)
+        _SPLITK_WS[key] = ws
+    hip.call("rv_gemm_tn_bf16_splitk", p, p.stride(0), q, q.stride(0), out, out.stride(0), R, I, J, float(alpha),
+             int(splits), ws)
+    return out
+
+
 def gemm_nt_f32(a, b, variant: int = -1) -> torch.Tensor:
     _chk2d(a, "a"), _chk2d(b, "b")
     out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
@@ -153,6 +202,20 @@ def gelu_fwd(x):
     y = torch.empty_like(x)
     hip.call("rv_gelu_fwd", x, y, x.numel())
     return y
+
+
+_NO_OUT = object()
+
+
+def dropout(x: torch.Tensor, p: float, seed: int, out=_NO_OUT, accumulate_into: Optional[torch.Tensor] = None):
+    """y = keep(seed, e) ? x / (1 - p) : 0  (counter-based mask, regenerated - never stored - in backward).
+    out=None with accumulate_into=t performs t += dropout(x) without materialising y."""
+    if not x.is_contiguous() or (accumulate_into is not None and not accumulate_into.is_contiguous()):
+        raise ValueError("dropout: contiguous tensors required")
+    if out is _NO_OUT:
+        out = torch.empty_like(x)
+    hip.call("rv_dropout", x, out, accumulate_into, x.numel(), float(p), int(seed) & 0x7FFFFFFF)
+    return out if out is not None else accumulate_into
 
 
 def gelu_bwd(dy, x):

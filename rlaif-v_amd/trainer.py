@@ -53,6 +53,21 @@ class TrainingArguments:
     past_index: int = -1
     bf16: bool = True
     seed: int = 42
+    # LoRA flags of muffin/train/train_llava15_lora.py:111-116 (same names and defaults)
+    fully_tune: bool = False
+    lora_enable: bool = False
+    lora_r: int = 64
+    lora_alpha: int = 16
+    lora_dropout: float = 0.05
+    lora_weight_path: Optional[str] = None
+    lora_bias: str = "none"
+
+    def lora_config(self):
+        """The LoraConfig init_model builds when --lora_enable (train_llava15_lora.py:304-312), else None."""
+        if not self.lora_enable:
+            return None
+        from .model import LoraConfig
+        return LoraConfig(r=self.lora_r, lora_alpha=self.lora_alpha, lora_dropout=self.lora_dropout, bias=self.lora_bias)
 
 
 def cosine_lr(step: int, total: int, base_lr: float, warmup_ratio: float) -> float:
@@ -201,12 +216,12 @@ class LLaVA15DPOTrainer:
         step = self.state["global_step"] + 1
         lr = self.current_lr() if lr is None else lr
         ops.grad_norm(st.flat_g, a.max_grad_norm, self._clip, pre_scale=1.0 / self.reducer.world_size)
-        nd = st.n_decay
-        ops.adamw_step(st.flat_p[:nd], st.flat_master[:nd], st.flat_m[:nd], st.flat_v[:nd], st.flat_g[:nd], lr,
+        nd, tp = st.n_decay, st.train_p          # the optimizer owns flat_p[t0:] (everything, or adapters + projector)
+        ops.adamw_step(tp[:nd], st.flat_master[:nd], st.flat_m[:nd], st.flat_v[:nd], st.flat_g[:nd], lr,
                        a.adam_beta1, a.adam_beta2, a.adam_epsilon, a.weight_decay, step, clip=self._clip)
-        ops.adamw_step(st.flat_p[nd:], st.flat_master[nd:], st.flat_m[nd:], st.flat_v[nd:], st.flat_g[nd:], lr,
+        ops.adamw_step(tp[nd:], st.flat_master[nd:], st.flat_m[nd:], st.flat_v[nd:], st.flat_g[nd:], lr,
                        a.adam_beta1, a.adam_beta2, a.adam_epsilon, 0.0, step, clip=self._clip)
-        st.refresh_transposes()
+        st.refresh_transposes(trainable_only=True)
         self.state["global_step"] = step
 
     def training_step(self, inputs: dict) -> torch.Tensor:
@@ -258,8 +273,10 @@ class LLaVA15DPOTrainer:
         """HF-layout weights (safe_save_model_for_hf_trainer, train_llava15.py:102-112)."""
         if int(os.environ.get("RANK", "0")) != 0:
             return
-        from .checkpoint import save_pretrained, save_state_dict_sharded
-        if state_dict is None:
+        from .checkpoint import save_lora_adapter, save_pretrained, save_state_dict_sharded
+        if self.model.lora is not None and state_dict is None:
+            save_lora_adapter(self.model, output_dir)        # adapter + non_lora_trainables.bin (train_llava15_lora.py:184-197)
+        elif state_dict is None:
             save_pretrained(self.model, output_dir)          # sharded safetensors + index + config.json, HF names
         else:
             save_state_dict_sharded(state_dict, output_dir, self.model.cfg)
@@ -284,6 +301,6 @@ class LLaVA15DPOTrainer:
         st = self.model.store
         blob = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
         st.flat_master.copy_(blob["master"]), st.flat_m.copy_(blob["m"]), st.flat_v.copy_(blob["v"])
-        ops.cast_f32_to_bf16(st.flat_master, st.flat_p)
-        st.refresh_transposes()
+        ops.cast_f32_to_bf16(st.flat_master, st.train_p)
+        st.refresh_transposes(trainable_only=True)
         self.state = blob["state"]

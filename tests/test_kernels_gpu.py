@@ -139,6 +139,42 @@ def test_gemm_tn_identity_asymmetric(ops):
     close(ops.gemm_tn(a, b), a.float().t() @ b.float(), what="gemm_tn strided views")
 
 
+@pytest.mark.parametrize("M,N,K,K2,gc", [(300, 768, 256, 64, 256), (200, 1024, 512, 64, 512), (130, 256, 128, 128, 0),
+                                          (27000, 3072, 1024, 64, 1024), (26000, 1024, 2048, 192, 0)])
+def test_gemm_nt_lora(ops, M, N, K, K2, gc):
+    """Fused LoRA GEMM: second K segment fetched from (a2, b2), column-grouped for fused q|k|v / gate|up; both the
+    128x128 kernel (small problems) and the 256x256 ping-pong kernel (>= 192 tiles)."""
+    dev = _dev()
+    groups = N // gc if gc else 1
+    a, b = rnd(M, K, seed=31, dev=dev), rnd(N, K, seed=32, dev=dev)
+    a2, b2 = rnd(M, groups * K2, seed=33, dev=dev), rnd(N, K2, seed=34, dev=dev)
+    res = rnd(M, N, seed=35, dev=dev)
+    ref = a.float() @ b.float().t()
+    for g in range(groups):
+        cols = slice(g * gc, (g + 1) * gc) if gc else slice(0, N)
+        ref[:, cols] += a2[:, g * K2:(g + 1) * K2].float() @ b2[cols].float().t()
+    close(ops.gemm_nt_lora(a, b, a2, b2, group_cols=gc), ref, what=f"gemm_nt_lora {M}x{N}x{K}+{K2}")
+    close(ops.gemm_nt_lora(a, b, a2, b2, group_cols=gc, residual=res), ref + res.float(), what="gemm_nt_lora + residual")
+    # zero adapter == plain GEMM, bit for bit (the extra K steps add exact zeros)
+    z = torch.zeros_like(a2)
+    assert torch.equal(ops.gemm_nt_lora(a, b, z, b2, group_cols=gc), ops.gemm_nt(a, b, variant=3 if M > 20000 else 1))
+
+
+@pytest.mark.parametrize("R,I,J", [(5000, 64, 1024), (27664, 192, 4096), (3000, 1024, 64), (777, 64, 64)])
+def test_gemm_tn_skinny(ops, R, I, J):
+    """Split-K TN GEMM (LoRA weight gradients): ragged last chunk, deterministic fp32 second pass."""
+    dev = _dev()
+    p, q = rnd(R, I, seed=41, dev=dev, scale=0.3), rnd(R, J, seed=42, dev=dev, scale=0.3)
+    out = ops.gemm_tn_skinny(p, q, alpha=0.25)
+    close(out, 0.25 * (p.float().t() @ q.float()), what=f"gemm_tn_skinny {R}x{I}x{J}")
+    assert torch.equal(ops.gemm_tn_skinny(p, q, alpha=0.25), out)
+    close(ops.gemm_tn_skinny(p, q, splits=1), ops.gemm_tn(p, q), rel=4e-3, what="splits=1 vs gemm_tn")
+    view = torch.zeros(I, J + 64, dtype=BF, device=dev)
+    ops.gemm_tn_skinny(p, q, out=view[:, 32:32 + J], splits=7)
+    close(view[:, 32:32 + J], p.float().t() @ q.float(), what="gemm_tn_skinny strided out")
+    assert view[:, :32].abs().sum() == 0 and view[:, 32 + J:].abs().sum() == 0
+
+
 def test_gemm_f32_out(ops):
     dev = _dev()
     a, b = rnd(190, 128, seed=9, dev=dev), rnd(260, 128, seed=10, dev=dev)

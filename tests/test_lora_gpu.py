@@ -1,0 +1,227 @@
+"""LoRA-DPO on the HIP path against the CPU oracle's adapter restatement.
+Same bars as tests/test_model_parity_gpu.py; everything goes through the C ABI (rv_gemm_nt_lora_bf16,
+rv_gemm_tn_bf16_splitk, rv_dropout ...)."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dpo_oracle as O  # noqa: E402
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _build(cfg, r, seed=3, b_std=0.02, dropout=0.0, alpha=16, share_prefix=True):
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel, LoraConfig
+    model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)), lora=LoraConfig(r=r, lora_alpha=alpha, lora_dropout=dropout))
+    model.share_prefix = share_prefix
+    W = O.make_weights(cfg, seed=seed)
+    W.update(O.make_lora_weights(cfg, r, seed=seed + 1, b_std=b_std))
+    model.load_state_dict(W)
+    return model, W
+
+
+def _trainer(model, **kw):
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    return LLaVA15DPOTrainer(model=model, args=TrainingArguments(**kw))
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _oracle_grads(batch, W, cfg, scale, masks=None):
+    names = O.lora_trainable_names(W)
+    for k in names:
+        W[k].requires_grad_(True)
+        W[k].grad = None
+    out = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0, lora_scale=scale, lora_masks=masks)
+    out["loss"].backward()
+    grads = {k: W[k].grad.detach().clone() for k in names}
+    for k in names:
+        W[k].requires_grad_(False)
+    return out, grads
+
+
+@pytest.mark.parametrize("share_prefix", [False, True])
+@pytest.mark.parametrize("r", [16, 64])
+def test_lora_forward_backward_vs_oracle(monkeypatch, r, share_prefix):
+    """r = 16 exercises the zero padding of the stored rank to the GEMM K step (64)."""
+    _need_gpu()
+    monkeypatch.setenv("SFT_weight", "0.0")
+    monkeypatch.setenv("DPO_weight", "1.0")
+    cfg = O.tiny_cfg()
+    model, W = _build(cfg, r, share_prefix=share_prefix)
+    model.train()
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, 3, 44, 12, seed=21)
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    model.backward(out, model.last_coef)
+    ref, grads = _oracle_grads(batch, W, cfg, 16 / r)
+    mask = ref["labels"][:, 1:] != -100
+    err_tok = (out.per_token_logp.cpu() - ref["per_token_logps"].detach()[mask]).abs().max().item()
+    err_lp = (out.seq_logp.cpu() - ref["log_prob"].detach()).abs()
+    print(f"lora r={r}: per-token err {err_tok:.3e}, seq err {err_lp.tolist()}, loss {float(loss):.6f} vs {float(ref['loss'].detach()):.6f}")
+    assert err_tok <= 3e-2
+    assert bool((err_lp <= 1e-3 * ref["log_prob"].abs() + 5e-2).all())
+    assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])) + 7e-3
+    got = model.grads_state_dict()
+    assert set(got) == set(grads), (sorted(set(got) ^ set(grads))[:6])
+    worst = 1.0
+    for k, gref in grads.items():
+        if gref.norm() < 1e-8:
+            continue
+        c = _cos(got[k], gref)
+        worst = min(worst, c)
+        assert c >= 0.99, (k, c)
+        assert abs(float(got[k].norm()) - float(gref.norm())) <= 4e-2 * float(gref.norm()) + 1e-6, k
+    print(f"lora r={r}: worst gradient cosine {worst:.5f} over {len(grads)} tensors")
+    # the padded rank rows / columns never receive gradient
+    if r < 64:
+        gA = model.store.g("layers.0.lora_qkv.A")
+        assert gA[r:64].abs().sum() == 0 and gA[64 + r:128].abs().sum() == 0
+        assert model.store.g("layers.0.lora_down.B")[:, r:].abs().sum() == 0
+
+
+def test_lora_zero_b_is_bit_identical_to_base(monkeypatch):
+    """peft's initial adapter (lora_B = 0) must not change a single bit of the log-probs."""
+    _need_gpu()
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    cfg = O.tiny_cfg()
+    model, W = _build(cfg, 64, b_std=None)
+    base = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)))
+    base.load_state_dict({k: v for k, v in W.items() if ".lora_" not in k})
+    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=5)
+    a = model.eval().forward_logps(batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"],
+                                   save_for_backward=False)
+    b = base.eval().forward_logps(batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"],
+                                  save_for_backward=False)
+    assert torch.equal(a.per_token_logp, b.per_token_logp)
+
+
+def test_lora_merge_and_adapter_roundtrip(tmp_path):
+    _need_gpu()
+    from rlaif_v_amd.checkpoint import load_lora_adapter, lora_config_from_dir, save_lora_adapter
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    cfg = O.tiny_cfg()
+    model, W = _build(cfg, 16)
+    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=6)
+    args = (batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"])
+    ref = model.eval().forward_logps(*args, save_for_backward=False).seq_logp.cpu()
+    d = str(tmp_path / "adapter")
+    save_lora_adapter(model, d, base_model_name_or_path="liuhaotian/llava-v1.5-7b")
+    assert sorted(os.listdir(d)) == ["adapter_config.json", "adapter_model.safetensors", "config.json", "non_lora_trainables.bin"]
+    ac = json.load(open(os.path.join(d, "adapter_config.json")))
+    assert ac["r"] == 16 and ac["peft_type"] == "LORA" and len(ac["target_modules"]) == 7
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(d, "adapter_model.safetensors"))
+    k = "base_model.model.model.layers.1.self_attn.v_proj.lora_B.weight"
+    assert tuple(sd[k].shape) == (cfg.hidden, 16)
+    assert torch.equal(sd[k], W["model.layers.1.self_attn.v_proj.lora_B.weight"].to(torch.bfloat16))
+    # fresh base + adapter directory -> same outputs; merged -> same within bf16 rounding of W + sBA
+    m2 = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)), lora=lora_config_from_dir(d), with_optimizer=False)
+    m2.load_state_dict({k: v for k, v in W.items() if ".lora_" not in k})
+    load_lora_adapter(m2, d)
+    got = m2.eval().forward_logps(*args, save_for_backward=False).seq_logp.cpu()
+    assert torch.equal(got, ref)
+    m2.merge_lora()
+    merged = m2.forward_logps(*args, save_for_backward=False).seq_logp.cpu()
+    assert (merged - ref).abs().max() <= 1e-3 * ref.abs().max() + 5e-2
+    assert m2.store.p("layers.0.lora_qkv.B").abs().sum() == 0
+
+
+def test_lora_training_steps_match_oracle():
+    """Two optimizer steps (clip + AdamW on adapters + projector only); the frozen base must not move."""
+    _need_gpu()
+    cfg = O.tiny_cfg()
+    model, W = _build(cfg, 64)
+    model.lora.lora_dropout = 0.0
+    tr = _trainer(model, learning_rate=1e-3, max_steps=10, warmup_ratio=0.0, lr_scheduler_type="constant")
+    base_before = model.store.flat_p[:model.store.t0].clone()
+    Wo = {k: v.clone() for k, v in W.items()}
+    state = {}
+    for step in (1, 2):
+        batch = O.make_synthetic_batch(cfg, 2, 36, 12, seed=30 + step)
+        loss = tr.training_step(dict(batch))
+        out_o, grads_o, gn_o = O.dpo_train_step(batch, Wo, cfg, state, lr=1e-3, step=step, sft_weight=0.0, dpo_weight=1.0,
+                                                lora_scale=16 / 64)
+        assert abs(float(loss) - float(out_o["loss"])) <= 2e-3 * abs(float(out_o["loss"])) + 7e-3
+        gn = float(tr._clip[0])
+        assert abs(gn - gn_o) <= 3e-2 * gn_o, (gn, gn_o)
+    assert torch.equal(model.store.flat_p[:model.store.t0], base_before)
+    new = model.lora_state_dict()
+    for k in ("model.layers.0.self_attn.q_proj.lora_A.weight", "model.layers.1.mlp.up_proj.lora_B.weight",
+              "model.layers.1.mlp.down_proj.lora_A.weight"):
+        ref_delta = Wo[k] - W[k]
+        got_delta = new["base_model.model." + k].float() - W[k]
+        assert _cos(got_delta, ref_delta) >= 0.95, (k, _cos(got_delta, ref_delta))
+    # W^T copies of the adapters follow the update
+    st = model.store
+    assert torch.equal(st.pT("layers.0.lora_o.A"), st.p("layers.0.lora_o.A").t().contiguous())
+
+
+def test_dropout_kernel_statistics():
+    _need_gpu()
+    from rlaif_v_amd import ops
+    x = torch.ones(4096, 512, dtype=torch.bfloat16, device="cuda:0")
+    for p in (0.05, 0.5):
+        y = ops.dropout(x, p, seed=7)
+        keep = (y != 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 4e-3, (p, keep)
+        assert torch.allclose(y[y != 0].float(), torch.tensor(1 / (1 - p)), rtol=1e-2)
+        assert torch.equal(ops.dropout(x, p, seed=7), y)
+        assert not torch.equal(ops.dropout(x, p, seed=8), y)
+        acc = torch.full_like(x, 2.0)
+        ops.dropout(x, p, seed=7, out=None, accumulate_into=acc)
+        expect = ((y != 0).float() / (1 - p) + 2.0).to(torch.bfloat16)      # accumulates the unrounded fp32 value
+        assert torch.equal(acc, expect)
+        # no row / column structure in the mask
+        m = (y != 0).float()
+        assert (m.mean(0) - (1 - p)).abs().max() < 0.05 and (m.mean(1) - (1 - p)).abs().max() < 0.1
+    assert torch.equal(ops.dropout(x, 0.0, seed=1), x)
+
+
+def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch):
+    """lora_dropout > 0: replay the device masks (regenerated from the model's seeds) inside the oracle."""
+    _need_gpu()
+    from rlaif_v_amd import ops
+    monkeypatch.setenv("SFT_weight", "0.0")
+    monkeypatch.setenv("DPO_weight", "1.0")
+    cfg = O.tiny_cfg()
+    p = 0.25
+    model, W = _build(cfg, 64, dropout=p, share_prefix=False)       # reference row layout: masks index [S, L, in]
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=41)
+    model.train()
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    N = out.plan.S * out.plan.L
+    masks = {}
+    d, f = cfg.hidden, cfg.ffn
+    for i in range(cfg.layers):
+        for slot, (mods, width) in enumerate(((("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), d),
+                                              (("self_attn.o_proj",), d), (("mlp.gate_proj", "mlp.up_proj"), d),
+                                              (("mlp.down_proj",), f))):
+            m = ops.dropout(torch.ones(N, width, dtype=torch.bfloat16, device="cuda:0"), p, model._dropout_seed(i, slot))
+            for mod in mods:        # q/k/v (gate/up) share one mask: the fused projection drops its input once
+                masks[f"model.layers.{i}.{mod}"] = (m != 0).float().cpu() / (1 - p)
+    model.backward(out, model.last_coef)
+    ref, grads = _oracle_grads(batch, W, cfg, 16 / 64, masks)
+    assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])) + 7e-3
+    assert bool(((out.seq_logp.cpu() - ref["log_prob"].detach()).abs() <= 1e-3 * ref["log_prob"].abs() + 5e-2).all())
+    got = model.grads_state_dict()
+    for k, gref in grads.items():
+        if gref.norm() < 1e-8:
+            continue
+        assert _cos(got[k], gref) >= 0.99, (k, _cos(got[k], gref))
+    # and the masks really were applied: the no-dropout oracle differs measurably
+    ref0, _ = _oracle_grads(batch, W, cfg, 16 / 64)
+    assert (ref0["log_prob"] - ref["log_prob"]).abs().max() > 1e-3
