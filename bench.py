@@ -24,13 +24,22 @@ sys.path.insert(0, REPO)
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def flops_per_pair(L: int, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000) -> float:
-    """algorithmic FLOPs of one pair, full fine-tune, causal attention counted at
-    half, no recompute, CLIP once per pair (forward only) + projector (fwd+bwd)."""
+def flops_per_seq(n_tok: float, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000,
+                  lora_r: int = 0) -> float:
+    """Algorithmic FLOPs of fwd + bwd over one sequence of n_tok tokens (causal attention at half, no recompute).
+    Full fine-tune: forward + input gradients + weight gradients = 3 passes over the linear layers.  LoRA: the base
+    weights are frozen -> 2 passes, plus the adapters (forward t = xA^T and tB^T; backward dt, dt A, dA, dB = 2x)."""
     per_tok_linear = layers * (8 * d * d + 6 * d * f) + 2 * d * V
-    per_tok_attn = layers * 2 * d * L
-    f_fwd_seq = L * (per_tok_linear + per_tok_attn)
-    return 3 * 2 * f_fwd_seq + 0.366e12 + 3 * 0.024e12
+    per_tok_attn = layers * 2 * d * n_tok
+    per_tok_lora = layers * 2 * lora_r * (4 * 2 * d + 3 * (d + f))
+    passes = 2 if lora_r else 3
+    return n_tok * (passes * per_tok_linear + 3 * per_tok_attn + 3 * per_tok_lora)
+
+
+def flops_per_pair(L: int, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000, lora_r: int = 0) -> float:
+    """algorithmic FLOPs of one pair (two sequences of L tokens), CLIP once per pair (forward
+    only) + projector (fwd+bwd).  Full fine-tune at L = 2048: 169.4 TFLOP."""
+    return 2 * flops_per_seq(L, layers, d, f, V, lora_r) + 0.366e12 + 3 * 0.024e12
 
 
 class GemmTimer:
@@ -66,7 +75,21 @@ class GemmTimer:
             return r
 
         ops.gemm_tn = timed_tn
-        self._restore = lambda: (setattr(ops, "gemm_nt", orig), setattr(ops, "gemm_tn", orig_tn))
+        orig_lora = ops.gemm_nt_lora
+
+        def timed_lora(a, b, a2, b2, **kw):       # fused LoRA GEMM: K + K2 contraction steps
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_lora(a, b, a2, b2, **kw)
+            e.record()
+            kk = a.shape[1] + b2.shape[1]
+            recs.append((s, e, 2.0 * a.shape[0] * b.shape[0] * kk,
+                         2.0 * (a.shape[0] * kk + b.shape[0] * kk + a.shape[0] * b.shape[0])))
+            return r
+
+        ops.gemm_nt_lora = timed_lora
+        self._restore = lambda: (setattr(ops, "gemm_nt", orig), setattr(ops, "gemm_tn", orig_tn),
+                                 setattr(ops, "gemm_nt_lora", orig_lora))
 
     def summary(self):
         tot_ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
@@ -124,6 +147,10 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=8)
     ap.add_argument("--seq-len", type=int, default=2048, help="spliced length L (text length = L - 575)")
     ap.add_argument("--layers", type=int, default=32, help="debug only: anything but 32 is not the headline config")
+    ap.add_argument("--lora", action="store_true",
+                    help="LoRA-DPO workload (BASELINE.json configs[4]: rank 64 adapters on all decoder projections, "
+                         "frozen base; use with --seq-len 4096).  Not the headline line.")
+    ap.add_argument("--lora-r", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     args = ap.parse_args()
@@ -135,17 +162,19 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel, LoraConfig
     from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
     from rlaif_v_amd.data import SyntheticPreferenceDataset, DataCollatorForDPODataset
     import torch.distributed as dist
 
     L, B = args.seq_len, args.pairs_per_gpu
     cfg = LlavaConfig(layers=args.layers, model_max_length=L)
-    model = LlavaDPOModel(cfg, device=dev)
+    lora = LoraConfig(r=args.lora_r) if args.lora else None        # peft defaults of train_llava15_lora.py:111-116
+    model = LlavaDPOModel(cfg, device=dev, lora=lora)
     model.init_random(seed=0)            # identical weights on every rank
     reducer = BucketedAllReduce(model.store.flat_g) if world > 1 else None
-    targs = TrainingArguments(max_steps=1000, per_device_train_batch_size=B)
+    targs = TrainingArguments(max_steps=1000, per_device_train_batch_size=B, lora_enable=args.lora,
+                              lora_r=args.lora_r, learning_rate=1e-5 if args.lora else 5e-7)
     trainer = LLaVA15DPOTrainer(model=model, args=targs, reducer=reducer)
 
     class _Tok:
@@ -183,24 +212,25 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         pairs_per_s = B * world * args.steps / dt
-        fp_nominal = flops_per_pair(L, layers=args.layers)
+        lr_ = args.lora_r if args.lora else 0
+        fp_nominal = flops_per_pair(L, layers=args.layers, lora_r=lr_)
         # shared-prefix reuse: the prefix of each pair is computed once -> subtract its work once per pair
         # (report the MFMA fraction on the FLOPs actually required)
         plan = model.last_out.plan
         shared = plan.shared_len or [0] * B
-        d_, f_, V_ = cfg.hidden, cfg.ffn, cfg.vocab
-        per_tok_linear = args.layers * (8 * d_ * d_ + 6 * d_ * f_) + 2 * d_ * V_
-        saved = sum(3.0 * p * (per_tok_linear + args.layers * 2 * d_ * p) for p in shared) / max(len(shared), 1)
+        saved = sum(flops_per_seq(p, layers=args.layers, lora_r=lr_) for p in shared) / max(len(shared), 1)
         fp = fp_nominal - saved
         step_tflops_per_gpu = fp * (pairs_per_s / world) / 1e12
         line = {
             "metric": "preference-pairs/sec (DPO step) LLaVA-1.5-7B bf16", "value": pairs_per_s, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B) full-FT DPO step, 336px, "
-                                   f"seq_len={L}, {B} pairs/GPU, random-init weights",
+            "config": {"workload": f"LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B) "
+                                   + (f"LoRA (r={args.lora_r}, all 7 decoder projections, dropout 0.05)" if args.lora else "full-FT")
+                                   + f" DPO step, 336px, seq_len={L}, {B} pairs/GPU, random-init weights",
                        "pairs_per_gpu": B, "global_batch_pairs": B * world, "seq_len": L, "llm_layers": args.layers,
                        "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0",
+                       "trainable_params": int(model.store.n_train),
                        "gradient_checkpointing": False, "shared_prefix_reuse": bool(model.share_prefix)},
             "loss": float(loss), "max_memory_allocated_gb": torch.cuda.max_memory_allocated() / 2**30,
             "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / PEAK_BF16_TFLOPS,
@@ -224,7 +254,7 @@ def main():
                                                 "operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
                                 "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
                                 "gemm_ms_per_step": g["total_ms"] / args.steps}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.lora:     # the CPU leg times the full-FT oracle step
             line["cpu_baseline"] = cpu_baseline(L)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -49,6 +49,12 @@ int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const
                          long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
                          const void* residual, long ldr, void* stream);
 
+/* C = dropout_{p,seed}(alpha * A B^T) + residual: rv_gemm_nt_bf16 whose result is masked with exactly the mask
+ * rv_dropout(p, seed) draws for a contiguous [M][N] tensor, before the residual is added.  Backward of the LoRA branch
+ * dropout: dx = dy W + mask * (dt A) / (1 - p) without materialising dt A.  N % 8 == 0. */
+int rv_gemm_nt_dropout_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                            const void* residual, long ldr, float alpha, float p, int seed, void* stream);
+
 /* Split-K form of rv_gemm_tn_bf16 for skinny outputs (LoRA weight gradients: I or J = r): `splits` chunks of the
  * contraction rows are reduced by separate workgroups into fp32 slabs (workspace: splits*I*J floats, caller owned)
  * which a second pass sums in a fixed order: C = bf16(alpha * sum).  Deterministic. */
@@ -127,7 +133,7 @@ int rv_swiglu_bwd(const void* dact, long ldd, const void* gu, long ldgu, void* d
 int rv_gelu_fwd(const void* x, void* y, long n, void* stream);
 int rv_gelu_bwd(const void* dy, const void* x, void* dx, long n, void* stream);
 /* Dropout of the LoRA branch input (peft lora_dropout, muffin/train/train_llava15_lora.py:114,309): element e is kept
- * iff hash(seed, e) >= p * 2^32 and scaled by 1/(1-p); the same (seed, n) regenerates the same mask in backward.
+ * iff hash16(seed, e) >= p * 2^16 and scaled by 1/(1-p); the same (seed, n) regenerates the same mask in backward.
  * y = dropped x (may alias x, may be NULL); acc (optional) += dropped x (gradient accumulation).  Contiguous, n % 8 == 0. */
 int rv_dropout(const void* x, void* y, void* acc, long n, float p, int seed, void* stream);
 

@@ -248,22 +248,25 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, long ldd, con
 }
 
 // ------------------------------------------------------------------ dropout on the LoRA branch (peft lora_dropout)
-// Counter-based mask: element e of a launch is kept iff mix32(e ^ seed-derived key) >= p * 2^32, so the backward
+// Counter-based mask: element e of a launch is kept iff its 16 hash bits (mix32 of the element-pair index and a seed-derived key) >= p * 2^16, so the backward
 // pass regenerates the identical mask from (seed, e) and nothing is stored.  y = keep ? x / (1 - p) : 0.
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
 }
 __global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ acc, long n8,
-                               uint32_t thresh, float inv_keep, uint32_t key) {
+                               uint32_t thresh16, float inv_keep, uint32_t key) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     float f[8];
     unpack8(((const uint4*)x)[i], f);
-    const uint32_t base = mix32((uint32_t)(i >> 29) + key);      // elements beyond 2^32 get a different stream
+    // one 32-bit hash serves two elements (16 random bits each: p is resolved to 1.5e-5) - the integer multiplies
+    // of the mixer, not HBM, bound this kernel otherwise
+    const uint32_t base = (uint32_t)(i >> 30) * 0x9e3779b9u + key;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t h = mix32(((uint32_t)(i * 8 + j)) ^ base);
-      f[j] = (h >= thresh) ? f[j] * inv_keep : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t h = mix32(((uint32_t)i * 4u + (uint32_t)j) ^ base);
+      f[2 * j] = ((h & 0xffffu) >= thresh16) ? f[2 * j] * inv_keep : 0.f;
+      f[2 * j + 1] = ((h >> 16) >= thresh16) ? f[2 * j + 1] * inv_keep : 0.f;
     }
     if (y) ((uint4*)y)[i] = pack8(f);
     if (acc) {
@@ -745,8 +748,7 @@ int rv_dropout(const void* x, void* y, void* acc, long n, float p, int seed, voi
   RV_REQUIRE(p >= 0.f && p < 1.f, "rv_dropout: 0 <= p < 1");
   RV_REQUIRE(y != nullptr || acc != nullptr, "rv_dropout: need an output (y) or an accumulator (acc)");
   if (n == 0) return 0;
-  const double t = (double)p * 4294967296.0;
-  const uint32_t thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+  const uint32_t thresh = (uint32_t)((double)p * 65536.0 + 0.5);        // 16 random bits per element
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, STREAM(stream), (const bf16_t*)x,
                      (bf16_t*)y, (bf16_t*)acc, n / 8, thresh, 1.f / (1.f - p), (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu);
   RV_CHECK_LAUNCH();

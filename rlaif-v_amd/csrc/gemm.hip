@@ -220,6 +220,21 @@ int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const
   return dispatch_ext(g, epi, stream);
 }
 
+int rv_gemm_nt_dropout_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                            const void* residual, long ldr, float alpha, float p, int seed, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
+  if (check_shape(g, "rv_gemm_nt_dropout_bf16")) return 1;
+  RV_REQUIRE(p >= 0.f && p < 1.f, "rv_gemm_nt_dropout_bf16: 0 <= p < 1");
+  RV_REQUIRE(N % 8 == 0, "rv_gemm_nt_dropout_bf16: N must be a multiple of 8 (mask layout of rv_dropout)");
+  RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_dropout_bf16: ldc/ldr must be multiples of 4");
+  EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
+  epi.drop_thresh16 = (uint32_t)((double)p * 65536.0 + 0.5);
+  epi.drop_key = (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu;
+  epi.drop_inv_keep = 1.f / (1.f - p);
+  return dispatch(g, epi, -1, stream);
+}
+
 int rv_gemm_tn_bf16_splitk(const void* P, long ldp, const void* Q, long ldq, void* C, long ldc, int R, int I, int J,
                            float alpha, int splits, float* workspace, void* stream) {
   if (I == 0 || J == 0) return 0;

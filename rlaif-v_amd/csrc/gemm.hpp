@@ -655,12 +655,21 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
 enum { RV_ACT_NONE = 0, RV_ACT_QUICK_GELU = 1, RV_ACT_GELU = 2 };
 
 // C[m][n] = act(acc + bias[n]) + R[m][n]   (bf16 out; bias/R optional)
+__device__ __forceinline__ uint32_t gemm_mix32(uint32_t h) {    // same mixer as dropout_kernel (elementwise.hip)
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+
 struct EpiStore {
   bf16_t* C; long ldc;
   const bf16_t* bias;
   const bf16_t* R; long ldr;
   int act;
   float alpha;
+  // optional dropout of the GEMM result BEFORE the residual is added (rv_gemm_nt_dropout_bf16): the mask of
+  // rv_dropout for a contiguous [M][N] tensor with the same (p, seed); drop_thresh16 = 0 disables it
+  uint32_t drop_thresh16 = 0, drop_key = 0;
+  float drop_inv_keep = 1.f;
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -686,6 +695,15 @@ struct EpiStore {
           } else if (act == RV_ACT_GELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+          }
+          if (drop_thresh16) {
+            const long e = (long)m * N + n;                               // element index in the logical [M][N] tensor
+            const uint32_t base = (uint32_t)(e >> 33) * 0x9e3779b9u + drop_key;
+            const uint32_t h0 = gemm_mix32((uint32_t)(e >> 1) ^ base), h1 = gemm_mix32(((uint32_t)(e >> 1) + 1u) ^ base);
+            v[0] = ((h0 & 0xffffu) >= drop_thresh16) ? v[0] * drop_inv_keep : 0.f;
+            v[1] = ((h0 >> 16) >= drop_thresh16) ? v[1] * drop_inv_keep : 0.f;
+            v[2] = ((h1 & 0xffffu) >= drop_thresh16) ? v[2] * drop_inv_keep : 0.f;
+            v[3] = ((h1 >> 16) >= drop_thresh16) ? v[3] * drop_inv_keep : 0.f;
           }
           if (R) {
             const uint2 rr = *(const uint2*)(R + (long)m * ldr + n);

@@ -291,6 +291,8 @@ class LlavaDPOModel:
         self.lora = lora
         self.store = ParamStore(cfg, self.device, with_optimizer, lora)
         self._dropout_step = 0          # advances once per forward: seeds the LoRA dropout masks
+        # keep the dropped adapter inputs for backward (+1.3 GB per layer at 27 k tokens) instead of regenerating them
+        self.keep_dropped_inputs = os.environ.get("RV_LORA_KEEP_DROPPED", "1") != "0"
         self.clip: Dict[str, torch.Tensor] = {}
         self.training = True
         self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -518,13 +520,13 @@ class LlavaDPOModel:
         gc = self._GROUP_COLS[grp]
         y = ops.gemm_nt_lora(x, W, t, st.p(f"layers.{i}.lora_{grp}.B"), group_cols=getattr(self.cfg, gc) if gc else 0,
                              residual=residual)
-        return y, t, xd
+        return y, t, (xd if self.keep_dropped_inputs else None)
 
     def _dropout_seed(self, layer: int, slot: int) -> int:
         return (self._cur_drop_step * 1000003 + layer * 8 + slot) & 0x7FFFFFFF
 
     def _proj_bwd(self, dy: torch.Tensor, xin: torch.Tensor, t: Optional[torch.Tensor], i: int, grp: str,
-                  drop_slot: int = 0) -> torch.Tensor:
+                  drop_slot: int = 0, xd: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Input gradient of _proj_fwd; writes the weight gradients that exist (full fine-tune: dW = dy^T x by the TN
         GEMM; LoRA: dA = dt^T x_d, dB = dy^T t by the split-K TN GEMM, base weight frozen)."""
         st = self.store
@@ -544,9 +546,10 @@ class LlavaDPOModel:
         if self.training and self.lora.lora_dropout > 0.0:
             # dropout sits on the adapter branch only: dx = dy W + mask * (dt A) / (1 - p)
             dx = ops.gemm_nt(dy, st.pT(wkey))
-            dxa = ops.gemm_nt(dt, st.pT(akey))
-            ops.dropout(dxa, self.lora.lora_dropout, self._dropout_seed(i, drop_slot), out=None, accumulate_into=dx)
-            xin = ops.dropout(xin, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
+            ops.gemm_nt_dropout(dt, st.pT(akey), self.lora.lora_dropout, self._dropout_seed(i, drop_slot), out=dx,
+                                residual=dx)
+            # the dropped adapter input: kept from forward (288 GB HBM) or regenerated from the seed
+            xin = xd if xd is not None else ops.dropout(xin, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
         else:
             dx = ops.gemm_nt_lora(dy, st.pT(wkey), dt, st.pT(akey), group_cols=0)
         ops.gemm_tn_skinny(dt, xin, out=st.g(akey))
@@ -595,17 +598,18 @@ class LlavaDPOModel:
         layers_ctx = []
         for i in range(cfg.layers):
             xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
-            qkv, t_qkv, _ = self._proj_fwd(xn, i, "qkv", drop_slot=0)
+            qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0)
             ops.rope_inplace(qkv, cos, sin, L, 2 * H, hd, pos=plan.pos)
             attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
-            x_mid, t_o, _ = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
+            x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
             xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
-            gu, t_gu, _ = self._proj_fwd(xn2, i, "gu", drop_slot=2)
+            gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2)
             act = ops.swiglu_fwd(gu)
-            x_next, t_down, _ = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3)
+            x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3)
             if save_for_backward:
                 layers_ctx.append(dict(x=x, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, gu=gu,
-                                       t_qkv=t_qkv, t_o=t_o, t_gu=t_gu, t_down=t_down))
+                                       t_qkv=t_qkv, t_o=t_o, t_gu=t_gu, t_down=t_down,
+                                       xd_qkv=xd_qkv, xd_o=xd_o, xd_gu=xd_gu, xd_down=xd_down))
             x = x_next
         n_sel = plan.n_sel
         n_pad = max(64, ops.round_up(n_sel, 64))
@@ -668,22 +672,22 @@ class LlavaDPOModel:
         for i in reversed(range(cfg.layers)):
             c = ctx["layers"][i]
             act = ops.swiglu_fwd(c["gu"])
-            dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3)
+            dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3, xd=c["xd_down"])
             del act
             dgu = ops.swiglu_bwd(dact, c["gu"])
             del dact
             xn2, _ = ops.rmsnorm_fwd(c["x_mid"], st.p(f"layers.{i}.ln2"), cfg.rms_eps, want_rstd=False)
-            dxn2 = self._proj_bwd(dgu, xn2, c["t_gu"], i, "gu", drop_slot=2)
+            dxn2 = self._proj_bwd(dgu, xn2, c["t_gu"], i, "gu", drop_slot=2, xd=c["xd_gu"])
             del dgu, xn2
             dx_mid = ops.rmsnorm_bwd(dxn2, c["x_mid"], st.p(f"layers.{i}.ln2"), c["rstd2"], gain_grad(f"layers.{i}.ln2"),
                                      dres=dx)
             del dxn2
-            dattn = self._proj_bwd(dx_mid, c["attn"], c["t_o"], i, "o", drop_slot=1)
+            dattn = self._proj_bwd(dx_mid, c["attn"], c["t_o"], i, "o", drop_slot=1, xd=c["xd_o"])
             dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
             del dattn
             ops.rope_inplace(dqkv, cos, sin, L, 2 * H, hd, backward=True, pos=plan.pos)
             xn, _ = ops.rmsnorm_fwd(c["x"], st.p(f"layers.{i}.ln1"), cfg.rms_eps, want_rstd=False)
-            dxn = self._proj_bwd(dqkv, xn, c["t_qkv"], i, "qkv", drop_slot=0)
+            dxn = self._proj_bwd(dqkv, xn, c["t_qkv"], i, "qkv", drop_slot=0, xd=c["xd_qkv"])
             del dqkv, xn
             dx = ops.rmsnorm_bwd(dxn, c["x"], st.p(f"layers.{i}.ln1"), c["rstd1"], gain_grad(f"layers.{i}.ln1"),
                                  dres=dx_mid)

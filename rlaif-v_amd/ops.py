@@ -83,6 +83,20 @@ def gemm_nt_lora(a: torch.Tensor, b: torch.Tensor, a2: torch.Tensor, b2: torch.T
     return out
 
 
+def gemm_nt_dropout(a: torch.Tensor, b: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None,
+                    residual: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """out = dropout(alpha * a @ b^T; p, seed) + residual, the mask being the one ``dropout`` draws for an [M, N] tensor."""
+    _chk2d(a, "a"), _chk2d(b, "b")
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    hip.call("rv_gemm_nt_dropout_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, K, residual,
+             residual.stride(0) if residual is not None else 0, float(alpha), float(p), int(seed) & 0x7FFFFFFF)
+    return out
+
+
 _SPLITK_WS = {}
 
 

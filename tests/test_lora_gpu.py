@@ -189,6 +189,26 @@ def test_dropout_kernel_statistics():
     assert torch.equal(ops.dropout(x, 0.0, seed=1), x)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 64), (26000, 4096, 192)])
+def test_gemm_nt_dropout_epilogue(M, N, K):
+    """dx += mask * (dt A) / (1 - p) fused into the GEMM epilogue: the mask must be rv_dropout's, element for element."""
+    _need_gpu()
+    from rlaif_v_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    a = torch.randn(M, K, device="cuda:0", generator=g).to(torch.bfloat16)
+    b = torch.randn(N, K, device="cuda:0", generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device="cuda:0", generator=g).to(torch.bfloat16)
+    p, seed = 0.3, 12345
+    mask = ops.dropout(torch.ones(M, N, dtype=torch.bfloat16, device="cuda:0"), p, seed) != 0
+    got = ops.gemm_nt_dropout(a, b, p, seed, alpha=0.5)
+    ref = 0.5 * (a.float() @ b.float().t()) * mask / (1 - p)
+    # (exact-zero dot products exist among 1e8 outputs; take them from the plain kernel, whose accumulation order is the same)
+    assert torch.equal(got != 0, mask & (ops.gemm_nt(a, b, alpha=0.5) != 0))
+    assert (got.float() - ref).abs().max() <= 1.6e-2 * ref.abs().max()
+    got2 = ops.gemm_nt_dropout(a, b, p, seed, alpha=0.5, residual=res, out=res.clone())
+    assert (got2.float() - (ref + res.float())).abs().max() <= 1.6e-2 * (ref + res.float()).abs().max()
+
+
 def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch):
     """lora_dropout > 0: replay the device masks (regenerated from the model's seeds) inside the oracle."""
     _need_gpu()
