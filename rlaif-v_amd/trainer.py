@@ -70,6 +70,20 @@ class TrainingArguments:
         return LoraConfig(r=self.lora_r, lora_alpha=self.lora_alpha, lora_dropout=self.lora_dropout, bias=self.lora_bias)
 
 
+def compute_weighted_logp(per_token_logp: torch.Tensor, labels: torch.Tensor, token_weight: torch.Tensor,
+                          use_average: bool) -> torch.Tensor:
+    """trainers.py:128-137 on the device: sum_t logp[s,t] * w[s,t] * (labels[s,t+1] != -100), optionally divided by the
+    weighted token count.  (get_beta_and_logps raises for dpo_token_weighted with LLaVA-1.5, exactly like the reference,
+    trainers.py:246-248 - its token weights are text-length, the log-probs spliced-length; this is the arithmetic the
+    OmniLMM / MiniCPM branches use.)"""
+    dev = per_token_logp.device
+    S, Lm1 = per_token_logp.shape
+    w = (token_weight.to(dev, torch.float32) * (labels[:, 1:].to(dev) != -100)).contiguous().view(-1)
+    off = (torch.arange(S + 1, dtype=torch.int32) * Lm1).to(dev)
+    s, c = ops.seq_sum(per_token_logp.to(torch.float32).contiguous().view(-1), off, S, weight=w)
+    return s / c if use_average else s
+
+
 def cosine_lr(step: int, total: int, base_lr: float, warmup_ratio: float) -> float:
     """transformers.get_cosine_schedule_with_warmup; ``step`` = optimizer steps already taken."""
     warm = math.ceil(total * warmup_ratio)

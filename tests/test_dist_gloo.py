@@ -20,28 +20,30 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, lora=False):
     sys.path.insert(0, REPO)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from oracle import dpo_oracle as O
     from rlaif_v_amd.dist import BucketedAllReduce, init_process_group_from_env
-    from rlaif_v_amd.model import LlavaConfig, ParamStore
+    from rlaif_v_amd.model import LlavaConfig, LoraConfig, ParamStore
     from rlaif_v_amd.trainer import LLaVA15DPOTrainer
     r, _, w = init_process_group_from_env("gloo")
     assert (r, w) == (rank, world)
-    st = ParamStore(LlavaConfig(**O.asdict(O.tiny_cfg())), "cpu")
+    # full fine-tune: the whole model is reduced; LoRA: only adapters + projector (frozen base has no gradient slot)
+    st = ParamStore(LlavaConfig(**O.asdict(O.tiny_cfg())), "cpu", lora=LoraConfig(r=16) if lora else None)
+    assert (st.n_train < st.n_total) == lora
     g = torch.Generator().manual_seed(100 + rank)
-    local = torch.randn(st.n_total, generator=g)
+    local = torch.randn(st.n_train, generator=g)
     st.flat_g = local.clone()          # fp32 on CPU (gloo); the GPU path reduces the bf16 buffer with RCCL
     red = BucketedAllReduce(st.flat_g, bucket_bytes=1 << 20)      # 1 MiB buckets -> several merges
     for name, a, b in st.bucket_schedule():
         red.on_bucket_ready(name, a, b)
     launched = red.finish()
     # every element reduced exactly once, collectives are contiguous and in schedule order
-    assert launched[0][0] == 0 and launched[-1][1] == st.n_total
+    assert launched[0][0] == 0 and launched[-1][1] == st.n_train
     assert all(launched[i][1] == launched[i + 1][0] for i in range(len(launched) - 1))
-    others = [torch.randn(st.n_total, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
+    others = [torch.randn(st.n_train, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
     expect = sum(others)
     ok_sum = torch.allclose(st.flat_g, expect, rtol=1e-6, atol=1e-6)
     m = red.reduce_metrics(torch.tensor([float(rank), 1.0, -2.0 * rank]))
@@ -70,12 +72,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_bucketed_allreduce_gloo_world2():
+@pytest.mark.parametrize("lora", [False, True])
+def test_bucketed_allreduce_gloo_world2(lora):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, lora)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]

@@ -196,6 +196,38 @@ def test_param_store_layout_and_schedules():
     assert n == 6_759_272_448 or n > 6.7e9
 
 
+def test_param_store_lora_layout():
+    """LoRA mode: frozen base in front, adapters (backward-completion order) + projector trainable; gradient buckets
+    tile flat_g exactly; peft tensor names map to (padded) slices of the fused q|k|v / gate|up adapter stacks."""
+    from rlaif_v_amd.model import LlavaConfig, LoraConfig, ParamStore
+    cfg = LlavaConfig(**O.asdict(O.tiny_cfg()))
+    st = ParamStore(cfg, "cpu", lora=LoraConfig(r=16, lora_alpha=32))
+    assert st.lora.scaling == 2.0 and st.lora.r_pad == 64
+    sch = st.bucket_schedule()
+    assert sch[0][1] == 0 and sch[-1][2] == st.n_train == st.flat_g.numel()
+    assert all(sch[i][2] == sch[i + 1][1] for i in range(len(sch) - 1))
+    assert [n for n, _, _ in sch][:2] == [f"layer{cfg.layers - 1}", f"layer{cfg.layers - 2}"]
+    with pytest.raises(KeyError):
+        st.g("layers.0.wqkv")                                # frozen: no gradient slot
+    assert st.g("layers.0.lora_qkv.A").shape == (3 * 64, cfg.hidden)
+    assert st.train_p.data_ptr() == st.flat_p[st.t0:].data_ptr()
+    W = O.make_lora_weights(O.tiny_cfg(), 16)
+    sl = st.lora_slices(cfg)
+    assert set(sl) == set(W)
+    for name, (key, r0, n, ncol) in sl.items():
+        assert tuple(st.p(key)[r0:r0 + n, :ncol].shape) == tuple(W[name].shape), name
+        assert key in st.trainable and key in st.t_offsets
+    # trainable set == what the reference's LoRA run trains (adapters + mm_projector)
+    full = dict(O.make_weights(O.tiny_cfg(), seed=0))
+    full.update(W)
+    ref_names = {n for n in O.lora_trainable_names(full)}
+    ours = set(sl) | {k for k in st.trainable if "mm_projector" in k}
+    assert ours == ref_names
+    # 7B: rank-64 adapters on all seven projections = 159.9 M parameters (+ 21 M projector)
+    d, f, r = 4096, 11008, 64
+    assert 32 * r * (4 * 2 * d + 3 * (d + f)) == 159_907_840
+
+
 def test_checkpoint_roundtrip_hf_layout(tmp_path):
     from rlaif_v_amd.checkpoint import (config_from_hf, hf_config_dict, load_state_dict_dir, save_state_dict_sharded)
     from rlaif_v_amd.model import LlavaConfig

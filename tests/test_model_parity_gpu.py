@@ -243,3 +243,21 @@ def test_checkpoint_save_load_resume(tmp_path):
     l2 = tr2.training_step(dict(batch))
     assert float(l1) == float(l2) and torch.equal(model.store.flat_master, m2.store.flat_master)
     assert tr2.state["global_step"] == 2
+
+
+def test_compute_weighted_logp_matches_oracle():
+    """Row a8: token-weighted log-prob reduction (trainers.py:128-137), incl. a row without targets (0/0 -> NaN)."""
+    _need_gpu()
+    from rlaif_v_amd.trainer import compute_weighted_logp
+    g = torch.Generator().manual_seed(0)
+    S, L = 5, 37
+    logp = -torch.rand(S, L - 1, generator=g) * 5
+    labels = torch.randint(3, 100, (S, L), generator=g)
+    labels[:, :9] = -100
+    labels[2, 20:] = -100
+    labels[4] = -100
+    w = torch.where(torch.rand(S, L - 1, generator=g) < 0.3, torch.tensor(2.5), torch.tensor(1.0))
+    for avg in (False, True):
+        ref = O.compute_weighted_logp(logp, labels, w, avg)
+        got = compute_weighted_logp(logp.cuda(), labels, w, avg).cpu()
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5, equal_nan=True)
