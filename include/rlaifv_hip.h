@@ -137,6 +137,18 @@ int rv_gelu_bwd(const void* dy, const void* x, void* dx, long n, void* stream);
  * y = dropped x (may alias x, may be NULL); acc (optional) += dropped x (gradient accumulation).  Contiguous, n % 8 == 0. */
 int rv_dropout(const void* x, void* y, void* acc, long n, float p, int seed, void* stream);
 
+/* ---- CLIP image preprocessing: CLIPImageProcessor of openai/clip-vit-large-patch14-336 as the reference applies it in
+ * its DataLoader workers (muffin/train/train_llava15.py:244, muffin/train/train_utils.py:208) - PIL BICUBIC resize
+ * (Pillow Resample.c: 22-bit fixed-point taps, uint8 after each pass), center crop, x 1/255, (x - mean) / std.
+ * Two passes over the CROPPED window only; tap tables (bounds [n][2] = first source index, tap count; kk [n][ksize])
+ * are built on the host exactly as Pillow's precompute_coeffs does.
+ *   rv_resize_h_u8      : tmp[r][x][c] (uint8, rows x out_w x 3) from src [H][W][3] rows y0 .. y0+rows-1
+ *   rv_resize_v_norm_u8 : out[c][y][x] (float32, 3 x out_h x out_w) = table[c][vertical pass], table = [3][256] */
+int rv_resize_h_u8(const void* src, int H, int W, int y0, int rows, const int* bounds, const int* kk, int ksize, int out_w,
+                   void* tmp, void* stream);
+int rv_resize_v_norm_u8(const void* tmp, int rows, int out_w, const int* bounds, const int* kk, int ksize, int out_h,
+                        const float* table, float* out, void* stream);
+
 /* ---- data movement */
 int rv_transpose(const void* in, long ld_in, void* out, long ldo, int R, int C, void* stream);
 /* prepare_inputs_labels_for_multimodal (llava/model/llava_arch.py:237-315): out row n = embed[src[n]] if

@@ -279,6 +279,47 @@ __global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ CLIP image preprocessing (PIL BICUBIC resize + normalise)
+// Pillow's ImagingResampleHorizontal_8bpc / Vertical_8bpc: 22-bit fixed-point taps, accumulator seeded with 1 << 21,
+// clip8(acc >> 22) after EACH pass.  Tap tables come from the host (rlaif-v_amd/image.py); only the cropped window is made.
+__device__ __forceinline__ int clip8_fixed(int acc) {
+  const int v = acc >> 22;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+// tmp[r][x][c] = clip8(sum_t src[y0 + r][x0(x) + t][c] * kk[x][t]),  r < rows, x < out_w, c < 3
+__global__ void resize_h_u8_kernel(const uint8_t* __restrict__ src, int W, int y0, int rows, const int* __restrict__ bounds,
+                                   const int* __restrict__ kk, int ksize, int out_w, uint8_t* __restrict__ tmp) {
+  const long n = (long)rows * out_w * 3;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % 3);
+    const int x = (int)((e / 3) % out_w);
+    const int r = (int)(e / (3L * out_w));
+    const int x0 = bounds[2 * x], nt = bounds[2 * x + 1];
+    const uint8_t* row = src + ((long)(y0 + r) * W + x0) * 3 + c;
+    const int* k = kk + (long)x * ksize;
+    int acc = 1 << 21;
+    for (int t = 0; t < nt; ++t) acc += (int)row[3 * t] * k[t];
+    tmp[e] = (uint8_t)clip8_fixed(acc);
+  }
+}
+// out[c][y][x] = table[c][clip8(sum_t tmp[r0(y) + t][x][c] * kk[y][t])]   (CHW float32: rescale + normalise via table)
+__global__ void resize_v_norm_u8_kernel(const uint8_t* __restrict__ tmp, int out_w, const int* __restrict__ bounds,
+                                        const int* __restrict__ kk, int ksize, int out_h, const float* __restrict__ table,
+                                        float* __restrict__ out) {
+  const long n = 3L * out_h * out_w;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(e % out_w);
+    const int y = (int)((e / out_w) % out_h);
+    const int c = (int)(e / ((long)out_w * out_h));
+    const int r0 = bounds[2 * y], nt = bounds[2 * y + 1];
+    const uint8_t* col = tmp + ((long)r0 * out_w + x) * 3 + c;
+    const int* k = kk + (long)y * ksize;
+    int acc = 1 << 21;
+    for (int t = 0; t < nt; ++t) acc += (int)col[(long)t * out_w * 3] * k[t];
+    out[e] = table[c * 256 + clip8_fixed(acc)];
+  }
+}
+
 // ------------------------------------------------------------------ GELU(erf) for the projector
 __global__ void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -751,6 +792,25 @@ int rv_dropout(const void* x, void* y, void* acc, long n, float p, int seed, voi
   const uint32_t thresh = (uint32_t)((double)p * 65536.0 + 0.5);        // 16 random bits per element
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, STREAM(stream), (const bf16_t*)x,
                      (bf16_t*)y, (bf16_t*)acc, n / 8, thresh, 1.f / (1.f - p), (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_resize_h_u8(const void* src, int H, int W, int y0, int rows, const int* bounds, const int* kk, int ksize, int out_w,
+                   void* tmp, void* stream) {
+  RV_REQUIRE(H > 0 && W > 0 && rows > 0 && y0 >= 0 && y0 + rows <= H && ksize > 0 && out_w > 0, "rv_resize_h_u8: bad sizes");
+  const long n = (long)rows * out_w * 3;
+  hipLaunchKernelGGL(resize_h_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM(stream), (const uint8_t*)src, W, y0,
+                     rows, bounds, kk, ksize, out_w, (uint8_t*)tmp);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+int rv_resize_v_norm_u8(const void* tmp, int rows, int out_w, const int* bounds, const int* kk, int ksize, int out_h,
+                        const float* table, float* out, void* stream) {
+  RV_REQUIRE(rows > 0 && out_w > 0 && out_h > 0 && ksize > 0, "rv_resize_v_norm_u8: bad sizes");
+  const long n = 3L * out_h * out_w;
+  hipLaunchKernelGGL(resize_v_norm_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM(stream), (const uint8_t*)tmp,
+                     out_w, bounds, kk, ksize, out_h, table, out);
   RV_CHECK_LAUNCH();
   return 0;
 }

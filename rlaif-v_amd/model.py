@@ -472,6 +472,10 @@ class LlavaDPOModel:
     def clip_features(self, pixels: torch.Tensor) -> torch.Tensor:
         """CLIPVisionTower.forward + feature_select('patch') (clip_encoder.py:36-58): [B*P, clip_hidden]."""
         cfg, c = self.cfg, self.clip
+        if isinstance(pixels, (list, tuple)) or pixels.dtype == torch.uint8:
+            # raw decoded images (uint8 HWC, any sizes): CLIPImageProcessor's resize / crop / normalise on the device
+            from .image import clip_preprocess_batch
+            pixels = clip_preprocess_batch(pixels, size=cfg.image_size, device=self.device)
         B = pixels.shape[0]
         P, T, cd, H, hd = cfg.n_patches, cfg.n_patches + 1, cfg.clip_hidden, cfg.clip_heads, cfg.clip_head_dim
         px = pixels.to(self.device, dtype=torch.float32).contiguous()
@@ -568,7 +572,7 @@ class LlavaDPOModel:
         the reference stores in its ``logps`` parquet column."""
         cfg, st = self.cfg, self.store
         d, H, hd, f = cfg.hidden, cfg.heads, cfg.head_dim, cfg.ffn
-        B = images.shape[0]
+        B = len(images)                  # tensor [B, 3, H, W] or a list of raw uint8 [H, W, 3] images
         ctx: dict = {}
         w_rows = None
         self._dropout_step += 1
@@ -720,7 +724,7 @@ class LlavaDPOModel:
         if attention_mask is not None:
             raise NotImplementedError("the DPO path passes attention_mask=None (trainers.py:199)")
         feats = self.encode_images(images)      # one feature block per row of `images`, like the reference
-        n_img = images.shape[0]
+        n_img = len(images)
         plan = build_splice_plan(input_ids, labels, self.cfg.n_patches, n_img, self.cfg.model_max_length).to(self.device)
         emb = ops.splice_fwd(plan.src, self.store.p("model.embed_tokens.weight"), feats, self.cfg.hidden)
         return None, None, None, past_key_values, emb.view(plan.S, plan.L, -1), plan.labels.to(self.device)

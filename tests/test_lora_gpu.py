@@ -66,6 +66,7 @@ def test_lora_forward_backward_vs_oracle(monkeypatch, r, share_prefix):
     out = model.last_out
     model.backward(out, model.last_coef)
     ref, grads = _oracle_grads(batch, W, cfg, 16 / r)
+    ref = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ref.items()}
     mask = ref["labels"][:, 1:] != -100
     err_tok = (out.per_token_logp.cpu() - ref["per_token_logps"].detach()[mask]).abs().max().item()
     err_lp = (out.seq_logp.cpu() - ref["log_prob"].detach()).abs()
@@ -235,6 +236,7 @@ def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch):
                 masks[f"model.layers.{i}.{mod}"] = (m != 0).float().cpu() / (1 - p)
     model.backward(out, model.last_coef)
     ref, grads = _oracle_grads(batch, W, cfg, 16 / 64, masks)
+    ref = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ref.items()}
     assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])) + 7e-3
     assert bool(((out.seq_logp.cpu() - ref["log_prob"].detach()).abs() <= 1e-3 * ref["log_prob"].abs() + 5e-2).all())
     got = model.grads_state_dict()
