@@ -233,6 +233,7 @@ def main():
                        "trainable_params": int(model.store.n_train),
                        "gradient_checkpointing": False, "shared_prefix_reuse": bool(model.share_prefix)},
             "loss": float(loss), "max_memory_allocated_gb": torch.cuda.max_memory_allocated() / 2**30,
+            "max_memory_reserved_gb": torch.cuda.max_memory_reserved() / 2**30,
             "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / PEAK_BF16_TFLOPS,
             "flops_per_pair": fp, "flops_per_pair_reference_layout": fp_nominal,
             "shared_prefix_tokens_per_pair": sum(shared) / max(len(shared), 1),

@@ -11,6 +11,8 @@
 // STAGE=1 fills that image with global_load_lds (LDS destination lane-linear, swizzle applied on the
 // per-lane SOURCE address); STAGE=0 stages through registers (global_load_dwordx4 + ds_write_b128).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 #define GEMM_BM 128
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
       for (int t = 0; t < 4; ++t) af[ks][t] = *(const bf16x8_t*)(st + a_off[ks] + t * 2048);
     }
     if (!DMA_IN_MSEG && p + 2 < nt && ABLATE != 1) issue(p + 2);
-    if (SPLIT) {
+    if (SPLIT == 1) {
       if (p + DIST < nt) {
         issue_piece(p + DIST, 0);
         issue_piece(p + DIST, 1);
@@ -334,27 +336,35 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     const bool dma = DMA_IN_MSEG && (p + DIST < nt) && ABLATE != 1;
+    // SLOT = the MFMA slot (mod 4) after which this wave issues one LDS-DMA piece (compile-time: a scalar branch
+    // between MFMAs costs ~9 %, and four slot-specialised copies of the segment made hipcc spill the accumulators).
+    auto mseg = [&](auto slot_c) {
+      constexpr int SLOT = decltype(slot_c)::value;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int k = (ks * 4 + tm) * 2 + tn;
-          if (DMA_IN_MSEG && !SPLIT && (k & 3) == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (dma) issue_piece(p + DIST, k >> 2);
-            __builtin_amdgcn_sched_barrier(0);
+          for (int tn = 0; tn < 2; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
+            const int k = (ks * 4 + tm) * 2 + tn;
+            if (DMA_IN_MSEG && SPLIT != 1 && (k & 3) == SLOT) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (dma) issue_piece(p + DIST, k >> 2);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (DMA_IN_MSEG && SPLIT == 1 && (k & 7) == 3) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (dma) issue_piece(p + DIST, 2 + (k >> 3));
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
-          if (DMA_IN_MSEG && SPLIT && (k & 7) == 3) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (dma) issue_piece(p + DIST, 2 + (k >> 3));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+    };
+    if (SPLIT == 2) {   // experiment: skew the four SIMDs of a group in time (16 clk per SIMD index) instead of in code
+      for (int i = 0; i < wn; ++i) asm volatile("s_nop 15" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mseg(std::integral_constant<int, 1>{});
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();

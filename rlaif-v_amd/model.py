@@ -293,6 +293,9 @@ class LlavaDPOModel:
         self._dropout_step = 0          # advances once per forward: seeds the LoRA dropout masks
         # keep the dropped adapter inputs for backward (+1.3 GB per layer at 27 k tokens) instead of regenerating them
         self.keep_dropped_inputs = os.environ.get("RV_LORA_KEEP_DROPPED", "1") != "0"
+        # keep normalised inputs and SwiGLU outputs for backward instead of recomputing them (RV_KEEP_RECOMPUTABLE=0:
+        # the lean layout, 1.05 GB / layer less at 27 k tokens)
+        self.keep_recomputable = os.environ.get("RV_KEEP_RECOMPUTABLE", "1") != "0"
         self.clip: Dict[str, torch.Tensor] = {}
         self.training = True
         self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -613,7 +616,12 @@ class LlavaDPOModel:
             if save_for_backward:
                 layers_ctx.append(dict(x=x, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, gu=gu,
                                        t_qkv=t_qkv, t_o=t_o, t_gu=t_gu, t_down=t_down,
-                                       xd_qkv=xd_qkv, xd_o=xd_o, xd_gu=xd_gu, xd_down=xd_down))
+                                       xd_qkv=xd_qkv, xd_o=xd_o, xd_gu=xd_gu, xd_down=xd_down,
+                                       # 288 GB of HBM: keep the cheap-to-recompute operands too (+1.05 GB / layer at 27 k
+                                       # tokens) instead of re-running RMSNorm / SwiGLU in backward
+                                       xn=xn if self.keep_recomputable else None,
+                                       xn2=xn2 if self.keep_recomputable else None,
+                                       act=act if self.keep_recomputable else None))
             x = x_next
         n_sel = plan.n_sel
         n_pad = max(64, ops.round_up(n_sel, 64))
@@ -675,12 +683,15 @@ class LlavaDPOModel:
         # ---- decoder layers, last to first
         for i in reversed(range(cfg.layers)):
             c = ctx["layers"][i]
-            act = ops.swiglu_fwd(c["gu"])
+            act = c["act"] if c["act"] is not None else ops.swiglu_fwd(c["gu"])
+            c["act"] = None
             dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3, xd=c["xd_down"])
             del act
             dgu = ops.swiglu_bwd(dact, c["gu"])
             del dact
-            xn2, _ = ops.rmsnorm_fwd(c["x_mid"], st.p(f"layers.{i}.ln2"), cfg.rms_eps, want_rstd=False)
+            xn2 = c["xn2"] if c["xn2"] is not None else \
+                ops.rmsnorm_fwd(c["x_mid"], st.p(f"layers.{i}.ln2"), cfg.rms_eps, want_rstd=False)[0]
+            c["xn2"] = None
             dxn2 = self._proj_bwd(dgu, xn2, c["t_gu"], i, "gu", drop_slot=2, xd=c["xd_gu"])
             del dgu, xn2
             dx_mid = ops.rmsnorm_bwd(dxn2, c["x_mid"], st.p(f"layers.{i}.ln2"), c["rstd2"], gain_grad(f"layers.{i}.ln2"),
@@ -690,7 +701,9 @@ class LlavaDPOModel:
             dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
             del dattn
             ops.rope_inplace(dqkv, cos, sin, L, 2 * H, hd, backward=True, pos=plan.pos)
-            xn, _ = ops.rmsnorm_fwd(c["x"], st.p(f"layers.{i}.ln1"), cfg.rms_eps, want_rstd=False)
+            xn = c["xn"] if c["xn"] is not None else \
+                ops.rmsnorm_fwd(c["x"], st.p(f"layers.{i}.ln1"), cfg.rms_eps, want_rstd=False)[0]
+            c["xn"] = None
             dxn = self._proj_bwd(dqkv, xn, c["t_qkv"], i, "qkv", drop_slot=0, xd=c["xd_qkv"])
             del dqkv, xn
             dx = ops.rmsnorm_bwd(dxn, c["x"], st.p(f"layers.{i}.ln1"), c["rstd1"], gain_grad(f"layers.{i}.ln1"),
