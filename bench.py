@@ -151,6 +151,7 @@ def main():
                     help="LoRA-DPO workload (BASELINE.json configs[4]: rank 64 adapters on all decoder projections, "
                          "frozen base; use with --seq-len 4096).  Not the headline line.")
     ap.add_argument("--lora-r", type=int, default=64)
+    ap.add_argument("--gradient-checkpointing", action="store_true", help="re-run each decoder layer in backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-timer", action="store_true")
     args = ap.parse_args()
@@ -174,7 +175,8 @@ def main():
     model.init_random(seed=0)            # identical weights on every rank
     reducer = BucketedAllReduce(model.store.flat_g) if world > 1 else None
     targs = TrainingArguments(max_steps=1000, per_device_train_batch_size=B, lora_enable=args.lora,
-                              lora_r=args.lora_r, learning_rate=1e-5 if args.lora else 5e-7)
+                              lora_r=args.lora_r, learning_rate=1e-5 if args.lora else 5e-7,
+                              gradient_checkpointing=args.gradient_checkpointing)
     trainer = LLaVA15DPOTrainer(model=model, args=targs, reducer=reducer)
 
     class _Tok:
@@ -231,7 +233,7 @@ def main():
                        "pairs_per_gpu": B, "global_batch_pairs": B * world, "seq_len": L, "llm_layers": args.layers,
                        "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0",
                        "trainable_params": int(model.store.n_train),
-                       "gradient_checkpointing": False, "shared_prefix_reuse": bool(model.share_prefix)},
+                       "gradient_checkpointing": bool(args.gradient_checkpointing), "shared_prefix_reuse": bool(model.share_prefix)},
             "loss": float(loss), "max_memory_allocated_gb": torch.cuda.max_memory_allocated() / 2**30,
             "max_memory_reserved_gb": torch.cuda.max_memory_reserved() / 2**30,
             "step_tflops_per_gpu": step_tflops_per_gpu, "step_mfma_frac": step_tflops_per_gpu / PEAK_BF16_TFLOPS,

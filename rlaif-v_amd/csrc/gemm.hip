@@ -150,7 +150,6 @@ static int dispatch(const GemmShape& g, const Epi& epi, int variant, void* strea
   if (variant == 101) return launch_gemm256<Epi, true, 1>(g, epi, (hipStream_t)stream);   // ablation: no DMA
   if (variant == 102) return launch_gemm256<Epi, true, 2>(g, epi, (hipStream_t)stream);   // ablation: stale ds_reads
   if (variant == 103) return launch_gemm256<Epi, true, 3>(g, epi, (hipStream_t)stream);   // ablation: L2-resident DMA
-  if (variant == 7) return launch_gemm256<Epi, true, 0, 3, 2>(g, epi, (hipStream_t)stream);   // DMA slots staggered by SIMD
   if (variant == 6) return launch_gemm256<Epi, true, 0, 3, 1>(g, epi, (hipStream_t)stream);
   if (variant == 5) return launch_gemm256x64<Epi>(g, epi, (hipStream_t)stream);
   if (variant == 4) return launch_gemm256<Epi, true, 0, 4>(g, epi, (hipStream_t)stream);
@@ -174,7 +173,7 @@ extern "C" {
 const char* rv_last_error(void) { return g_err; }
 
 int rv_set_gemm_variant(int variant) {
-  RV_REQUIRE(variant >= -1 && variant <= 7, "rv_set_gemm_variant: -1 (auto), 0..7");
+  RV_REQUIRE(variant >= -1 && variant <= 6, "rv_set_gemm_variant: -1 (auto), 0..6");
   g_default_variant = variant;
   return 0;
 }

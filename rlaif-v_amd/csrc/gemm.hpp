@@ -360,10 +360,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
             }
           }
     };
-    if (SPLIT == 2) {   // experiment: skew the four SIMDs of a group in time (16 clk per SIMD index) instead of in code
-      for (int i = 0; i < wn; ++i) asm volatile("s_nop 15" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    // (measured and dropped: staggering the four SIMDs' DMA slots - by a scalar branch per slot -9 %, by slot-specialised
+    //  copies of the segment -> accumulator spills, by a 16-clk time skew per SIMD -11 %: the closing barrier pays for it)
     mseg(std::integral_constant<int, 1>{});
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);

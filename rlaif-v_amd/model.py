@@ -296,6 +296,9 @@ class LlavaDPOModel:
         # keep normalised inputs and SwiGLU outputs for backward instead of recomputing them (RV_KEEP_RECOMPUTABLE=0:
         # the lean layout, 1.05 GB / layer less at 27 k tokens)
         self.keep_recomputable = os.environ.get("RV_KEEP_RECOMPUTABLE", "1") != "0"
+        # --gradient_checkpointing (script/train/llava15_train.sh:39): keep only each decoder layer's input and re-run the
+        # layer in backward.  Off by default: 288 GB holds 8 pairs x 2048 tokens without it.
+        self.gradient_checkpointing = False
         self.clip: Dict[str, torch.Tensor] = {}
         self.training = True
         self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -565,6 +568,31 @@ class LlavaDPOModel:
             ops.gemm_tn_skinny(dy[:, g * og:(g + 1) * og], t[:, g * rp:(g + 1) * rp], out=gB[g * og:(g + 1) * og])
         return dx
 
+    def _layer_fwd(self, i: int, x: torch.Tensor, plan: SplicePlan, cos, sin, save: bool):
+        """One decoder layer (HF LlamaDecoderLayer: RMSNorm, QKV, RoPE, causal attention, O + residual, RMSNorm, SwiGLU
+        + residual).  Returns (x_next, context for backward or None)."""
+        cfg, st = self.cfg, self.store
+        d, H, hd = cfg.hidden, cfg.heads, cfg.head_dim
+        S, L = plan.S, plan.L
+        xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
+        qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0)
+        ops.rope_inplace(qkv, cos, sin, L, 2 * H, hd, pos=plan.pos)
+        attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
+        x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
+        xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
+        gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2)
+        act = ops.swiglu_fwd(gu)
+        x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3)
+        if not save:
+            return x_next, None
+        keep = self.keep_recomputable
+        return x_next, dict(x=x, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, gu=gu,
+                            t_qkv=t_qkv, t_o=t_o, t_gu=t_gu, t_down=t_down,
+                            xd_qkv=xd_qkv, xd_o=xd_o, xd_gu=xd_gu, xd_down=xd_down,
+                            # 288 GB of HBM: keep the cheap-to-recompute operands too (+1.05 GB / layer at 27 k tokens)
+                            # instead of re-running RMSNorm / SwiGLU in backward
+                            xn=xn if keep else None, xn2=xn2 if keep else None, act=act if keep else None)
+
     # ------------------------------------------------------------------ forward
     def forward_logps(self, input_ids: torch.Tensor, labels: torch.Tensor, images: torch.Tensor,
                       save_for_backward: bool = True, all_rows: bool = False) -> StepOutput:
@@ -604,24 +632,9 @@ class LlavaDPOModel:
         cos, sin = self._rope(L)
         layers_ctx = []
         for i in range(cfg.layers):
-            xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
-            qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0)
-            ops.rope_inplace(qkv, cos, sin, L, 2 * H, hd, pos=plan.pos)
-            attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
-            x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
-            xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
-            gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2)
-            act = ops.swiglu_fwd(gu)
-            x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3)
+            x_next, lctx = self._layer_fwd(i, x, plan, cos, sin, save_for_backward and not self.gradient_checkpointing)
             if save_for_backward:
-                layers_ctx.append(dict(x=x, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, gu=gu,
-                                       t_qkv=t_qkv, t_o=t_o, t_gu=t_gu, t_down=t_down,
-                                       xd_qkv=xd_qkv, xd_o=xd_o, xd_gu=xd_gu, xd_down=xd_down,
-                                       # 288 GB of HBM: keep the cheap-to-recompute operands too (+1.05 GB / layer at 27 k
-                                       # tokens) instead of re-running RMSNorm / SwiGLU in backward
-                                       xn=xn if self.keep_recomputable else None,
-                                       xn2=xn2 if self.keep_recomputable else None,
-                                       act=act if self.keep_recomputable else None))
+                layers_ctx.append(lctx if lctx is not None else dict(x=x, recompute=True))
             x = x_next
         n_sel = plan.n_sel
         n_pad = max(64, ops.round_up(n_sel, 64))
@@ -683,6 +696,8 @@ class LlavaDPOModel:
         # ---- decoder layers, last to first
         for i in reversed(range(cfg.layers)):
             c = ctx["layers"][i]
+            if c.get("recompute"):      # --gradient_checkpointing: only the layer input was kept; run the layer again
+                _, c = self._layer_fwd(i, c["x"], plan, cos, sin, True)
             act = c["act"] if c["act"] is not None else ops.swiglu_fwd(c["gu"])
             c["act"] = None
             dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3, xd=c["xd_down"])

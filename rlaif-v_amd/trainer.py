@@ -53,6 +53,7 @@ class TrainingArguments:
     past_index: int = -1
     bf16: bool = True
     seed: int = 42
+    gradient_checkpointing: bool = False
     # LoRA flags of muffin/train/train_llava15_lora.py:111-116 (same names and defaults)
     fully_tune: bool = False
     lora_enable: bool = False
@@ -176,6 +177,8 @@ class LLaVA15DPOTrainer:
         self.reducer = reducer or GradReducer()
         self.model.grad_ready_hook = self.reducer.on_bucket_ready \
             if (self.reducer.world_size > 1 or getattr(self.reducer, "force", False)) else None
+        if self.args.gradient_checkpointing:
+            self.model.gradient_checkpointing = True
         self.state = dict(global_step=0, log_history=[])
         self._clip = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._pending_metrics: Optional[torch.Tensor] = None

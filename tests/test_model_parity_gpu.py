@@ -261,3 +261,20 @@ def test_compute_weighted_logp_matches_oracle():
         ref = O.compute_weighted_logp(logp, labels, w, avg)
         got = compute_weighted_logp(logp.cuda(), labels, w, avg).cpu()
         torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5, equal_nan=True)
+
+
+def test_gradient_checkpointing_is_bit_identical():
+    """K16: re-running each decoder layer in backward must reproduce the stored-activation gradients exactly."""
+    _need_gpu()
+    cfg = O.tiny_cfg()
+    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=8)
+    grads = []
+    for ckpt in (False, True):
+        model, _ = _build(O.asdict(cfg), seed=5)
+        tr = _trainer(model, gradient_checkpointing=ckpt)
+        assert model.gradient_checkpointing == ckpt
+        model.train()
+        tr.compute_loss(model, dict(batch))
+        model.backward(model.last_out, model.last_coef)
+        grads.append(model.store.flat_g.clone())
+    assert torch.equal(grads[0], grads[1])
