@@ -265,6 +265,20 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
 #pragma unroll
     for (int j = 0; j < 4; ++j) issue_piece(t, j);
   };
+  // steady-state form: per-lane source pointers that already point at the tile to fetch (advanced once per K tile),
+  // so a DMA issue between two MFMAs is "write M0, global_load_lds" and nothing else
+  const bf16_t* a_run[2] = {a_src[0] + DIST * G2_BK, a_src[1] + DIST * G2_BK};
+  const bf16_t* b_run[2] = {b_src[0] + DIST * G2_BK, b_src[1] + DIST * G2_BK};
+  auto issue_piece_run = [&](int t, int j) {
+    uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
+    const int i = j >> 1;
+    if ((j & 1) == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_run[i],
+                                       (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_run[i],
+                                       (__attribute__((address_space(3))) void*)(st + 16384 + piece0 + i * 1024), 16, 0, 0);
+  };
 
   // ---- fragment read offsets: row = base + t*32 + fr with base a multiple of 32 => swizzle depends on fr only
   const int fr = lane & 31, half = lane >> 5;
@@ -298,7 +312,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
-  for (int p = 0; p < nt; ++p) {
+  // One K tile.  STEADY (compile time) = this is not one of the last DIST tiles: the DMA of tile p+DIST is issued
+  // unconditionally and the counted wait is a constant - no scalar branch or select ends up between the MFMAs
+  // (the rolled-up form had one per DMA piece; hipcc materialised each `if (dma)` as s_cbranch + v_cndmask chains).
+  auto tile = [&](const int p, auto steady_c) {
+    constexpr bool STEADY = decltype(steady_c)::value;
     const uint8_t* st = smem + ((ABLATE == 2 ? 0 : p) % NST) * G2_STAGE_BYTES;
     bf16x8_t af[2][4], bfr[2][2];
 #pragma unroll
@@ -324,7 +342,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
       // tile p+DIST is only issued in the M segment that follows, so they are p+2 .. p+DIST-1; otherwise p+2.
       // (An earlier revision counted DIST-1 and thereby waited for tile p only - results then depended on the DMA
       // beating the consumer by three iterations, which a memory-bound launch mix can break.)
-      const int newer = (ABLATE == 1) ? 0 : min(DMA_IN_MSEG ? DIST - 2 : 1, nt - 2 - p);
+      const int newer = STEADY ? DIST - 2 : ((ABLATE == 1) ? 0 : min(DMA_IN_MSEG ? DIST - 2 : 1, nt - 2 - p));
       if (newer >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    const bool dma = DMA_IN_MSEG && (p + DIST < nt) && ABLATE != 1;
+    const bool dma = STEADY || (DMA_IN_MSEG && (p + DIST < nt) && ABLATE != 1);
     // SLOT = the MFMA slot (mod 4) after which this wave issues one LDS-DMA piece (compile-time: a scalar branch
     // between MFMAs costs ~9 %, and four slot-specialised copies of the segment made hipcc spill the accumulators).
     auto mseg = [&](auto slot_c) {
@@ -350,7 +368,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
             const int k = (ks * 4 + tm) * 2 + tn;
             if (DMA_IN_MSEG && SPLIT != 1 && (k & 3) == SLOT) {
               __builtin_amdgcn_sched_barrier(0);
-              if (dma) issue_piece(p + DIST, k >> 2);
+              if (STEADY && !EXT) issue_piece_run(p + DIST, k >> 2);
+              else if (dma) issue_piece(p + DIST, k >> 2);
               __builtin_amdgcn_sched_barrier(0);
             }
             if (DMA_IN_MSEG && SPLIT == 1 && (k & 7) == 3) {
@@ -367,6 +386,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    int p = 0;
+    if (DMA_IN_MSEG && SPLIT == 0 && ABLATE == 0)
+      for (; p + DIST < nt; ++p) {
+        tile(p, std::true_type{});
+        a_run[0] += G2_BK; a_run[1] += G2_BK; b_run[0] += G2_BK; b_run[1] += G2_BK;
+      }
+    for (; p < nt; ++p) tile(p, std::false_type{});
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count
 
@@ -603,7 +631,27 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   __builtin_amdgcn_s_barrier();
   if (wi == 1) __builtin_amdgcn_s_barrier();
 
-  for (int p = 0; p < nt; ++p) {
+  // STEADY tiles (all but the last DIST+1): the fetched tile p+DIST is neither past the end nor ragged, so its DMA
+  // needs no validity select and no branch, and uses pointers advanced once per tile (see gemm_nt_256_kernel)
+  const bf16_t* p_run[2];
+  const bf16_t* q_run[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    p_run[i] = P + ((long)DIST * 32 + p_row[i]) * ldp + src_col(p_row[i], i0, I);
+    q_run[i] = Q + ((long)DIST * 32 + p_row[i]) * ldq + src_col(p_row[i], j0, J);
+  }
+  auto issue_piece_run = [&](int t, int jj) {
+    uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
+    const int i = jj >> 1;
+    if ((jj & 1) == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p_run[i],
+                                       (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q_run[i],
+                                       (__attribute__((address_space(3))) void*)(st + 16384 + piece0 + i * 1024), 16, 0, 0);
+  };
+  auto tile = [&](const int p, auto steady_c) {
+    constexpr bool STEADY = decltype(steady_c)::value;
     const uint8_t* st = smem + (p % NST) * G2_STAGE_BYTES;
     bf16x8_t qf[2][2], pf[2][4];
     const uint32_t sta = lds_addr_of(st);
@@ -620,7 +668,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
       for (int ks = 0; ks < 2; ++ks) pf[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
     }
     {
-      const int newer = min(DIST - 2, nt - 2 - p);   // tiles p+2 .. p+DIST-1 (p+DIST is issued after this wait)
+      const int newer = STEADY ? DIST - 2 : min(DIST - 2, nt - 2 - p);   // tiles p+2 .. p+DIST-1 (p+DIST comes after this wait)
       if (newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -641,7 +689,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
           const int k = (ks * 4 + ti) * 2 + tj;
           if ((k & 3) == 1) {
             __builtin_amdgcn_sched_barrier(0);
-            if (dma) issue_piece(p + DIST, k >> 2);
+            if (STEADY) issue_piece_run(p + DIST, k >> 2);
+            else if (dma) issue_piece(p + DIST, k >> 2);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -649,6 +698,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    int p = 0;
+    for (; p + DIST < nt - 1; ++p) {
+      tile(p, std::true_type{});
+      p_run[0] += 32 * ldp; p_run[1] += 32 * ldp; q_run[0] += 32 * ldq; q_run[1] += 32 * ldq;
+    }
+    for (; p < nt; ++p) tile(p, std::false_type{});
   }
   if (wi == 0) __builtin_amdgcn_s_barrier();
 
