@@ -88,8 +88,20 @@ class GemmTimer:
             return r
 
         ops.gemm_nt_lora = timed_lora
+        orig_nn = ops.gemm_nn
+
+        def timed_nn(a, b, out=None, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_nn(a, b, out=out, **kw)
+            e.record()
+            recs.append((s, e, 2.0 * a.shape[0] * b.shape[1] * a.shape[1],
+                         2.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[1])))
+            return r
+
+        ops.gemm_nn = timed_nn
         self._restore = lambda: (setattr(ops, "gemm_nt", orig), setattr(ops, "gemm_tn", orig_tn),
-                                 setattr(ops, "gemm_nt_lora", orig_lora))
+                                 setattr(ops, "gemm_nt_lora", orig_lora), setattr(ops, "gemm_nn", orig_nn))
 
     def summary(self):
         tot_ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
@@ -249,7 +261,7 @@ def main():
                     traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
             except Exception:
                 pass
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256_kernel / gemm_tn_256_kernel (256x256x32 ping-pong; all rv_gemm_nt_bf16 + rv_gemm_tn_bf16 launches)",
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nn_256_kernel / gemm_tn_256_kernel / gemm_nt_256_kernel (256x256x32 ping-pong; all rv_gemm_nn_bf16 + rv_gemm_tn_bf16 + rv_gemm_nt_bf16 launches)",
                                 "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                 "traffic_note": "HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "

@@ -38,6 +38,13 @@ int rv_set_gemm_variant(int variant);
 int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* bias, const void* residual, long ldr, int act, float alpha, int variant,
                     void* stream);
+/* C[m][n] = alpha * sum_k A[m][k] * B[k][n] (+ residual): NN form - B is [K][N] row-major (N contiguous).  The same
+ * nn.Linear forward / input-gradient products as rv_gemm_nt_bf16, fed with the other orientation of the weight
+ * (forward: B = W^T copy [in][out]; input gradient: B = W [out][in]) so that the weight tile is fetched in full
+ * 512-byte row segments.  Large problems only (256x256 tiles); K % 32 == 0, N % 8 == 0. */
+int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                    const void* residual, long ldr, float alpha, void* stream);
+
 /* Fused LoRA GEMM (peft LoraLayer.forward as used by muffin/train/train_llava15_lora.py:304-318):
  *   C[m][n] = sum_{k<K} A[m][k] B[n][k] + sum_{q<K2} A2[m][c0(n)+q] B2[n][q] (+ residual[m][n]),
  *   c0(n) = group_cols ? (n / group_cols) * K2 : 0.

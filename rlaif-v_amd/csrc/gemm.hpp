@@ -713,6 +713,170 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), i0 + wi * 128 + 64, j0 + wj * 64, lane, I, J);
 }
 
+// =============================================================================================
+// NN GEMM:  D[m][n] = sum_k A[m][k] * B[k][n]   (A [M][K] K-contiguous, B [K][N] N-contiguous, both row-major).
+// The A side is gemm_nt_256_kernel's (64-byte row slices by LDS-DMA, ds_read_b128 fragments), the B side is
+// gemm_tn_256_kernel's Q operand: the [32 k][256 n] tile is staged as it lies in memory - FULL 512-byte row segments per
+// DMA piece - and the "8 consecutive k of one column" fragments come from ds_read_b64_tr_b16.  Full-line requests are
+// what the L2->LDS fabric likes (profiles/r01_glds_probe.log: 34 vs 20 TB/s chip-wide), which is why the TN kernel
+// outruns the NT kernel; this kernel gives the weight operand of every forward / input-gradient GEMM the same
+// treatment: forward runs on the W^T copy ([in][out]), the input gradient on W itself ([out][in]).
+// Same ping-pong schedule, 4-stage ring, counted vmcnt and hazards as gemm_nt_256_kernel.  K % 32 == 0.
+// =============================================================================================
+template <class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g, Epi epi) {
+  constexpr int NST = 4, DIST = 3;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int GROUP = g.group > 0 ? g.group : 4;
+  const int group_size = GROUP * tiles_n;
+  const int first_m = (id / group_size) * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tile_m = first_m + (id % group_size) % gsz;
+  const int tile_n = (id % group_size) / gsz;
+  const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
+  const long ldb = g.ldb;
+
+  // ---- A pieces: 16 rows x 64 B (as gemm_nt_256_kernel); B pieces: 2 k-rows x 512 B (as gemm_tn_256_kernel's Q)
+  const bf16_t* a_src[2];
+  const bf16_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    const int kc = (lane & 3) ^ ((row >> 2) & 3);
+    a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+    const int r = (wave * 2 + i) * 2 + (lane >> 5);              // k row of the tile filled by this lane
+    const int c = lane & 31;
+    const int col = (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3);   // 64-byte block (c>>2) ^ (r&3), 16-byte slot c&3
+    b_src[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
+  }
+  const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
+  auto issue_piece = [&](int t, int j) {   // j: 0 = A piece 0, 1 = B piece 0, 2 = A piece 1, 3 = B piece 1
+    uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
+    const int i = j >> 1;
+    if ((j & 1) == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (long)t * G2_BK),
+                                       (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (long)t * G2_BK * ldb),
+                                       (__attribute__((address_space(3))) void*)(st + 16384 + piece0 + i * 1024), 16, 0, 0);
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_piece(t, j);
+  };
+  const bf16_t* a_run[2] = {a_src[0] + DIST * G2_BK, a_src[1] + DIST * G2_BK};
+  const bf16_t* b_run[2] = {b_src[0] + (long)DIST * G2_BK * ldb, b_src[1] + (long)DIST * G2_BK * ldb};
+  auto issue_piece_run = [&](int t, int j) {
+    uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
+    const int i = j >> 1;
+    if ((j & 1) == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_run[i],
+                                       (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_run[i],
+                                       (__attribute__((address_space(3))) void*)(st + 16384 + piece0 + i * 1024), 16, 0, 0);
+  };
+
+  // ---- A fragments (ds_read_b128) and B fragments (transposing reads)
+  const int fr = lane & 31, half = lane >> 5;
+  uint32_t a_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    a_off[ks] = (uint32_t)((wm * 128 + fr) * 64) + (uint32_t)(((ks * 2 + half) ^ ((fr >> 2) & 3)) << 4);
+  const int g4 = lane >> 4, s16 = lane & 15;
+  const uint32_t lane_part = (uint32_t)((8 * (g4 >> 1) + (s16 >> 2)) * 512 + 32 * (g4 & 1) + 8 * (s16 & 3));
+  uint32_t q_blk[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) q_blk[t] = lane_part + 16384u + (uint32_t)((((wn * 2 + t) ^ (s16 >> 2))) << 6);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = g.K / G2_BK;
+  issue(0);
+  if (nt > 1) issue(1);
+  if (nt > 2) issue(2);
+  {
+    const int issued = min(nt, DIST);
+    if (issued == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+  auto tile = [&](const int p, auto steady_c) {
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const uint8_t* st = smem + (p % NST) * G2_STAGE_BYTES;
+    bf16x8_t af[2][4], bfr[2][2];
+    const uint32_t sta = lds_addr_of(st);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t a0 = sta + q_blk[t];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bfr[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[ks][t] = *(const bf16x8_t*)(st + a_off[ks] + t * 2048);
+    {
+      const int newer = STEADY ? DIST - 2 : min(DIST - 2, nt - 2 - p);
+      if (newer >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    const bool dma = STEADY || (p + DIST < nt);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
+          const int k = (ks * 4 + tm) * 2 + tn;
+          if ((k & 3) == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (STEADY) issue_piece_run(p + DIST, k >> 2);
+            else if (dma) issue_piece(p + DIST, k >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    int p = 0;
+    for (; p + DIST < nt; ++p) {
+      tile(p, std::true_type{});
+      a_run[0] += G2_BK; a_run[1] += G2_BK; b_run[0] += G2_BK * ldb; b_run[1] += G2_BK * ldb;
+    }
+    for (; p < nt; ++p) tile(p, std::false_type{});
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count
+
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogues.  apply() receives the wave's 64x64 accumulators and its tile origin.
 // ---------------------------------------------------------------------------------------------

@@ -522,7 +522,7 @@ class LlavaDPOModel:
         st = self.store
         W = st.p(f"layers.{i}.w{grp}")
         if self.lora is None:
-            return ops.gemm_nt(x, W, residual=residual), None, None
+            return ops.linear(x, W, st.pT(f"layers.{i}.w{grp}"), residual=residual), None, None
         xd = None
         if self.training and self.lora.lora_dropout > 0.0:
             xd = ops.dropout(x, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
@@ -542,7 +542,7 @@ class LlavaDPOModel:
         st = self.store
         wkey = f"layers.{i}.w{grp}"
         if self.lora is None:
-            dx = ops.gemm_nt(dy, st.pT(wkey))
+            dx = ops.linear(dy, st.pT(wkey), st.p(wkey))        # dx = dy @ W: "weight" = W^T, its transpose = W itself
             ops.gemm_tn(dy, xin, out=st.g(wkey))
             return dx
         rp, sc = self.lora.r_pad, self.lora.scaling
@@ -681,7 +681,7 @@ class LlavaDPOModel:
         if n_sel > 0:
             rc = ops.row_coef(coef, plan.seq_of_row, ctx["w_rows"])
             dlog = ops.lmhead_logp_bwd(ctx["hsel"], st.p("lm_head.weight"), plan.tgt, ctx["lse_v"], rc, n_sel)
-            dh = ops.gemm_nt(dlog, st.pT("lm_head.weight"))
+            dh = ops.linear(dlog, st.pT("lm_head.weight"), st.p("lm_head.weight"))
             if not lora:
                 wgrad(dlog, ctx["hsel"], "lm_head.weight")
             del dlog

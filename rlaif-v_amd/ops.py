@@ -47,6 +47,33 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """out[m][n] = alpha * sum_k a[m][k] b[k][n] + residual[m][n]   (b row-major [K, N]: rv_gemm_nn_bf16)."""
+    _chk2d(a, "a"), _chk2d(b, "b")
+    M, K = a.shape
+    Kb, N = b.shape
+    if K != Kb:
+        raise ValueError(f"gemm_nn: inner dimensions differ: {K} vs {Kb}")
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    hip.call("rv_gemm_nn_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, K, residual,
+             residual.stride(0) if residual is not None else 0, float(alpha))
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, wT: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ w^T (+ residual) for a weight held in both orientations (w [out, in], wT [in, out]).  Problems that fill
+    the chip with 256x256 tiles take the NN kernel on wT - its weight tile is fetched in full 512-byte segments
+    (+6-12 % over the NT kernel on the 7B shapes); small ones take the NT kernels on w."""
+    M, N = x.shape[0], w.shape[0]
+    if wT is not None and ((M + 255) // 256) * ((N + 255) // 256) >= 192 and x.shape[1] % 32 == 0 and N % 8 == 0:
+        return gemm_nn(x, wT[:, :N], out=out, residual=residual)
+    return gemm_nt(x, w, out=out, residual=residual)
+
+
 def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
             alpha: float = 1.0) -> torch.Tensor:
     """out[i][j] = alpha * sum_r p[r][i] q[r][j] + residual[i][j]  (weight gradient dW = dY^T X)."""

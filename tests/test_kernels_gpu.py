@@ -175,6 +175,24 @@ def test_gemm_tn_skinny(ops, R, I, J):
     assert view[:, :32].abs().sum() == 0 and view[:, 32 + J:].abs().sum() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 64), (1000, 1288, 160), (27000, 4096, 1024), (26000, 3072, 4096)])
+def test_gemm_nn(ops, M, N, K):
+    """NN GEMM (weight operand as [K][N], fetched in full 512-byte segments, transposing LDS reads): ragged M / N,
+    strided views, residual + alpha; bit-identical to the NT kernel on the transposed operand (same MFMA sequence)."""
+    dev = _dev()
+    a, b = rnd(M, K, seed=51, dev=dev), rnd(K, N, seed=52, dev=dev)
+    out = ops.gemm_nn(a, b)
+    close(out, a.float() @ b.float(), what=f"gemm_nn {M}x{N}x{K}")
+    bt = b.t().contiguous()
+    if K % 64 == 0:
+        assert torch.equal(out, ops.gemm_nt(a, bt, variant=3))
+    res = rnd(M, N, seed=53, dev=dev)
+    close(ops.gemm_nn(a, b, residual=res, alpha=0.5), 0.5 * (a.float() @ b.float()) + res.float(), what="gemm_nn epilogue")
+    wide = rnd(K, N + 128, seed=54, dev=dev)
+    close(ops.gemm_nn(a, wide[:, 64:64 + N]), a.float() @ wide[:, 64:64 + N].float(), what="gemm_nn strided b")
+    assert torch.equal(ops.gemm_nn(a, b), out)
+
+
 def test_gemm_f32_out(ops):
     dev = _dev()
     a, b = rnd(190, 128, seed=9, dev=dev), rnd(260, 128, seed=10, dev=dev)

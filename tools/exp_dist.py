@@ -16,10 +16,12 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "nt"
 if mode == "nt":
     for name, M, N, K in [("qkv", R, 12288, 4096), ("o", R, 4096, 4096), ("gate_up", R, 22016, 4096), ("down", R, 4096, 11008)]:
         a = torch.randn(M, K, device="cuda").to(BF); b = torch.randn(N, K, device="cuda").to(BF); out = torch.empty(M, N, device="cuda", dtype=BF)
+        bT = b.t().contiguous()
         for rep in range(2):
-            for v in (3, 3):
-                ms = timeit(lambda: ops.gemm_nt(a, b, out=out, variant=v))
-                print(f"nt {name:8s} v{v}: {ms:.3f} ms {2*M*N*K/ms/1e9:7.1f} TF/s")
+            ms = timeit(lambda: ops.gemm_nt(a, b, out=out, variant=3))
+            print(f"nt {name:8s} v3: {ms:.3f} ms {2*M*N*K/ms/1e9:7.1f} TF/s")
+            ms = timeit(lambda: ops.gemm_nn(a, bT, out=out))
+            print(f"nn {name:8s}   : {ms:.3f} ms {2*M*N*K/ms/1e9:7.1f} TF/s")
 else:
     for name, I, J in [("wqkv", 12288, 4096), ("wdown", 4096, 11008), ("wgu", 22016, 4096)]:
         p = torch.randn(R, I, device="cuda").to(BF); q = torch.randn(R, J, device="cuda").to(BF); out = torch.empty(I, J, device="cuda", dtype=BF)
