@@ -56,6 +56,13 @@ int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const
                          long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
                          const void* residual, long ldr, void* stream);
 
+/* NN form of rv_gemm_nt_lora_bf16: B is [K][N], B2 is [K2][N] (both row-major); A2 as there.  Forward: B = W^T copy,
+ * B2 = stacked lora_B^T [r][N]; input gradient: B = W, B2 = stacked lora_A [G*r][N], group_cols = 0.  K, K2 % 32 == 0;
+ * group_cols a multiple of 256. */
+int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                         long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
+                         const void* residual, long ldr, void* stream);
+
 /* C = dropout_{p,seed}(alpha * A B^T) + residual: rv_gemm_nt_bf16 whose result is masked with exactly the mask
  * rv_dropout(p, seed) draws for a contiguous [M][N] tensor, before the residual is added.  Backward of the LoRA branch
  * dropout: dx = dy W + mask * (dt A) / (1 - p) without materialising dt A.  N % 8 == 0. */

@@ -242,6 +242,33 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   return 0;
 }
 
+int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                         long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
+                         const void* residual, long ldr, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  RV_REQUIRE(K > 0 && K % G2_BK == 0 && K2 > 0 && K2 % G2_BK == 0, "rv_gemm_nn_lora_bf16: K and K2 must be positive multiples of 32");
+  RV_REQUIRE(N % 8 == 0 && N >= 8, "rv_gemm_nn_lora_bf16: N must be a multiple of 8");
+  RV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0),
+             "rv_gemm_nn_lora_bf16: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
+  RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15) == 0,
+             "rv_gemm_nn_lora_bf16: operands must be 16-byte aligned");
+  RV_REQUIRE(group_cols == 0 || (group_cols % G2_BN == 0 && N % group_cols == 0),
+             "rv_gemm_nn_lora_bf16: group_cols must be 0 or a multiple of 256 that divides N");
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group,
+              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols};
+  EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, 1.0f};
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nn_256_kernel<EpiStore, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
+  hipLaunchKernelGGL((gemm_nn_256_kernel<EpiStore, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES,
+                     (hipStream_t)stream, g, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
 int rv_gemm_nt_dropout_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             const void* residual, long ldr, float alpha, float p, int seed, void* stream) {
   if (M == 0 || N == 0) return 0;

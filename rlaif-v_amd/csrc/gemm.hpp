@@ -723,7 +723,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
 // treatment: forward runs on the W^T copy ([in][out]), the input gradient on W itself ([out][in]).
 // Same ping-pong schedule, 4-stage ring, counted vmcnt and hazards as gemm_nt_256_kernel.  K % 32 == 0.
 // =============================================================================================
-template <class Epi>
+// EXT: second contraction segment (GemmShape::A2 [M][..] K2-contiguous slices, B2 [K2][N] row-major) - the fused LoRA form.
+template <class Epi, bool EXT = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g, Epi epi) {
   constexpr int NST = 4, DIST = 3;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -757,10 +758,26 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
     b_src[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
   }
   const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
+  const int nt1 = g.K / G2_BK;
+  const int nt = nt1 + (EXT ? g.K2 / G2_BK : 0);
+  const int a2_col0 = (EXT && g.group_cols > 0) ? (n0 / g.group_cols) * g.K2 : 0;
   auto issue_piece = [&](int t, int j) {   // j: 0 = A piece 0, 1 = B piece 0, 2 = A piece 1, 3 = B piece 1
     uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
     const int i = j >> 1;
-    if ((j & 1) == 0)
+    if (EXT && t >= nt1) {     // wave-uniform: tiles of the second segment, addresses rebuilt on the fly
+      const bf16_t* src;
+      if ((j & 1) == 0) {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        src = g.A2 + (long)min(m0 + row, g.M - 1) * g.lda2 + a2_col0 + (long)(t - nt1) * G2_BK +
+              (((lane & 3) ^ ((row >> 2) & 3)) << 3);
+      } else {
+        const int r = (wave * 2 + i) * 2 + (lane >> 5), c = lane & 31;
+        src = g.B2 + ((long)(t - nt1) * G2_BK + r) * g.ldb2 + min(n0 + (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3), g.N - 8);
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + ((j & 1) ? 16384 : 0) + piece0 + i * 1024),
+                                       16, 0, 0);
+    } else if ((j & 1) == 0)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (long)t * G2_BK),
                                        (__attribute__((address_space(3))) void*)(st + piece0 + i * 1024), 16, 0, 0);
     else
@@ -804,7 +821,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = g.K / G2_BK;
   issue(0);
   if (nt > 1) issue(1);
   if (nt > 2) issue(2);
@@ -865,7 +881,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
   };
   {
     int p = 0;
-    for (; p + DIST < nt; ++p) {
+    for (; p + DIST < nt1; ++p) {      // steady: the fetched tile p+DIST lies in the main segment
       tile(p, std::true_type{});
       a_run[0] += G2_BK; a_run[1] += G2_BK; b_run[0] += G2_BK * ldb; b_run[1] += G2_BK * ldb;
     }

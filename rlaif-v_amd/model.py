@@ -528,8 +528,9 @@ class LlavaDPOModel:
             xd = ops.dropout(x, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
         t = ops.gemm_nt(x if xd is None else xd, st.p(f"layers.{i}.lora_{grp}.A"), alpha=self.lora.scaling)
         gc = self._GROUP_COLS[grp]
-        y = ops.gemm_nt_lora(x, W, t, st.p(f"layers.{i}.lora_{grp}.B"), group_cols=getattr(self.cfg, gc) if gc else 0,
-                             residual=residual)
+        y = ops.linear_lora(x, W, st.pT(f"layers.{i}.w{grp}"), t, st.p(f"layers.{i}.lora_{grp}.B"),
+                            st.pT(f"layers.{i}.lora_{grp}.B"), group_cols=getattr(self.cfg, gc) if gc else 0,
+                            residual=residual)
         return y, t, (xd if self.keep_dropped_inputs else None)
 
     def _dropout_seed(self, layer: int, slot: int) -> int:
@@ -555,13 +556,13 @@ class LlavaDPOModel:
             ops.gemm_nt(dy[:, g * og:(g + 1) * og], BT[:, g * og:(g + 1) * og], out=dt[:, g * rp:(g + 1) * rp], alpha=sc)
         if self.training and self.lora.lora_dropout > 0.0:
             # dropout sits on the adapter branch only: dx = dy W + mask * (dt A) / (1 - p)
-            dx = ops.gemm_nt(dy, st.pT(wkey))
+            dx = ops.linear(dy, st.pT(wkey), st.p(wkey))
             ops.gemm_nt_dropout(dt, st.pT(akey), self.lora.lora_dropout, self._dropout_seed(i, drop_slot), out=dx,
                                 residual=dx)
             # the dropped adapter input: kept from forward (288 GB HBM) or regenerated from the seed
             xin = xd if xd is not None else ops.dropout(xin, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
         else:
-            dx = ops.gemm_nt_lora(dy, st.pT(wkey), dt, st.pT(akey), group_cols=0)
+            dx = ops.linear_lora(dy, st.pT(wkey), st.p(wkey), dt, st.pT(akey), st.p(akey), group_cols=0)
         ops.gemm_tn_skinny(dt, xin, out=st.g(akey))
         gB = st.g(bkey)
         for g in range(G):

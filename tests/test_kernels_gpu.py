@@ -160,6 +160,24 @@ def test_gemm_nt_lora(ops, M, N, K, K2, gc):
     assert torch.equal(ops.gemm_nt_lora(a, b, z, b2, group_cols=gc), ops.gemm_nt(a, b, variant=3 if M > 20000 else 1))
 
 
+@pytest.mark.parametrize("M,N,K,K2,gc", [(27000, 3072, 1024, 64, 1024), (26000, 1024, 2048, 192, 0), (300, 512, 128, 64, 256)])
+def test_gemm_nn_lora(ops, M, N, K, K2, gc):
+    """NN form of the fused LoRA GEMM: bit-identical to the NT form on the transposed weight operands."""
+    dev = _dev()
+    groups = N // gc if gc else 1
+    a, b = rnd(M, K, seed=61, dev=dev), rnd(N, K, seed=62, dev=dev)
+    a2, b2 = rnd(M, groups * K2, seed=63, dev=dev), rnd(N, K2, seed=64, dev=dev)
+    res = rnd(M, N, seed=65, dev=dev)
+    ref = ops.gemm_nt_lora(a, b, a2, b2, group_cols=gc, residual=res)
+    got = ops.gemm_nn_lora(a, b.t().contiguous(), a2, b2.t().contiguous(), group_cols=gc, residual=res)
+    if M > 20000:
+        assert torch.equal(got, ref)
+    else:
+        close(got, ref, rel=4e-3, what="gemm_nn_lora vs nt_lora (different tile kernels)")
+    assert torch.equal(ops.linear_lora(a, b, b.t().contiguous(), a2, b2, b2.t().contiguous(), group_cols=gc, residual=res),
+                       got if M > 20000 and gc % 256 == 0 else ref)
+
+
 @pytest.mark.parametrize("R,I,J", [(5000, 64, 1024), (27664, 192, 4096), (3000, 1024, 64), (777, 64, 64)])
 def test_gemm_tn_skinny(ops, R, I, J):
     """Split-K TN GEMM (LoRA weight gradients): ragged last chunk, deterministic fp32 second pass."""
