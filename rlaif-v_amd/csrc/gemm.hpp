@@ -893,6 +893,200 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
 }
 
+// =============================================================================================
+// NN GEMM with FULL-LINE fetches on BOTH operands ("A64"): as gemm_nn_256_kernel, but the A operand is staged in
+// 64-deep tiles - one LDS-DMA piece = 8 rows x 128 B, a whole cache line per row - held in a 3-stage ring of its own
+// (3 x 32 KiB) next to the 4-stage ring of 32-deep B tiles (4 x 16 KiB): 160 KiB of LDS, the CU's whole allocation.
+// Phase p (32 of K) computes on A tile p>>1 (k half p&1) and B tile p.  Its M segment issues, interleaved A,B,A,B:
+//     A pieces 2(p&1), 2(p&1)+1 of A tile (p>>1)+2      and      B pieces 0, 1 of B tile p+3.
+// Hazards (barrier instances as in gemm_nt_256_kernel; loads retire in order, every M segment issues exactly 4):
+//   RAW: the wait of L-seg(p) is vmcnt(4) = "everything issued up to M-seg(p-2) has landed" - that covers B tile p+1
+//        (issued in M-seg(p-2)) and A tile (p+1)>>1 (issued in M-segs 2((p+1)>>1)-4, -3 <= p-2), one barrier or more
+//        before any group reads them.  Prologue order A0 B0 | A1 B1 B2: vmcnt(8) before the first barrier, vmcnt(2) in
+//        L-seg(0).
+//   WAR: A stage ((p>>1)+2)%3 = ((p>>1)-1)%3 was last read in L-seg(2(p>>1)-1) <= L-seg(p-1), retired by both groups
+//        before G1.X(p-1) = barrier instance 2p-1, which precedes every M-seg(p).  B ring as in the NT kernel.
+// Requires K % 64 == 0.
+// =============================================================================================
+#define G4_A_STAGE 32768
+#define G4_B_STAGE 16384
+#define G4_LDS_BYTES (3 * G4_A_STAGE + 4 * G4_B_STAGE)
+
+template <class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const smA = smem;
+  uint8_t* const smB = smem + 3 * G4_A_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int GROUP = g.group > 0 ? g.group : 4;
+  const int group_size = GROUP * tiles_n;
+  const int first_m = (id / group_size) * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tile_m = first_m + (id % group_size) % gsz;
+  const int tile_n = (id % group_size) / gsz;
+  const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
+  const long ldb = g.ldb;
+
+  // ---- A pieces: wave w owns pieces 4w .. 4w+3 of a 64-deep tile; piece = 8 rows x 128 B, LDS image row*128 +
+  //      ((kc ^ ((row>>1)&7))<<4) (the 128x128 kernel's conflict-free layout), swizzle applied on the source address.
+  //      B pieces: 2 k-rows x 512 B, as gemm_nn_256_kernel.
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((row >> 1) & 7);
+    a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 2 + (lane >> 5);
+    const int c = lane & 31;
+    const int col = (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3);
+    b_src[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
+  }
+  const uint32_t a_piece0 = (uint32_t)(wave * 4) * 1024u, b_piece0 = (uint32_t)(wave * 2) * 1024u;
+  auto issue_a = [&](int T, int i, const bf16_t* src) {      // piece i (0..3) of A tile T
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smA + (T % 3) * G4_A_STAGE + a_piece0 + i * 1024),
+                                     16, 0, 0);
+  };
+  auto issue_b = [&](int t, int i, const bf16_t* src) {      // piece i (0..1) of B tile t
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smB + (t % 4) * G4_B_STAGE + b_piece0 + i * 1024),
+                                     16, 0, 0);
+  };
+
+  // ---- fragments
+  const int fr = lane & 31, half = lane >> 5;
+  const uint32_t a_row_off = (uint32_t)((wm * 128 + fr) * 128);
+  const int a_sw = (fr >> 1) & 7;                               // (row >> 1) & 7 with row = wm*128 + t*32 + fr
+  const int g4 = lane >> 4, s16 = lane & 15;
+  const uint32_t lane_part = (uint32_t)((8 * (g4 >> 1) + (s16 >> 2)) * 512 + 32 * (g4 & 1) + 8 * (s16 & 3));
+  uint32_t q_blk[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) q_blk[t] = lane_part + (uint32_t)((((wn * 2 + t) ^ (s16 >> 2))) << 6);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = g.K / G2_BK;            // 32-deep phases (even)
+  const int ntA = nt >> 1;               // 64-deep A tiles
+  // prologue: A0 B0 | A1 B1 B2
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_a(0, i, a_src[i]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_b(0, i, b_src[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_a(1, i, a_src[i] + (ntA > 1 ? 64 : 0));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_b(1, i, b_src[i] + (long)G2_BK * ldb);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt > 2 ? 2 : 1) * G2_BK * ldb);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+  // running sources of the pieces issued in M-seg(p): A tile (p>>1)+2, B tile p+3 (clamped to the last tile at the end:
+  // the redundant loads land in stages nobody reads any more)
+  const bf16_t* a_run[4];
+  const bf16_t* b_run[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_run[i] = a_src[i] + 2 * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) b_run[i] = b_src[i] + 3L * G2_BK * ldb;
+
+  // A fragment address of k half h: chunk (4h + 2ks + half) ^ sw = the h = 0 chunk with bit 2 flipped -> offset ^ (h << 6)
+  uint32_t a_pre[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) a_pre[ks] = a_row_off + (uint32_t)((((ks * 2 + half) ^ a_sw)) << 4);
+
+  // One phase.  MODE (compile time): 1 = steady (issues 2 A + 2 B pieces, counted wait), 0 = tail (no A; B pieces only
+  // when `b_too`; drains completely).  Only three instantiations exist (steady even, steady odd, tail): more copies of
+  // the segment made hipcc spill the accumulators.
+  auto phase = [&](const int p, const int h, auto hc, auto mode_c, const bool b_too) {
+    constexpr int H = decltype(hc)::value;              // = h in steady phases (selects the A pieces to issue)
+    constexpr int MODE = decltype(mode_c)::value;
+    const uint8_t* stA = smA + ((p >> 1) % 3) * G4_A_STAGE;
+    const uint32_t stB = lds_addr_of(smB + (p % 4) * G4_B_STAGE);
+    const uint32_t hx = (uint32_t)h << 6;
+    bf16x8_t af[2][4], bfr[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t a0 = stB + q_blk[t];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bfr[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[ks][t] = *(const bf16x8_t*)(stA + (a_pre[ks] ^ hx) + t * 4096);
+    if (MODE == 1) {
+      if (p == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // prologue: only B tile 2 may still be in flight
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
+          const int k = (ks * 4 + tm) * 2 + tn;
+          if ((k & 3) == 1) {
+            const int j = k >> 2;                                  // 0: A, 1: B, 2: A, 3: B
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 1) {
+              if ((j & 1) == 0) issue_a((p >> 1) + 2, 2 * H + (j >> 1), a_run[2 * H + (j >> 1)]);
+              else issue_b(p + 3, j >> 1, b_run[j >> 1]);
+            } else if ((j & 1) == 1 && b_too) {
+              issue_b(p + 3, j >> 1, b_run[j >> 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // steady pairs: p + 4 < nt (A tile (p>>1)+2 <= ntA-1 and B tiles p+3, p+4 <= nt-1 exist)
+  int p = 0;
+  for (; p + 4 < nt; p += 2) {
+    phase(p, 0, I0{}, I1{}, false);
+    b_run[0] += G2_BK * ldb; b_run[1] += G2_BK * ldb;
+    phase(p + 1, 1, I1{}, I1{}, false);
+    b_run[0] += G2_BK * ldb; b_run[1] += G2_BK * ldb;
+    a_run[0] += 64; a_run[1] += 64; a_run[2] += 64; a_run[3] += 64;
+  }
+  // tail: phase nt-4 still fetches the last B tile; every tail phase drains completely before its barrier
+  for (; p < nt; ++p) phase(p, p & 1, I0{}, I0{}, p + 4 == nt);
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count
+
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
+  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogues.  apply() receives the wave's 64x64 accumulators and its tile origin.
 // ---------------------------------------------------------------------------------------------
