@@ -15,6 +15,10 @@ void rv_set_error(const char* msg) {
 // -1 (default) = pick 2 when the problem fills the chip with 256x256 tiles, else 1.
 static int g_default_variant = -1;
 static int g_group = 0;     // experiment knob: RV_GEMM_GROUP
+static void read_group_env() {
+  static bool env_done = false;
+  if (!env_done) { const char* e = getenv("RV_GEMM_GROUP"); if (e) g_group = atoi(e); env_done = true; }
+}
 
 template <class Epi, bool DMA_IN_MSEG, int ABLATE = 0, int DIST = 3, int SPLIT = 0>
 static int launch_gemm256(const GemmShape& g, const Epi& epi, hipStream_t st) {
@@ -140,8 +144,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
 
 template <class Epi>
 static int dispatch(const GemmShape& g, const Epi& epi, int variant, void* stream) {
-  static bool env_done = false;
-  if (!env_done) { const char* e = getenv("RV_GEMM_GROUP"); if (e) g_group = atoi(e); env_done = true; }
+  read_group_env();
   if (variant < 0) variant = g_default_variant;
   if (variant < 0) {
     const long t256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
@@ -228,6 +231,7 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   RV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0),
              "rv_gemm_nn_bf16: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
   RV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "rv_gemm_nn_bf16: A/B must be 16-byte aligned");
+  read_group_env();
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
   static bool attr_done = false;
