@@ -118,12 +118,15 @@ int rv_row_coef(const float* coef, const int* seq_of_row, const float* weight, f
  *   [shared prefix | chosen branch | rejected branch]; queries at index >= seg_e1[s] (rejected branch) do not attend
  *   keys in [seg_sh[s], seg_e1[s]) (the chosen branch): the image / prompt prefix is computed ONCE per pair. */
 int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
-                int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, void* stream);
-/* backward (hd = 128): delta = rv_attn_delta(dO, O).  Writes dQ, dK, dV into dqkv at the column offsets of
+                int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
+                void* stream);
+/* kv_group (both calls): grouped-query attention as in HF Mistral / Llama-3 (`repeat_kv`): H query heads share
+ * H / kv_group key/value heads, query head h reads kv head h / kv_group (K at k_col0 + (h / kv_group) * hd); 1 = MHA.
+ * backward (hd = 128): delta = rv_attn_delta(dO, O).  Writes dQ, dK, dV into dqkv at the column offsets of
  * qkv.  Deterministic (no atomics): one kernel per 128-query block for dQ, one per 128-key block for dK/dV. */
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
                 const float* lse, const float* delta, void* dqkv, long lddq, int S, int L, int H, int hd, int causal,
-                float scale, const int* seg_sh, const int* seg_e1, void* stream);
+                float scale, const int* seg_sh, const int* seg_e1, int kv_group, void* stream);
 int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
                   void* stream);
 

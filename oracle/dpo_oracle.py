@@ -52,10 +52,15 @@ class LlavaCfg:
     select_layer: int = -2          # mm_vision_select_layer (script/train/llava15_train.sh)
     model_max_length: int = 2048    # tokenizer_model_max_length (train_llava15.py:249)
     pad_token_id: int = 0           # tokenizer.pad_token = unk (train_llava15.py:228)
+    kv_heads: Optional[int] = None  # num_key_value_heads of the HF Llama/Mistral config (None = heads: LLaVA-1.5 is MHA)
 
     @property
     def head_dim(self) -> int:
         return self.hidden // self.heads
+
+    @property
+    def n_kv_heads(self) -> int:
+        return self.heads if self.kv_heads is None else self.kv_heads
 
     @property
     def clip_head_dim(self) -> int:
@@ -71,6 +76,14 @@ class LlavaCfg:
         # (llava/model/multimodal_encoder/clip_encoder.py:36-44)
         idx = self.select_layer if self.select_layer >= 0 else self.clip_layers + 1 + self.select_layer
         return idx
+
+
+def tiny_gqa_cfg() -> LlavaCfg:
+    """Grouped-query attention (4 query heads on 2 key/value heads), the Mistral / Llama-3 arrangement of the
+    reference's other language models (OmniLMM's Zephyr, MiniCPM-Llama3-V); head_dim stays 128."""
+    return LlavaCfg(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=512,
+                    clip_hidden=128, clip_layers=3, clip_heads=2, clip_ffn=256,
+                    image_size=56, patch=14, model_max_length=256)
 
 
 def tiny_cfg() -> LlavaCfg:
@@ -91,8 +104,9 @@ def weight_shapes(cfg: LlavaCfg) -> Dict[str, Tuple[int, ...]]:
     s["model.embed_tokens.weight"] = (v, d)
     for i in range(cfg.layers):
         p = f"model.layers.{i}."
+        kvd = cfg.n_kv_heads * cfg.head_dim
         for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            s[p + f"self_attn.{n}.weight"] = (d, d)
+            s[p + f"self_attn.{n}.weight"] = (kvd if n in ("k_proj", "v_proj") else d, d)
         s[p + "mlp.gate_proj.weight"] = (f, d)
         s[p + "mlp.up_proj.weight"] = (f, d)
         s[p + "mlp.down_proj.weight"] = (d, f)
@@ -411,7 +425,7 @@ def llama_hidden(embeds: torch.Tensor, W: Dict[str, torch.Tensor], cfg: LlavaCfg
     """Decoder stack + final norm.  positions = arange(L) (position_ids dropped at
     llava_llama.py:94), pure causal mask, no pad mask (trainers.py:199)."""
     S, L, d = embeds.shape
-    H, hd = cfg.heads, cfg.head_dim
+    H, hd, Hkv = cfg.heads, cfg.head_dim, cfg.n_kv_heads
     cos, sin = rope_tables(L, hd, cfg.rope_theta, embeds.dtype)
     causal = torch.full((L, L), float("-inf"), dtype=embeds.dtype).triu(1)
     x = embeds
@@ -419,10 +433,13 @@ def llama_hidden(embeds: torch.Tensor, W: Dict[str, torch.Tensor], cfg: LlavaCfg
         p = f"model.layers.{i}."
         h = rms_norm(x, W[p + "input_layernorm.weight"], cfg.rms_eps)
         q = lora_linear(h, W, p + "self_attn.q_proj", lora_scale, lora_masks).view(S, L, H, hd).transpose(1, 2)
-        k = lora_linear(h, W, p + "self_attn.k_proj", lora_scale, lora_masks).view(S, L, H, hd).transpose(1, 2)
-        v = lora_linear(h, W, p + "self_attn.v_proj", lora_scale, lora_masks).view(S, L, H, hd).transpose(1, 2)
+        k = lora_linear(h, W, p + "self_attn.k_proj", lora_scale, lora_masks).view(S, L, Hkv, hd).transpose(1, 2)
+        v = lora_linear(h, W, p + "self_attn.v_proj", lora_scale, lora_masks).view(S, L, Hkv, hd).transpose(1, 2)
         q = q * cos + rotate_half(q) * sin
         k = k * cos + rotate_half(k) * sin
+        if Hkv != H:        # HF repeat_kv: query head h attends key/value head h // (H / Hkv)
+            k = k.repeat_interleave(H // Hkv, dim=1)
+            v = v.repeat_interleave(H // Hkv, dim=1)
         att = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + causal
         att = torch.softmax(att.float(), dim=-1).to(q.dtype)
         a = (att @ v).transpose(1, 2).reshape(S, L, d)

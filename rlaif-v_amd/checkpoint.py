@@ -22,7 +22,7 @@ def hf_config_dict(cfg) -> Dict:
     return {
         "architectures": ["LlavaLlamaForCausalLM"], "model_type": "llava_llama",
         "hidden_size": cfg.hidden, "intermediate_size": cfg.ffn, "num_hidden_layers": cfg.layers,
-        "num_attention_heads": cfg.heads, "num_key_value_heads": cfg.heads, "vocab_size": cfg.vocab,
+        "num_attention_heads": cfg.heads, "num_key_value_heads": cfg.n_kv_heads, "vocab_size": cfg.vocab,
         "rms_norm_eps": cfg.rms_eps, "rope_theta": cfg.rope_theta, "max_position_embeddings": 4096,
         "pad_token_id": cfg.pad_token_id, "bos_token_id": 1, "eos_token_id": 2, "hidden_act": "silu",
         "torch_dtype": "bfloat16", "tie_word_embeddings": False, "use_cache": True,
@@ -42,7 +42,7 @@ def config_from_hf(d: Dict, **overrides):
               select_layer=d.get("mm_vision_select_layer", -2),
               model_max_length=d.get("tokenizer_model_max_length", 2048), pad_token_id=d.get("pad_token_id") or 0)
     if d.get("num_key_value_heads", d["num_attention_heads"]) != d["num_attention_heads"]:
-        raise NotImplementedError("grouped-query attention checkpoints are not supported (LLaVA-1.5 uses MHA)")
+        kw["kv_heads"] = d["num_key_value_heads"]           # Mistral / Llama-3 style grouped-query attention
     kw.update(overrides)
     return LlavaConfig(**kw)
 

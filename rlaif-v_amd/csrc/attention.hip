@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
                                                            int k_col0, int v_col0, bf16_t* __restrict__ out, long ldo,
                                                            float* __restrict__ lse, int L, int H, int nx, float scale,
                                                            const int* __restrict__ seg_sh,
-                                                           const int* __restrict__ seg_e1) {
+                                                           const int* __restrict__ seg_e1, int kv_group) {
   constexpr int KS = HD / 16, ET = HD / 32, TILE = 64 * HD * 2, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   uint32_t boff[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) boff[ks] = kvtile_off<HD>(fr, 2 * ks + half);
-  const bf16_t* kbase = qkv + k_col0 + h * HD;
-  const bf16_t* vbase = qkv + v_col0 + h * HD;
+  const bf16_t* kbase = qkv + k_col0 + (h / kv_group) * HD;     // grouped-query attention: query head h -> kv head h / G
+  const bf16_t* vbase = qkv + v_col0 + (h / kv_group) * HD;
 
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
                                                               const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
                                                               int nx, float scale, const int* __restrict__ seg_sh,
-                                                              const int* __restrict__ seg_e1) {
+                                                              const int* __restrict__ seg_e1, int kv_group) {
   constexpr int HD = 128, KS = 8, ET = 4, TILE = 64 * HD * 2, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
   uint32_t boff[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) boff[ks] = kvtile_off<HD>(fr, 2 * ks + half);
-  const bf16_t* kbase = qkv + k_col0 + h * HD;
-  const bf16_t* vbase = qkv + v_col0 + h * HD;
+  const bf16_t* kbase = qkv + k_col0 + (h / kv_group) * HD;
+  const bf16_t* vbase = qkv + v_col0 + (h / kv_group) * HD;
 
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
@@ -429,7 +429,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
                                                                const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, long lddq, int L, int H,
                                                                int nx, float scale, const int* __restrict__ seg_sh,
-                                                               const int* __restrict__ seg_e1) {
+                                                               const int* __restrict__ seg_e1, int kv_group) {
+  // H = number of KEY/VALUE heads (the grid walks kv heads); the kv_group query heads h*G .. h*G+G-1 that share kv head h
+  // are accumulated into the same dK / dV tile (grouped-query attention; kv_group = 1: plain multi-head attention)
   constexpr int HD = 128, KS = 8, ET = 4;
   constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64]
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -444,8 +446,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const int nkb = (L + 127) / 128;
   const float c = scale * LOG2E;
-  const float* lse_base = lse + ((long)s * H + h) * L;
-  const float* delta_base = delta + ((long)s * H + h) * L;
+  const int HQ = H * kv_group;
 
   // LDS-DMA assignment: each wave fills 4 pieces (4 rows x 256 B) of Q and of dO per tile; wave 0 also lse/delta
   int d_row[4], d_chunk[4];
@@ -454,17 +455,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     d_row[i] = (wave * 4 + i) * 4 + (lane >> 4);
     d_chunk[i] = (lane & 15) ^ (((d_row[i] & 3) << 2) | ((d_row[i] >> 2) & 3));
   }
-  auto issue_tile = [&](int t, int buf) {
+  auto issue_tile = [&](int hq, int t, int buf) {          // hq = query head
     uint8_t* st = smem + buf * STAGE;
     const int qs0 = t * 64;
+    const float* lse_base = lse + ((long)s * HQ + hq) * L;
+    const float* delta_base = delta + ((long)s * HQ + hq) * L;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long tk = tok0 + min(qs0 + d_row[i], L - 1);
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(qkv + tk * ld + q_col0 + h * HD + d_chunk[i] * 8),
+          (const __attribute__((address_space(1))) void*)(qkv + tk * ld + q_col0 + hq * HD + d_chunk[i] * 8),
           (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(dO + tk * lddo + h * HD + d_chunk[i] * 8),
+          (const __attribute__((address_space(1))) void*)(dO + tk * lddo + hq * HD + d_chunk[i] * 8),
           (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
     }
     if (wave == 0) {
@@ -518,7 +521,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 
     const int t_begin = CAUSAL ? (kv0 / 64) : 0;
     const int nt = (L + 63) / 64;
-    issue_tile(t_begin, 0);
+    for (int gq = 0; gq < kv_group; ++gq) {
+    const int hq = h * kv_group + gq;
+    issue_tile(hq, t_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
       const float* lse_s = (const float*)(Qs + 32768);
       const float* delta_s = lse_s + 64;
       const int qs0 = t * 64;
-      if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
+      if (t + 1 < nt) issue_tile(hq, t + 1, buf ^ 1);
 
       if (!(CAUSAL && qs0 + 63 < kv0w) && !(qs0 >= e1 && kv0w >= sh && kv0w + 31 < e1)) {
 #pragma unroll
@@ -597,6 +602,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    }  // query heads of the group
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
 
     if (key < L) {
@@ -622,8 +628,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 extern "C" {
 
 int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
-                int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, void* stream) {
+                int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group, void* stream) {
   RV_REQUIRE(hd == 64 || hd == 128, "rv_attn_fwd: head dim must be 64 or 128");
+  RV_REQUIRE(kv_group >= 1 && H % kv_group == 0, "rv_attn_fwd: kv_group must divide the number of query heads");
   RV_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0 && v_col0 % 8 == 0,
              "rv_attn_fwd: alignment");
   if (S == 0 || L == 0) return 0;
@@ -642,7 +649,7 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   }
 #define LAUNCH_FWD(HD_, C_)                                                                                      \
   hipLaunchKernelGGL((attn_fwd2_kernel<HD_, C_>), grid, block, 4 * 64 * HD_ * 2, st, (const bf16_t*)qkv, ld, q_col0, \
-                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1)
+                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group)
   if (hd == 128) { if (causal) LAUNCH_FWD(128, true); else LAUNCH_FWD(128, false); }
   else { if (causal) LAUNCH_FWD(64, true); else LAUNCH_FWD(64, false); }
 #undef LAUNCH_FWD
@@ -652,8 +659,10 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
 
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
                 const float* lse, const float* delta, void* dqkv, long lddq, int S, int L, int H, int hd, int causal,
-                float scale, const int* seg_sh, const int* seg_e1, void* stream) {
+                float scale, const int* seg_sh, const int* seg_e1, int kv_group,
+                void* stream) {
   RV_REQUIRE(hd == 128, "rv_attn_bwd: head dim must be 128");
+  RV_REQUIRE(kv_group >= 1 && H % kv_group == 0, "rv_attn_bwd: kv_group must divide the number of query heads");
   RV_REQUIRE((seg_sh == nullptr) == (seg_e1 == nullptr), "rv_attn_bwd: seg_sh and seg_e1 go together");
   RV_REQUIRE(ld % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0, "rv_attn_bwd: alignment");
   if (S == 0 || L == 0) return 0;
@@ -674,15 +683,18 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
     hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     attr_done = true;
   }
-#define BWD_ARGS (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, H, nx, scale, seg_sh, seg_e1
+  // dQ: one workgroup per (query head, query block); dK/dV: per (KEY/VALUE head, key block), looping over its query heads
+  const int Hkv = H / kv_group;
+  dim3 grid_kv(nxr * Hkv * S);
+#define BWD_ARGS(HH) (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, HH, nx, scale, seg_sh, seg_e1, kv_group
   if (causal) {
-    hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_ARGS);
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_ARGS(H));
     RV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid, block, DKV_LDS, st, BWD_ARGS);
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_ARGS(Hkv));
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, block, DQ_LDS, st, BWD_ARGS);
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, block, DQ_LDS, st, BWD_ARGS(H));
     RV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid, block, DKV_LDS, st, BWD_ARGS);
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_ARGS(Hkv));
   }
 #undef BWD_ARGS
   RV_CHECK_LAUNCH();

@@ -54,10 +54,23 @@ class LlavaConfig:
     select_layer: int = -2
     model_max_length: int = 2048
     pad_token_id: int = 0
+    kv_heads: Optional[int] = None      # num_key_value_heads (Mistral / Llama-3 style GQA); None = heads (LLaVA-1.5: MHA)
 
     @property
     def head_dim(self) -> int:
         return self.hidden // self.heads
+
+    @property
+    def n_kv_heads(self) -> int:
+        return self.heads if self.kv_heads is None else self.kv_heads
+
+    @property
+    def kv_dim(self) -> int:
+        return self.n_kv_heads * self.head_dim
+
+    @property
+    def kv_group(self) -> int:
+        return self.heads // self.n_kv_heads
 
     @property
     def clip_head_dim(self) -> int:
@@ -115,7 +128,11 @@ class ParamStore:
     """Flat parameter / gradient / optimizer-state buffers with named views."""
 
     def __init__(self, cfg: LlavaConfig, device, with_optimizer: bool = True, lora: Optional[LoraConfig] = None):
-        d, f, V, cd = cfg.hidden, cfg.ffn, cfg.vocab, cfg.clip_hidden
+        d, f, V, cd, kvd = cfg.hidden, cfg.ffn, cfg.vocab, cfg.clip_hidden, cfg.kv_dim
+        if cfg.heads % cfg.n_kv_heads != 0:
+            raise ValueError("kv_heads must divide heads")
+        if lora is not None and kvd != d:
+            raise NotImplementedError("LoRA with grouped-query attention: the fused q|k|v adapter groups assume equal widths")
         Entry = Tuple[str, Tuple[int, ...], bool]        # (key, shape, needs transposed copy); fused keys map to HF names
         self.lora = lora
         proj_w: List[Entry] = [("model.mm_projector.2.weight", (d, d), True), ("model.mm_projector.0.weight", (d, cd), False)]
@@ -123,7 +140,7 @@ class ParamStore:
         base_w: List[Entry] = [("lm_head.weight", (V, d), True)]
         for i in reversed(range(cfg.layers)):
             base_w += [(f"layers.{i}.wdown", (d, f), True), (f"layers.{i}.wgu", (2 * f, d), True),
-                       (f"layers.{i}.wo", (d, d), True), (f"layers.{i}.wqkv", (3 * d, d), True)]
+                       (f"layers.{i}.wo", (d, d), True), (f"layers.{i}.wqkv", (d + 2 * kvd, d), True)]
         base_w += [("model.embed_tokens.weight", (V, d), False)]
         norms: List[Entry] = [("model.norm.weight", (d,), False)]
         for i in reversed(range(cfg.layers)):
@@ -228,13 +245,13 @@ class ParamStore:
     # ---- HF state-dict mapping ------------------------------------------------------------
     def hf_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int]]:
         """HF name -> (store key, first row, n rows) for the language model + projector."""
-        d, f = cfg.hidden, cfg.ffn
+        d, f, kvd = cfg.hidden, cfg.ffn, cfg.kv_dim
         m: Dict[str, Tuple[str, int, int]] = {}
         for i in range(cfg.layers):
             p = f"model.layers.{i}."
             m[p + "self_attn.q_proj.weight"] = (f"layers.{i}.wqkv", 0, d)
-            m[p + "self_attn.k_proj.weight"] = (f"layers.{i}.wqkv", d, d)
-            m[p + "self_attn.v_proj.weight"] = (f"layers.{i}.wqkv", 2 * d, d)
+            m[p + "self_attn.k_proj.weight"] = (f"layers.{i}.wqkv", d, kvd)
+            m[p + "self_attn.v_proj.weight"] = (f"layers.{i}.wqkv", d + kvd, kvd)
             m[p + "self_attn.o_proj.weight"] = (f"layers.{i}.wo", 0, d)
             m[p + "mlp.gate_proj.weight"] = (f"layers.{i}.wgu", 0, f)
             m[p + "mlp.up_proj.weight"] = (f"layers.{i}.wgu", f, f)
@@ -577,8 +594,8 @@ class LlavaDPOModel:
         S, L = plan.S, plan.L
         xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
         qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0)
-        ops.rope_inplace(qkv, cos, sin, L, 2 * H, hd, pos=plan.pos)
-        attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
+        ops.rope_inplace(qkv, cos, sin, L, H + cfg.n_kv_heads, hd, pos=plan.pos)      # q heads then k heads
+        attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, d + cfg.kv_dim, seg=plan.seg, kv_group=cfg.kv_group)
         x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
         xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
         gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2)
@@ -714,9 +731,10 @@ class LlavaDPOModel:
                                      dres=dx)
             del dxn2
             dattn = self._proj_bwd(dx_mid, c["attn"], c["t_o"], i, "o", drop_slot=1, xd=c["xd_o"])
-            dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, 2 * d, seg=plan.seg)
+            dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, d + cfg.kv_dim,
+                                seg=plan.seg, kv_group=cfg.kv_group)
             del dattn
-            ops.rope_inplace(dqkv, cos, sin, L, 2 * H, hd, backward=True, pos=plan.pos)
+            ops.rope_inplace(dqkv, cos, sin, L, H + cfg.n_kv_heads, hd, backward=True, pos=plan.pos)
             xn = c["xn"] if c["xn"] is not None else \
                 ops.rmsnorm_fwd(c["x"], st.p(f"layers.{i}.ln1"), cfg.rms_eps, want_rstd=False)[0]
             c["xn"] = None

@@ -296,19 +296,20 @@ def gelu_bwd(dy, x):
 
 # ------------------------------------------------------------------------------------- attention
 def attn_fwd(qkv: torch.Tensor, S: int, L: int, H: int, hd: int, causal: bool, q_col0: int, k_col0: int,
-             v_col0: int, out: Optional[torch.Tensor] = None, seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-    """Returns (out [S*L, H*hd], lse [S,H,L])."""
+             v_col0: int, out: Optional[torch.Tensor] = None, seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+             kv_group: int = 1):
+    """Returns (out [S*L, H*hd], lse [S,H,L]).  kv_group > 1: grouped-query attention (H / kv_group key/value heads)."""
     _chk2d(qkv, "qkv")
     if out is None:
         out = torch.empty(S * L, H * hd, dtype=BF16, device=qkv.device)
     lse = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
     hip.call("rv_attn_fwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, out, out.stride(0), lse, S, L, H, hd,
-             int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None, seg[1] if seg else None)
+             int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None, seg[1] if seg else None, int(kv_group))
     return out, lse
 
 
 def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv: Optional[torch.Tensor] = None,
-             seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+             seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, kv_group: int = 1):
     """Returns dqkv with dQ/dK/dV written at the qkv column offsets."""
     _chk2d(qkv, "qkv"), _chk2d(o, "o"), _chk2d(do, "do")
     if dqkv is None:
@@ -317,7 +318,7 @@ def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv:
     hip.call("rv_attn_delta", do, do.stride(0), o, o.stride(0), delta, S, L, H, hd)
     hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, do, do.stride(0), lse, delta, dqkv,
              dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None,
-             seg[1] if seg else None)
+             seg[1] if seg else None, int(kv_group))
     return dqkv
 
 

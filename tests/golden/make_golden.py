@@ -54,7 +54,7 @@ def build_reference_model(cfg: O.LlavaCfg, W):
                    "image_std": [0.26862954, 0.26130258, 0.27577711],
                    "image_processor_type": "CLIPImageProcessor"}, f)
     lcfg = LlavaConfig(hidden_size=cfg.hidden, intermediate_size=cfg.ffn, num_hidden_layers=cfg.layers,
-                       num_attention_heads=cfg.heads, num_key_value_heads=cfg.heads, vocab_size=cfg.vocab,
+                       num_attention_heads=cfg.heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab,
                        rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
                        max_position_embeddings=4096, pad_token_id=None, attn_implementation="eager")
     model = LlavaLlamaForCausalLM(lcfg)
@@ -125,6 +125,10 @@ def run_case(name, cfg, n_pairs, text_len, prompt_len, seed, dpo_use_average=Fal
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    # grouped-query attention (num_key_value_heads < heads) through the same reference classes
+    run_case("tiny_b2_gqa", O.tiny_gqa_cfg(), n_pairs=2, text_len=40, prompt_len=12, seed=4)
+    if "--gqa-only" in sys.argv:
+        sys.exit(0)
     cfg = O.tiny_cfg()
     run_case("tiny_b2", cfg, n_pairs=2, text_len=40, prompt_len=12, seed=1)
     run_case("tiny_b3_avg_sft", cfg, n_pairs=3, text_len=56, prompt_len=16, seed=2,

@@ -372,6 +372,31 @@ def test_attn_bwd(ops, causal, L):
         close(dqkv[:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"attn bwd d{nm} L{L} causal={causal}")
 
 
+@pytest.mark.parametrize("H,G,causal,L", [(4, 2, True, 200), (8, 4, True, 130), (4, 4, False, 97), (6, 3, True, 257)])
+def test_attn_gqa_fwd_bwd(ops, H, G, causal, L):
+    """Grouped-query attention (HF repeat_kv): H query heads on H/G key/value heads; dK/dV sum over the group."""
+    dev = _dev()
+    S, hd = 2, 128
+    Hkv = H // G
+    width = (H + 2 * Hkv) * hd
+    qkv = rnd(S * L, width, seed=L + H, dev=dev, scale=0.7)
+    do = rnd(S * L, H * hd, seed=L + 1, dev=dev)
+    kc, vc = H * hd, (H + Hkv) * hd
+    out, lse = ops.attn_fwd(qkv, S, L, H, hd, causal, 0, kc, vc, kv_group=G)
+    dqkv = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, causal, 0, kc, vc, kv_group=G)
+    qf = qkv.float().requires_grad_(True)
+    q = qf[:, :kc].view(S, L, H, hd).transpose(1, 2)
+    k = qf[:, kc:vc].view(S, L, Hkv, hd).transpose(1, 2).repeat_interleave(G, dim=1)
+    v = qf[:, vc:].view(S, L, Hkv, hd).transpose(1, 2).repeat_interleave(G, dim=1)
+    ro, rl = _attn_ref(q, k, v, causal)
+    close(out, ro.transpose(1, 2).reshape(S * L, H * hd), rel=2e-2, what=f"gqa fwd H{H} G{G}")
+    torch.testing.assert_close(lse, rl.detach(), rtol=1e-3, atol=2e-3)
+    ro.transpose(1, 2).reshape(S * L, H * hd).backward(do.float())
+    for nm, sl in (("q", slice(0, kc)), ("k", slice(kc, vc)), ("v", slice(vc, width))):
+        close(dqkv[:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"gqa bwd d{nm} H{H} G{G} L{L}")
+    assert torch.equal(ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, causal, 0, kc, vc, kv_group=G), dqkv)
+
+
 def _packed_mask(L, sh, e1, dev):
     i = torch.arange(L, device=dev)[:, None]
     j = torch.arange(L, device=dev)[None, :]

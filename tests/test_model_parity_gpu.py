@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import dpo_oracle as O  # noqa: E402
 
-CASES = ["tiny_b2", "tiny_b3_avg_sft", "tiny_b2_trunc"]
+CASES = ["tiny_b2", "tiny_b3_avg_sft", "tiny_b2_trunc", "tiny_b2_gqa"]
 
 
 def _need_gpu():
@@ -84,7 +84,7 @@ def test_forward_matches_reference_golden(golden_dir, name, monkeypatch, share_p
 
 
 @pytest.mark.parametrize("share_prefix", [False, True])
-@pytest.mark.parametrize("name", CASES[:2])
+@pytest.mark.parametrize("name", [CASES[0], CASES[1], CASES[3]])
 def test_backward_matches_reference_golden(golden_dir, name, monkeypatch, share_prefix):
     _need_gpu()
     g = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)

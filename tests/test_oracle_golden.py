@@ -7,7 +7,7 @@ import torch
 
 from oracle import dpo_oracle as O
 
-CASES = ["tiny_b2", "tiny_b3_avg_sft", "tiny_b2_trunc"]
+CASES = ["tiny_b2", "tiny_b3_avg_sft", "tiny_b2_trunc", "tiny_b2_gqa"]
 
 
 def _load(golden_dir, name):
@@ -38,7 +38,7 @@ def test_oracle_matches_reference_forward(golden_dir, name):
     torch.testing.assert_close(out["loss"], g["loss"], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("name", CASES[:2])
+@pytest.mark.parametrize("name", [CASES[0], CASES[1], CASES[3]])
 def test_oracle_matches_reference_backward(golden_dir, name):
     g = _load(golden_dir, name)
     cfg = O.LlavaCfg(**g["cfg"])
