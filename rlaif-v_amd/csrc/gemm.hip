@@ -270,13 +270,21 @@ int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const
               (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols};
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, 1.0f};
   static bool attr_done = false;
+  static int use_a64 = 1;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_nn_256_kernel<EpiStore, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    const char* e = getenv("RV_GEMM_NN_A64");
+    if (e) use_a64 = atoi(e);
     attr_done = true;
   }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
-  hipLaunchKernelGGL((gemm_nn_256_kernel<EpiStore, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES,
-                     (hipStream_t)stream, g, epi);
+  if (use_a64 && K % 64 == 0 && K2 % 64 == 0 && K >= 512)
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  else
+    hipLaunchKernelGGL((gemm_nn_256_kernel<EpiStore, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
   RV_CHECK_LAUNCH();
   return 0;
 }

@@ -912,7 +912,10 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
 #define G4_B_STAGE 16384
 #define G4_LDS_BYTES (3 * G4_A_STAGE + 4 * G4_B_STAGE)
 
-template <class Epi>
+// EXT: second contraction segment (A2 slices / B2 [K2][N], K2 % 64 == 0: the fused LoRA form).  The steady loop only
+// covers phases whose fetches lie in the main segment; the few phases around the seam and the adapter's own K2/32
+// phases run in the generic form (addresses rebuilt on the fly, full drain per phase).
+template <class Epi, bool EXT = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const smA = smem;
@@ -981,19 +984,35 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = g.K / G2_BK;            // 32-deep phases (even)
-  const int ntA = nt >> 1;               // 64-deep A tiles
-  // prologue: A0 B0 | A1 B1 B2
+  const int nt1 = g.K / G2_BK;                          // 32-deep phases of the main segment (even)
+  const int nt = nt1 + (EXT ? g.K2 / G2_BK : 0);        // + the second segment
+  const int ntA1 = nt1 >> 1, ntA = nt >> 1;             // 64-deep A tiles
+  const int a2_col0 = (EXT && g.group_cols > 0) ? (n0 / g.group_cols) * g.K2 : 0;
+  // generic sources (any tile of either segment), rebuilt per piece
+  auto a_tile_src = [&](int T, int i) -> const bf16_t* {          // piece i (0..3) of A tile T
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((row >> 1) & 7);
+    const long mrow = min(m0 + row, g.M - 1);
+    if (EXT && T >= ntA1) return g.A2 + mrow * g.lda2 + a2_col0 + (long)(T - ntA1) * 64 + kc * 8;
+    return g.A + mrow * g.lda + (long)T * 64 + kc * 8;
+  };
+  auto b_tile_src = [&](int t, int i) -> const bf16_t* {          // piece i (0..1) of B tile t
+    const int r = (wave * 2 + i) * 2 + (lane >> 5), c = lane & 31;
+    const int col = min(n0 + (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3), g.N - 8);
+    if (EXT && t >= nt1) return g.B2 + ((long)(t - nt1) * G2_BK + r) * g.ldb2 + col;
+    return g.B + ((long)t * G2_BK + r) * ldb + col;
+  };
+  // prologue: A0 B0 | A1 B1 B2  (K >= 256 is required by the launcher, so these all lie in the main segment)
 #pragma unroll
   for (int i = 0; i < 4; ++i) issue_a(0, i, a_src[i]);
 #pragma unroll
   for (int i = 0; i < 2; ++i) issue_b(0, i, b_src[i]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) issue_a(1, i, a_src[i] + (ntA > 1 ? 64 : 0));
+  for (int i = 0; i < 4; ++i) issue_a(1, i, a_src[i] + (ntA1 > 1 ? 64 : 0));
 #pragma unroll
   for (int i = 0; i < 2; ++i) issue_b(1, i, b_src[i] + (long)G2_BK * ldb);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt > 2 ? 2 : 1) * G2_BK * ldb);
+  for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt1 > 2 ? 2 : 1) * G2_BK * ldb);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
@@ -1012,10 +1031,10 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) a_pre[ks] = a_row_off + (uint32_t)((((ks * 2 + half) ^ a_sw)) << 4);
 
-  // One phase.  MODE (compile time): 1 = steady (issues 2 A + 2 B pieces, counted wait), 0 = tail (no A; B pieces only
-  // when `b_too`; drains completely).  Only three instantiations exist (steady even, steady odd, tail): more copies of
+  // One phase.  MODE (compile time): 1 = steady (issues 2 A + 2 B pieces from the running pointers, counted wait),
+  // 0 = generic (issues whatever tiles still exist - B tile p+3, with EXT also A tile (p>>1)+2 - and drains completely).  Only three instantiations exist (steady even, steady odd, tail): more copies of
   // the segment made hipcc spill the accumulators.
-  auto phase = [&](const int p, const int h, auto hc, auto mode_c, const bool b_too) {
+  auto phase = [&](const int p, const int h, auto hc, auto mode_c) {
     constexpr int H = decltype(hc)::value;              // = h in steady phases (selects the A pieces to issue)
     constexpr int MODE = decltype(mode_c)::value;
     const uint8_t* stA = smA + ((p >> 1) % 3) * G4_A_STAGE;
@@ -1057,8 +1076,10 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
             if (MODE == 1) {
               if ((j & 1) == 0) issue_a((p >> 1) + 2, 2 * H + (j >> 1), a_run[2 * H + (j >> 1)]);
               else issue_b(p + 3, j >> 1, b_run[j >> 1]);
-            } else if ((j & 1) == 1 && b_too) {
-              issue_b(p + 3, j >> 1, b_run[j >> 1]);
+            } else if ((j & 1) == 1) {
+              if (p + 3 < nt) issue_b(p + 3, j >> 1, b_tile_src(p + 3, j >> 1));
+            } else if (EXT) {
+              if ((p >> 1) + 2 < ntA) issue_a((p >> 1) + 2, 2 * h + (j >> 1), a_tile_src((p >> 1) + 2, 2 * h + (j >> 1)));
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -1070,17 +1091,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  // steady pairs: p + 4 < nt (A tile (p>>1)+2 <= ntA-1 and B tiles p+3, p+4 <= nt-1 exist)
+  // steady pairs: p + 4 < nt1 (A tile (p>>1)+2 and B tiles p+3, p+4 exist and lie in the main segment)
   int p = 0;
-  for (; p + 4 < nt; p += 2) {
-    phase(p, 0, I0{}, I1{}, false);
+  for (; p + 4 < nt1; p += 2) {
+    phase(p, 0, I0{}, I1{});
     b_run[0] += G2_BK * ldb; b_run[1] += G2_BK * ldb;
-    phase(p + 1, 1, I1{}, I1{}, false);
+    phase(p + 1, 1, I1{}, I1{});
     b_run[0] += G2_BK * ldb; b_run[1] += G2_BK * ldb;
     a_run[0] += 64; a_run[1] += 64; a_run[2] += 64; a_run[3] += 64;
   }
-  // tail: phase nt-4 still fetches the last B tile; every tail phase drains completely before its barrier
-  for (; p < nt; ++p) phase(p, p & 1, I0{}, I0{}, p + 4 == nt);
+  // tail / seam: generic phases (without EXT only phase nt-4 still has something to fetch: the last B tile)
+  for (; p < nt; ++p) phase(p, p & 1, I0{}, I0{});
   if (wm == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count
 
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
