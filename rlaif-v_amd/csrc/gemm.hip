@@ -15,6 +15,11 @@ void rv_set_error(const char* msg) {
 // -1 (default) = pick 2 when the problem fills the chip with 256x256 tiles, else 1.
 static int g_default_variant = -1;
 static int g_group = 0;     // experiment knob: RV_GEMM_GROUP
+static int epi_narrow() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RV_EPI_WIDE"); v = (e && atoi(e) == 0) ? 1 : 0; }
+  return v;
+}
 static void read_group_env() {
   static bool env_done = false;
   if (!env_done) { const char* e = getenv("RV_GEMM_GROUP"); if (e) g_group = atoi(e); env_done = true; }
@@ -191,6 +196,7 @@ int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   if (check_shape(g, "rv_gemm_nt_bf16")) return 1;
   RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_bf16: ldc/ldr must be multiples of 4");
   EpiStore epi{(bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, alpha};
+  epi.narrow = epi_narrow();
   return dispatch(g, epi, variant, stream);
 }
 
@@ -203,6 +209,7 @@ int rv_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, void* C, l
              "rv_gemm_tn_bf16: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
   RV_REQUIRE((((uintptr_t)P | (uintptr_t)Q) & 15) == 0, "rv_gemm_tn_bf16: P/Q must be 16-byte aligned");
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
+  epi.narrow = epi_narrow();
   return launch_gemm_tn((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, R, I, J, epi, (hipStream_t)stream);
 }
 
@@ -220,6 +227,7 @@ int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const
              "rv_gemm_nt_lora_bf16: group_cols must be 0 or a multiple of 128 that divides N");
   RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_lora_bf16: ldc/ldr must be multiples of 4");
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, 1.0f};
+  epi.narrow = epi_narrow();
   return dispatch_ext(g, epi, stream);
 }
 
@@ -234,6 +242,7 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   read_group_env();
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
+  epi.narrow = epi_narrow();
   static bool attr_done = false;
   static int use_a64 = 1;          // RV_GEMM_NN_A64=0: 32-deep A tiles (gemm_nn_256_kernel) also when K % 64 == 0
   if (!attr_done) {
@@ -269,6 +278,7 @@ int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group,
               (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols};
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, 1.0f};
+  epi.narrow = epi_narrow();
   static bool attr_done = false;
   static int use_a64 = 1;
   if (!attr_done) {
@@ -298,6 +308,7 @@ int rv_gemm_nt_dropout_bf16(const void* A, long lda, const void* B, long ldb, vo
   RV_REQUIRE(N % 8 == 0, "rv_gemm_nt_dropout_bf16: N must be a multiple of 8 (mask layout of rv_dropout)");
   RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_dropout_bf16: ldc/ldr must be multiples of 4");
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
+  epi.narrow = epi_narrow();
   epi.drop_thresh16 = (uint32_t)((double)p * 65536.0 + 0.5);
   epi.drop_key = (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu;
   epi.drop_inv_keep = 1.f / (1.f - p);

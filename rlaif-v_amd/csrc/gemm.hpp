@@ -1115,6 +1115,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
 enum { RV_ACT_NONE = 0, RV_ACT_QUICK_GELU = 1, RV_ACT_GELU = 2 };
 
 // C[m][n] = act(acc + bias[n]) + R[m][n]   (bf16 out; bias/R optional)
+__device__ __forceinline__ void epi_unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = bf2f((bf16_t)(v.x & 0xffff)); f[1] = bf2f((bf16_t)(v.x >> 16));
+  f[2] = bf2f((bf16_t)(v.y & 0xffff)); f[3] = bf2f((bf16_t)(v.y >> 16));
+  f[4] = bf2f((bf16_t)(v.z & 0xffff)); f[5] = bf2f((bf16_t)(v.z >> 16));
+  f[6] = bf2f((bf16_t)(v.w & 0xffff)); f[7] = bf2f((bf16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 epi_pack8(const float (&f)[8]) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
 __device__ __forceinline__ uint32_t gemm_mix32(uint32_t h) {    // same mixer as dropout_kernel (elementwise.hip)
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
@@ -1130,7 +1142,70 @@ struct EpiStore {
   // rv_dropout for a contiguous [M][N] tensor with the same (p, seed); drop_thresh16 = 0 disables it
   uint32_t drop_thresh16 = 0, drop_key = 0;
   float drop_inv_keep = 1.f;
+  int narrow = 0;            // 1: force the 8-byte store path (A/B knob RV_EPI_WIDE=0)
+  // 16-byte stores: lanes l and l+32 hold the two 4-column halves of the same row's 8-column groups; one exchange per
+  // value turns {cols 0-3 | 8-11} + {cols 4-7 | 12-15} into {0-7} + {8-15}, halving the number of store (and residual
+  // load) instructions - the epilogue of a 1-workgroup-per-CU kernel is store-ISSUE bound and nothing overlaps it.
+  __device__ __forceinline__ void apply_wide(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = mw + tm * 32 + (lane & 31);
+      if (m >= M) continue;                       // lanes l and l+32 share m: partners skip together
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int rgp = 0; rgp < 2; ++rgp) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = acc[tm][tn][(2 * rgp) * 4 + j] * alpha, b = acc[tm][tn][(2 * rgp + 1) * 4 + j] * alpha;
+            const float recv = __shfl_xor(half ? a : b, 32);
+            v[j] = half ? recv : a;
+            v[4 + j] = half ? b : recv;
+          }
+          const int n = nw + tn * 32 + rgp * 16 + 8 * half;
+          if (n >= N) continue;
+          if (bias) {
+            float bb[8];
+            epi_unpack8(*(const uint4*)(bias + n), bb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += bb[j];
+          }
+          if (act == RV_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
+          } else if (act == RV_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+          }
+          if (drop_thresh16) {
+            const long e = (long)m * N + n;
+            const uint32_t base = (uint32_t)(e >> 33) * 0x9e3779b9u + drop_key;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t h = gemm_mix32(((uint32_t)(e >> 1) + (uint32_t)q) ^ base);
+              v[2 * q] = ((h & 0xffffu) >= drop_thresh16) ? v[2 * q] * drop_inv_keep : 0.f;
+              v[2 * q + 1] = ((h >> 16) >= drop_thresh16) ? v[2 * q + 1] * drop_inv_keep : 0.f;
+            }
+          }
+          if (R) {
+            float rr[8];
+            epi_unpack8(*(const uint4*)(R + (long)m * ldr + n), rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
+          }
+          *(uint4*)(C + (long)m * ldc + n) = epi_pack8(v);
+        }
+      }
+    }
+  }
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+    if (!narrow && ((ldc | N) & 7) == 0 && (((uintptr_t)C | (uintptr_t)bias) & 15) == 0 &&
+        (R == nullptr || ((ldr & 7) == 0 && ((uintptr_t)R & 15) == 0))) {
+      apply_wide(acc, mw, nw, lane, M, N);
+      return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int m = mw + tm * 32 + (lane & 31);
