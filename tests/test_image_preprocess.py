@@ -42,6 +42,24 @@ def test_coefficient_tables_properties():
     assert t.shape == (3, 256) and np.all(np.diff(t, axis=1) > 0)
 
 
+def test_product_tap_tables_equal_the_oracle():
+    """rlaif-v_amd/image.py builds the fixed-point tap tables itself (the product never imports the oracle): they must
+    be the oracle's - and therefore Pillow's - integers, and the lookup table transformers' float32 arithmetic."""
+    from rlaif_v_amd import image as img
+    for n_in, n_out in [(640, 448), (480, 336), (150, 336), (200, 448), (1024, 336), (97, 336), (411, 1423), (336, 336),
+                        (900, 336), (337, 336), (56, 56), (120, 74)]:
+        ks, b, k = img._taps(n_in, n_out)
+        ks2, b2, k2 = P.precompute_coeffs(n_in, 0.0, float(n_in), n_out)
+        assert ks == ks2 and np.array_equal(b, b2) and np.array_equal(k, k2), (n_in, n_out)
+    assert np.array_equal(img._norm_table(img.CLIP_MEAN, img.CLIP_STD, 1 / 255), P.normalize_table())
+    for h, w in [(480, 640), (640, 480), (336, 336), (97, 411), (1000, 352)]:
+        assert img.resize_output_size(h, w, 336) == P.resize_output_size(h, w, 336)
+    raw = img.RawImageProcessor()(G.make_image(30, 20, 1))
+    assert raw.dtype == np.uint8 and raw.shape == (30, 20, 3)
+    with pytest.raises(ValueError):
+        img.RawImageProcessor()(np.zeros((4, 4), dtype=np.uint8))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", list(range(len(G.CASES))))
 def test_hip_preprocess_bit_exact(case, golden_dir):
