@@ -261,7 +261,7 @@ def main():
                     traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
             except Exception:
                 pass
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nn_256_kernel / gemm_tn_256_kernel / gemm_nt_256_kernel (256x256x32 ping-pong; all rv_gemm_nn_bf16 + rv_gemm_tn_bf16 + rv_gemm_nt_bf16 launches)",
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nn_a64_kernel / gemm_tn_256_kernel (+ gemm_nn_256 / gemm_nt_256 for the shapes they serve): 256x256 ping-pong tiles; all rv_gemm_nn_bf16 + rv_gemm_tn_bf16 + rv_gemm_nt_bf16 launches",
                                 "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                 "traffic_note": "HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
