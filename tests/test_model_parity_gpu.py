@@ -278,3 +278,70 @@ def test_gradient_checkpointing_is_bit_identical():
         model.backward(model.last_out, model.last_coef)
         grads.append(model.store.flat_g.clone())
     assert torch.equal(grads[0], grads[1])
+
+
+def test_full_size_7b_properties():
+    """BASELINE config 2 at FULL size (32 layers, 7B widths, L = 2048, CLIP-L/14-336): the oracle cannot run it in
+    seconds, so parity is checked through size-independent properties of the reference (SURVEY.md section 8a [probe]):
+    (i) the log-prob of a sequence does not depend on its batch mates nor on right padding, (ii) computing the shared
+    image + prompt prefix once (packed layout) equals the reference's 2B-row layout, (iii) the forward is
+    deterministic, (iv) counts / targets are the integer-exact label arithmetic."""
+    _need_gpu()
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2**30:
+        pytest.skip("needs the 288 GB part")
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    cfg = LlavaConfig()                                  # LLaVA-1.5-7B
+    model = LlavaDPOModel(cfg, with_optimizer=False)
+    model.init_random(seed=3)
+    model.eval()
+    ocfg = O.LlavaCfg()
+    T = 2048 - 575
+    batch = O.make_synthetic_batch(ocfg, 2, T, 64, seed=17, ragged=True)
+    ids, labels, images = batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"]
+
+    def run(ids_, labels_, images_, share):
+        model.share_prefix = share
+        o = model.forward_logps(ids_, labels_, images_, save_for_backward=False)
+        return o.seq_logp.cpu().clone(), o.seq_cnt.cpu().clone(), o
+
+    lp_packed, cnt, out = run(ids, labels, images, True)
+    assert out.plan.S == 2 and out.plan.L > 2048 and min(out.plan.shared_len) >= 575 + 60       # really packed, full length
+    lp_again, _, _ = run(ids, labels, images, True)
+    assert torch.equal(lp_packed, lp_again)                                                     # (iii)
+    lp_plain, cnt_plain, out2 = run(ids, labels, images, False)
+    assert out2.plan.S == 4 and out2.plan.L == 2048
+    assert torch.equal(cnt, cnt_plain)
+    assert torch.equal(cnt, (labels[:, 1:] != -100).sum(1).float())                             # (iv)
+    tol = 1e-3 * lp_plain.abs() + 5e-2
+    assert bool(((lp_packed - lp_plain).abs() <= tol).all()), (lp_packed, lp_plain)             # (ii)
+    # (i) pair 0 alone, and with 37 extra right-pad tokens (pad id 0, label -100)
+    sel = torch.tensor([0, 2])
+    lp_alone, _, _ = run(ids[sel], labels[sel], images[:1], False)
+    assert bool(((lp_alone - lp_plain[sel]).abs() <= tol[sel]).all()), (lp_alone, lp_plain[sel])
+    model.cfg.model_max_length = 2048 + 37
+    pad_ids = torch.cat([ids[sel], torch.zeros(2, 37, dtype=ids.dtype)], 1)
+    pad_lab = torch.cat([labels[sel], torch.full((2, 37), -100, dtype=labels.dtype)], 1)
+    lp_pad, _, o3 = run(pad_ids, pad_lab, images[:1], False)
+    assert o3.plan.L == 2048 + 37
+    assert bool(((lp_pad - lp_plain[sel]).abs() <= tol[sel]).all()), (lp_pad, lp_plain[sel])
+    print("full-size 7B: packed", lp_packed.tolist(), "plain", lp_plain.tolist(), "alone", lp_alone.tolist(),
+          "padded", lp_pad.tolist())
+    # (v) backward at full size: the packed layout's gradient equals the reference layout's, and is deterministic
+    model.cfg.model_max_length = 2048
+    model.train()
+    coef = torch.tensor([0.3, 0.1, -0.2, -0.4], device=model.device)
+    grads = []
+    for share in (True, False, True):
+        model.share_prefix = share
+        o = model.forward_logps(ids, labels, images, save_for_backward=True)
+        model.backward(o, coef)
+        grads.append(model.store.flat_g.clone())
+    assert torch.equal(grads[0], grads[2])
+    ab = aa = bb = 0.0
+    for lo in range(0, grads[0].numel(), 1 << 27):            # 6.76 G elements: accumulate chunk-wise in float64
+        x, y = grads[0][lo:lo + (1 << 27)].double(), grads[1][lo:lo + (1 << 27)].double()
+        ab, aa, bb = ab + float(x @ y), aa + float(x @ x), bb + float(y @ y)
+    cos = ab / ((aa ** 0.5) * (bb ** 0.5))
+    rel = abs(aa ** 0.5 - bb ** 0.5) / (bb ** 0.5)
+    print(f"full-size 7B backward: packed vs reference layout cosine {cos:.6f}, norm rel diff {rel:.2e}")
+    assert cos >= 0.999 and rel <= 1e-2
