@@ -141,11 +141,27 @@ class RLAIFVDataset(torch.utils.data.Dataset):
     def __init__(self, data_dir: str, reference_model=None, tokenizer=None, image_token_len=None, img_processor=None,
                  use_im_start_end: bool = False, is_llava15: bool = True):
         import pandas as pd
-        files = sorted(f for f in os.listdir(data_dir) if f.endswith(".parquet") and "logp" in f) if os.path.isdir(data_dir) else []
-        if not files:
-            raise FileNotFoundError(
-                f"no *logp*.parquet under {data_dir}: run rlaif_v_amd.inference_logp.inference_logp(reference_model, ...) "
-                "first (the reference downloads openbmb/RLAIF-V-Dataset here, muffin/data/datasets.py:38-50; there is no network)")
+        os.makedirs(data_dir, exist_ok=True)
+
+        def logp_files():
+            return sorted(f for f in os.listdir(data_dir) if f.endswith(".parquet") and "logp" in f)
+
+        if not logp_files():
+            # muffin/data/datasets.py:38-50: no cached reference log-probs -> compute them with the reference model.  The
+            # reference downloads openbmb/RLAIF-V-Dataset from the hub; here the raw rows are the *.parquet files (without
+            # 'logp' in the name) found under data_dir or ./RLAIF-V-Dataset (there is no network).
+            assert reference_model is not None, "`reference_model` is mandatory when logps do not exist."
+            raw = [os.path.join(d, f) for d in (data_dir, "./RLAIF-V-Dataset") if os.path.isdir(d)
+                   for f in sorted(os.listdir(d)) if f.endswith(".parquet") and "logp" not in f]
+            if not raw:
+                raise FileNotFoundError(f"no *logp*.parquet and no raw preference *.parquet under {data_dir} or ./RLAIF-V-Dataset "
+                                        "(the reference would download openbmb/RLAIF-V-Dataset here; there is no network)")
+            from .inference_logp import PreferenceInferenceDataset, inference_logp
+            rows = pd.concat([pd.read_parquet(f) for f in raw], ignore_index=True).to_dict("records")
+            inference_logp(reference_model, tokenizer,
+                           PreferenceInferenceDataset(rows, tokenizer, image_token_len, img_processor, use_im_start_end),
+                           data_dir, is_llava15=is_llava15)
+        files = logp_files()
         self.data = pd.concat([pd.read_parquet(os.path.join(data_dir, f)) for f in files], ignore_index=True).to_dict("records")
 
     def __len__(self):

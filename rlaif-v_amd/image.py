@@ -42,7 +42,7 @@ class RawImageProcessor:
         arr = np.asarray(image)
         if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
             raise ValueError(f"RawImageProcessor: expected an RGB uint8 image, got {arr.dtype} {arr.shape}")
-        return np.ascontiguousarray(arr)
+        return np.array(arr, dtype=np.uint8, order="C")          # own, writable copy (PIL hands out a read-only view)
 
 
 def resize_output_size(h: int, w: int, size: int) -> Tuple[int, int]:

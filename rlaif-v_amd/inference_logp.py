@@ -49,6 +49,34 @@ class InferenceSampler(torch.utils.data.sampler.Sampler):
         return len(self._local_indices)
 
 
+class PreferenceInferenceDataset(torch.utils.data.Dataset):
+    """muffin/eval/muffin_inference_logp.py:116-165: raw preference rows -> (rej_dict, win_dict) of token ids."""
+
+    def __init__(self, data, tokenizer, image_token_len, img_processor, use_im_start_end: bool = True):
+        self.data = data
+        self.mm_cfg = {"image_processor": img_processor, "is_multimodal": True, "image_token_len": image_token_len,
+                       "use_im_start_end": use_im_start_end, "keep_image_tag": True}
+        self.tokenizer = tokenizer
+
+    def __getitem__(self, index):
+        from .dataset import bytes_to_PIL_image, encode_multimodal_preference_sample, preprocess_v1
+        sample = self.data[index]
+        split = sample.get("origin_split")
+        metainfo = {"origin_dataset": sample.get("origin_dataset"),
+                    "origin_split": json.loads(split) if isinstance(split, str) and split[:1] in "[{\"" else split,
+                    "origin_idx": sample["idx"], "image_id": sample.get("image_path")}
+        formated_sample = {"image": bytes_to_PIL_image(sample["image"]["bytes"]),
+                           "question": {"from": "human", "value": f"<image>\n{sample['question']}"},
+                           "chosen": {"from": "gpt", "value": sample["chosen"]},
+                           "rejected": {"from": "gpt", "value": sample["rejected"]},
+                           "idx": sample["idx"], "metainfo": metainfo}
+        return encode_multimodal_preference_sample(formated_sample, self.tokenizer, self.mm_cfg,
+                                                   preprocess_func=lambda s, t: preprocess_v1(s, t, has_image=True))
+
+    def __len__(self):
+        return len(self.data)
+
+
 def get_multimodal_sample_logps(model, dataloader, tokenizer=None, is_llava15: bool = True):
     """Returns (win_logp, win_avg_logp, win_per_token_logp, rej_logp, rej_avg_logp, rej_per_token_logp) as Python
     lists, one entry per sample; per-token lists have spliced_length - 1 entries like the reference's."""
