@@ -300,5 +300,7 @@ def test_sample_encoding_matches_reference_golden(golden_dir, tmp_path):
     batch = DataCollatorForDPODataset(tok, beta=0.1, mod_token_weight=1.0)([ds[i] for i in range(3)])
     assert batch["images"].shape == (3, 3, 4, 4) and batch["ref_win_logp"].tolist() == [-5.0, -6.0, -7.0]
     assert batch["concatenated_input_ids"].shape[0] == 6 and (batch["concatenated_input_ids"] == -200).sum() == 6
-    with pytest.raises(FileNotFoundError):
+    with pytest.raises(AssertionError, match="reference_model"):       # muffin/data/datasets.py:39 (same message)
         DPODataset(tok, str(tmp_path / "empty"), {})
+    with pytest.raises(FileNotFoundError):                             # reference model given, but no raw rows to score (no hub)
+        DPODataset(tok, str(tmp_path / "empty2"), {}, reference_model=object())
