@@ -229,9 +229,10 @@ def test_transpose(ops):
 
 
 # ------------------------------------------------------------------------------------------- norms
-def test_rmsnorm_fwd_bwd(ops):
+@pytest.mark.parametrize("rows,d", [(333, 512), (1000, 1280), (5000, 4096), (3, 4096), (700, 5120)])
+def test_rmsnorm_fwd_bwd(ops, rows, d):
+    """Row lengths from one 2048-column pass to three (d = 5120), ragged row counts."""
     dev = _dev()
-    rows, d = 333, 512
     x, w, dy, dres = rnd(rows, d, seed=1, dev=dev), (1 + 0.1 * rnd(d, seed=2, dev=dev).float()).to(BF), \
         rnd(rows, d, seed=3, dev=dev), rnd(rows, d, seed=4, dev=dev)
     y, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
