@@ -67,7 +67,7 @@ static int launch_gemm_tn_d(const bf16_t* P, long ldp, const bf16_t* Q, long ldq
   }
   const int tiles_i = (I + 255) / 256, tiles_j = (J + 255) / 256;
   hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST>), dim3(tiles_i * tiles_j, splits), dim3(G2_THREADS), LDS, st, P,
-                     ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride);
+                     ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride, g_group);
   RV_CHECK_LAUNCH();
   return 0;
 }
@@ -76,6 +76,7 @@ template <class Epi>
 static int launch_gemm_tn(const bf16_t* P, long ldp, const bf16_t* Q, long ldq, int R, int I, int J, const Epi& epi,
                           hipStream_t st, int splits = 1, int r_chunk = 0, long split_stride = 0) {
   static bool env_done = false;
+  read_group_env();
   if (!env_done) { const char* e = getenv("RV_GEMM_TN_DIST"); if (e && atoi(e) == 4) g_tn_dist = 4; env_done = true; }
   if (g_tn_dist == 3) return launch_gemm_tn_d<Epi, 3>(P, ldp, Q, ldq, R, I, J, epi, st, splits, r_chunk, split_stride);
   return launch_gemm_tn_d<Epi, 4>(P, ldp, Q, ldq, R, I, J, epi, st, splits, r_chunk, split_stride);
