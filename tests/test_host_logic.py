@@ -304,3 +304,33 @@ def test_sample_encoding_matches_reference_golden(golden_dir, tmp_path):
         DPODataset(tok, str(tmp_path / "empty"), {})
     with pytest.raises(FileNotFoundError):                             # reference model given, but no raw rows to score (no hub)
         DPODataset(tok, str(tmp_path / "empty2"), {}, reference_model=object())
+
+
+def test_entrypoint_flag_surface():
+    """script/train/llava15_train.sh and llava15_train_lora.sh flag lines parse into the reference's three argument
+    dataclasses (muffin/train/train_llava15.py:32-100, train_llava15_lora.py:111-116); control-plane flags are ignored."""
+    from rlaif_v_amd import train_llava15 as T
+    common = ("--deepspeed ./script/zero2.json --model_name_or_path liuhaotian/llava-v1.5-7b --data_dir ./RLAIF-V-Dataset_logps/ "
+              "--image_folder not_used --vision_tower openai/clip-vit-large-patch14-336 --mm_use_im_start_end False "
+              "--mm_use_im_patch_token False --image_aspect_ratio pad --bf16 True --mm_projector_type mlp2x_gelu "
+              "--mm_vision_select_layer -2 --output_dir .ckpt/x --num_train_epochs 10 --per_device_train_batch_size 1 "
+              "--per_device_eval_batch_size 4 --gradient_accumulation_steps 1 --evaluation_strategy no --save_strategy steps "
+              "--save_steps 167 --save_total_limit 50 --data_source_names x --data_source_weights 1 --max_steps 2672 "
+              "--weight_decay 0.01 --warmup_ratio 0.05 --lr_scheduler_type cosine --logging_steps 2 --logging_dir .ckpt/log "
+              "--tf32 True --model_max_length 2048 --gradient_checkpointing True --lazy_preprocess True --task DPO "
+              "--report_to wandb --run_name x --dataloader_num_workers 16 --dpo_use_average False --dpo_token_weighted False "
+              "--dpo_token_weight 1.0 --dpo_beta 0.1")
+    m, d, t = T.parse_args((common + " --fully_tune True --learning_rate 5e-7").split())
+    assert (m.mm_vision_select_layer, m.mm_projector_type, m.version) == (-2, "mlp2x_gelu", "llava_v1")
+    assert (d.dpo_beta, d.dpo_token_weight, d.image_aspect_ratio, d.lazy_preprocess) == (0.1, 1.0, "pad", True)
+    assert (t.task, t.max_steps, t.learning_rate, t.warmup_ratio, t.model_max_length, t.save_steps, t.bf16) == \
+        ("DPO", 2672, 5e-7, 0.05, 2048, 167, True)
+    assert t.fully_tune and t.gradient_checkpointing and not t.lora_enable and t.lora_config() is None
+    m, d, t = T.parse_args((common + " --fully_tune False --learning_rate 1e-5 --lora_enable True").split())
+    lc = t.lora_config()
+    assert t.lora_enable and (lc.r, lc.lora_alpha, lc.lora_dropout, lc.bias) == (64, 16, 0.05, "none") and lc.scaling == 0.25
+    # dataclass defaults are the reference's
+    assert T.DataArguments().dpo_beta == 0.5 and T.DataArguments().dpo_token_weight == 3.0
+    assert T.ModelArguments().mm_vision_select_layer == -1 and T.TrainingArguments().task == "LM"
+    with pytest.raises(NotImplementedError):
+        T.init_model(T.ModelArguments(), T.DataArguments(), T.TrainingArguments(task="LM"))
