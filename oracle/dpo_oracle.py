@@ -474,6 +474,21 @@ def get_batch_logps(logits: torch.Tensor, labels: torch.Tensor, return_all: bool
     return log_prob, avg
 
 
+def get_batch_logps_minicpm(logits: torch.Tensor, labels: torch.Tensor, return_all: bool = False):
+    """muffin/eval/muffin_inference_logp.py:21-52: the MiniCPM data pipeline pre-shifts its labels, so position t of
+    the logits is scored against labels[:, t] (labels[:, :-1] vs logits[:, :-1])."""
+    labels = labels[:, :-1].clone()
+    logits = logits[:, :-1, :]
+    loss_mask = labels != IGNORE_INDEX
+    labels[labels == IGNORE_INDEX] = 0
+    per_token = torch.gather(logits.log_softmax(-1), 2, labels.unsqueeze(2)).squeeze(2)
+    log_prob = (per_token * loss_mask).sum(-1)
+    avg = log_prob / loss_mask.sum(-1)
+    if return_all:
+        return per_token, log_prob, avg
+    return log_prob, avg
+
+
 def dpo_loss(pw, pr, rw, rr, beta: float, reference_free: bool = False):
     """muffin/train/trainers.py:91-126."""
     ref = 0 if reference_free else (rw - rr)

@@ -613,7 +613,7 @@ class LlavaDPOModel:
 
     # ------------------------------------------------------------------ forward
     def forward_logps(self, input_ids: torch.Tensor, labels: torch.Tensor, images: torch.Tensor,
-                      save_for_backward: bool = True, all_rows: bool = False) -> StepOutput:
+                      save_for_backward: bool = True, all_rows: bool = False, label_shift: int = 1) -> StepOutput:
         """Everything of get_beta_and_logps up to ``get_batch_logps``: returns per-sequence log-prob sums
         and counts (muffin/eval/muffin_inference_logp.py:82-115) without materialising logits.
         ``all_rows`` (forward only, reference layout): evaluate EVERY position like
@@ -638,6 +638,9 @@ class LlavaDPOModel:
             plan.seq_of_row = torch.arange(S_).repeat_interleave(Lm1).to(torch.int32)
             plan.n_sel = int(plan.sel_idx.numel())
             w_rows = (nxt != -100).reshape(-1).to(torch.float32).to(self.device)     # loss_mask of get_batch_logps
+        elif label_shift != 1:
+            # get_batch_logps_minicpm convention (labels pre-shifted, muffin_inference_logp.py:21-52): reference layout only
+            plan = build_splice_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length, label_shift=label_shift)
         elif self.share_prefix and input_ids.shape[0] == 2 * B:
             plan = build_packed_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length, cfg.pad_token_id)
         else:

@@ -127,9 +127,13 @@ def _tables(flat: torch.Tensor, n_feat_rows: int):
 
 
 def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
-                      max_len: Optional[int]) -> SplicePlan:
+                      max_len: Optional[int], label_shift: int = 1) -> SplicePlan:
     """Reference layout.  input_ids/labels: int64 [S, T] (the collator's ``concatenated_*`` tensors);
-    ``n_images`` distinct images were encoded (one per pair)."""
+    ``n_images`` distinct images were encoded (one per pair).  label_shift = 1: get_batch_logps
+    (labels[:, 1:] vs logits[:, :-1], muffin_inference_logp.py:93-94); 0: get_batch_logps_minicpm (labels already
+    shifted by the data pipeline: labels[:, :-1] vs logits[:, :-1], :32-33)."""
+    if label_shift not in (0, 1):
+        raise ValueError("label_shift must be 0 (minicpm) or 1 (llava / omnilmm)")
     input_ids = input_ids.cpu().long()
     labels = labels.cpu().long()
     S = input_ids.shape[0]
@@ -142,8 +146,8 @@ def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
         src_full[r, :n] = rows_src[r]
         lab_full[r, :n] = rows_lab[r]
 
-    # rows whose next-position label is a target (labels[:,1:] vs logits[:,:-1])
-    nxt = lab_full[:, 1:]
+    # rows whose next-position label is a target (labels[:,1:] vs logits[:,:-1]; minicpm: labels[:,:-1])
+    nxt = lab_full[:, 1:] if label_shift == 1 else lab_full[:, :-1]
     mask = nxt != IGNORE_INDEX                                             # [S, L-1]
     s_idx, l_idx = torch.nonzero(mask, as_tuple=True)                      # row-major order: by s then l
     sel = (s_idx * L + l_idx).to(torch.int32)

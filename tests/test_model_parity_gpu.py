@@ -345,3 +345,22 @@ def test_full_size_7b_properties():
     rel = abs(aa ** 0.5 - bb ** 0.5) / (bb ** 0.5)
     print(f"full-size 7B backward: packed vs reference layout cosine {cos:.6f}, norm rel diff {rel:.2e}")
     assert cos >= 0.999 and rel <= 1e-2
+
+
+def test_minicpm_label_convention_matches_oracle():
+    """get_batch_logps_minicpm (labels pre-shifted: labels[:, :-1] vs logits[:, :-1]) through the fused LM head."""
+    _need_gpu()
+    cfg = O.tiny_cfg()
+    model, W = _build(O.asdict(cfg), seed=6)
+    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=12)
+    out = model.eval().forward_logps(batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"],
+                                     save_for_backward=False, label_shift=0)
+    with torch.no_grad():
+        feats = O.encode_images(torch.cat([batch["images"], batch["images"]]), W, cfg)
+        emb, lab = O.prepare_inputs_labels_for_multimodal(batch["concatenated_input_ids"], batch["concatenated_labels"], feats,
+                                                          W["model.embed_tokens.weight"], cfg.model_max_length)
+        lp, avg = O.get_batch_logps_minicpm(O.llama_logits(emb, W, cfg), lab)
+        lp_std, _ = O.get_batch_logps(O.llama_logits(emb, W, cfg), lab)
+    assert out.seq_cnt.cpu().tolist() == (lab[:, :-1] != -100).sum(1).float().tolist()
+    assert bool(((out.seq_logp.cpu() - lp).abs() <= 1e-3 * lp.abs() + 5e-2).all()), (out.seq_logp, lp)
+    assert (lp - lp_std).abs().min() > 1.0              # the two conventions really differ

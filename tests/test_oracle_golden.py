@@ -102,3 +102,22 @@ def test_adamw_matches_torch():
         O.adamw_reference(p, grads, state, 1e-3, step)
         for k in p:
             torch.testing.assert_close(p[k], ref[k].detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_logp_reductions_match_reference_functions(golden_dir):
+    """get_batch_logps, get_batch_logps_minicpm and compute_weighted_logp of the oracle against outputs of the
+    reference's own functions (tests/golden/make_logps_golden.py) - bit exact, NaN average for a target-less row."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_mk", os.path.join(golden_dir, "make_logps_golden.py"))
+    src = open(spec.origin).read()
+    ns = {}
+    exec(src[src.index("def inputs"):src.index('if __name__')], {"torch": torch}, ns)     # the input generator only
+    logits, labels, weight = ns["inputs"]()
+    g = torch.load(os.path.join(golden_dir, "logps_fns.pt"))
+    pt, lp, avg = O.get_batch_logps(logits, labels, return_all=True)
+    ptm, lpm, avgm = O.get_batch_logps_minicpm(logits, labels, return_all=True)
+    for got, key in ((pt, "per_token"), (lp, "log_prob"), (avg, "avg"), (ptm, "per_token_minicpm"), (lpm, "log_prob_minicpm"),
+                     (avgm, "avg_minicpm"), (O.compute_weighted_logp(pt, labels, weight, False), "weighted_sum"),
+                     (O.compute_weighted_logp(pt, labels, weight, True), "weighted_avg")):
+        torch.testing.assert_close(got, g[key], rtol=0, atol=0, equal_nan=True)
+    assert torch.isnan(avg[3]) and torch.isnan(avgm[3])
