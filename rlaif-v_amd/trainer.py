@@ -71,6 +71,25 @@ class TrainingArguments:
         return LoraConfig(r=self.lora_r, lora_alpha=self.lora_alpha, lora_dropout=self.lora_dropout, bias=self.lora_bias)
 
 
+def forward_DPO(model, input_ids, labels, attention_mask, images, **kwargs):
+    """trainers.py:66-88, the generic (non-LLaVA-1.5) branch of get_beta_and_logps: per-sequence log-probs - sum, or mean
+    with ``dpo_use_average`` - under the model's label convention (``is_minicpm``: labels pre-shifted), or the per-token
+    log-probs [S, L-1] when ``token_weighted`` (fed to compute_weighted_logp by the caller)."""
+    token_weighted = kwargs.pop("token_weighted", False)
+    dpo_use_average = kwargs.pop("dpo_use_average", False)
+    is_minicpm = kwargs.pop("is_minicpm", False)
+    if attention_mask is not None:
+        raise NotImplementedError("attention_mask is None on the DPO path (trainers.py:199)")
+    if token_weighted:
+        if is_minicpm:
+            raise NotImplementedError("per-token log-probs under the minicpm label convention")
+        out = model.forward_logps(input_ids, labels, images, save_for_backward=False, all_rows=True)
+        return out.per_token_logp.view(input_ids.shape[0], -1)
+    out = model.forward_logps(input_ids, labels, images, save_for_backward=model.training, label_shift=0 if is_minicpm else 1)
+    model.last_out = out
+    return out.seq_logp / out.seq_cnt if dpo_use_average else out.seq_logp
+
+
 def compute_weighted_logp(per_token_logp: torch.Tensor, labels: torch.Tensor, token_weight: torch.Tensor,
                           use_average: bool) -> torch.Tensor:
     """trainers.py:128-137 on the device: sum_t logp[s,t] * w[s,t] * (labels[s,t+1] != -100), optionally divided by the

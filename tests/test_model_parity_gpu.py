@@ -364,3 +364,14 @@ def test_minicpm_label_convention_matches_oracle():
     assert out.seq_cnt.cpu().tolist() == (lab[:, :-1] != -100).sum(1).float().tolist()
     assert bool(((out.seq_logp.cpu() - lp).abs() <= 1e-3 * lp.abs() + 5e-2).all()), (out.seq_logp, lp)
     assert (lp - lp_std).abs().min() > 1.0              # the two conventions really differ
+    # forward_DPO (trainers.py:66-88): the generic branch's three return modes
+    from rlaif_v_amd.trainer import compute_weighted_logp, forward_DPO
+    ids, labs, imgs = batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"]
+    got_avg = forward_DPO(model, ids, labs, None, imgs, dpo_use_average=True, is_minicpm=True).cpu()
+    assert bool(((got_avg - avg).abs() <= 2e-3 * avg.abs() + 5e-3).all())
+    got_std = forward_DPO(model, ids, labs, None, imgs).cpu()
+    assert bool(((got_std - lp_std).abs() <= 1e-3 * lp_std.abs() + 5e-2).all())
+    per_tok = forward_DPO(model, ids, labs, None, imgs, token_weighted=True)
+    w = torch.ones(per_tok.shape)
+    wl = compute_weighted_logp(per_tok, lab, w, False).cpu()         # unit weights: equals the plain sum
+    assert bool(((wl - lp_std).abs() <= 1e-3 * lp_std.abs() + 5e-2).all())
