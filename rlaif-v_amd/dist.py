@@ -31,6 +31,7 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (the host driver has no legacy IPC)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" IS RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
