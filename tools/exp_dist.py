@@ -27,4 +27,4 @@ else:
         p = torch.randn(R, I, device="cuda").to(BF); q = torch.randn(R, J, device="cuda").to(BF); out = torch.empty(I, J, device="cuda", dtype=BF)
         for rep in range(2):
             ms = timeit(lambda: ops.gemm_tn(p, q, out=out))
-            print(f"tn dist={os.environ.get('RV_GEMM_TN_DIST','4')} {name:6s}: {ms:.3f} ms {2*R*I*J/ms/1e9:7.1f} TF/s")
+            print(f"tn dist={os.environ.get('RV_GEMM_TN_DIST','3')} {name:6s}: {ms:.3f} ms {2*R*I*J/ms/1e9:7.1f} TF/s")
