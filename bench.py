@@ -124,12 +124,14 @@ def cpu_baseline(L: int, seed: int = 0):
     torch.set_num_threads(threads)
     T = L - 575
 
+    phases = {}
+
     def run(layers, clip_layers):
         cfg = O.LlavaCfg(layers=layers, clip_layers=clip_layers, model_max_length=L)
         W = O.make_weights(cfg, seed=seed, bf16_round=False)
         batch = O.make_synthetic_batch(cfg, 1, T, 64, seed=seed, ragged=False)
         t0 = time.time()
-        O.dpo_train_step(batch, W, cfg, {}, lr=5e-7, step=1, sft_weight=0.0, dpo_weight=1.0)
+        O.dpo_train_step(batch, W, cfg, {}, lr=5e-7, step=1, sft_weight=0.0, dpo_weight=1.0, timings=phases)
         return time.time() - t0
 
     t11 = run(1, 2)     # 1 LLM layer, 1 CLIP layer used (select_layer = -2)
@@ -150,7 +152,8 @@ def cpu_baseline(L: int, seed: int = 0):
                 sample=(f"oracle/dpo_oracle.py fwd+bwd+AdamW, fp32, 1 pair, L={L}, full 7B widths at depth "
                         f"(1,1),(2,1) LLM/CLIP layers: {t11:.1f}s,{t21:.1f}s (+ CLIP forward micro-timing {t12:.2f}s) -> per-layer "
                         f"{llm:.2f}s LLM, {clip:.2f}s CLIP, fixed {fixed:.2f}s; extrapolated to 32/23 layers = "
-                        f"{step:.1f}s per pair on {threads} threads of {cores} host cores"))
+                        f"{step:.1f}s per pair on {threads} threads of {cores} host cores; phases of the depth-2 sample: forward "
+                        f"{phases.get('fwd_s', 0):.1f}s, backward {phases.get('bwd_s', 0):.1f}s, clip+AdamW {phases.get('opt_s', 0):.1f}s"))
 
 
 def main():

@@ -603,19 +603,25 @@ def adamw_reference(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tens
 
 
 def dpo_train_step(batch, W: Dict[str, torch.Tensor], cfg: LlavaCfg, opt_state, lr: float, step: int,
-                   **kw):
+                   timings: Optional[Dict[str, float]] = None, **kw):
     """One full optimisation step on CPU: forward, autograd backward, clip, AdamW.  This is the
     <=30-line shim loop of SURVEY.md section 8c around the reference functions."""
     names = lora_trainable_names(W) if kw.get("lora_scale") is not None else trainable_names(cfg)
     for k in names:
         W[k].requires_grad_(True)
         W[k].grad = None
+    import time
+    t0 = time.time()
     out = dpo_step_forward(batch, W, cfg, **kw)
+    t1 = time.time()
     out["loss"].backward()
+    t2 = time.time()
     grads = {k: W[k].grad.detach().clone() for k in names if W[k].grad is not None}
     with torch.no_grad():
         params = {k: W[k] for k in names}
         for k in names:
             W[k].requires_grad_(False)
         gn = adamw_reference(params, grads, opt_state, lr, step)
+    if timings is not None:            # SURVEY.md section 8d: forward, backward and optimizer timed separately
+        timings.update(fwd_s=t1 - t0, bwd_s=t2 - t1, opt_s=time.time() - t2)
     return out, grads, gn
