@@ -27,21 +27,25 @@ PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICR
 
 
 def flops_per_seq(n_tok: float, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000,
-                  lora_r: int = 0) -> float:
+                  lora_r: int = 0, n_tgt: float = None) -> float:
     """Algorithmic FLOPs of fwd + bwd over one sequence of n_tok tokens (causal attention at half, no recompute).
     Full fine-tune: forward + input gradients + weight gradients = 3 passes over the linear layers.  LoRA: the base
-    weights are frozen -> 2 passes, plus the adapters (forward t = xA^T and tB^T; backward dt, dt A, dA, dB = 2x)."""
-    per_tok_linear = layers * (8 * d * d + 6 * d * f) + 2 * d * V
+    weights are frozen -> 2 passes, plus the adapters (forward t = xA^T and tB^T; backward dt, dt A, dA, dB = 2x).
+    ``n_tgt``: rows that reach the LM head (positions whose next label is a target); None = all n_tok rows, SURVEY's
+    reference-layout accounting (the reference computes logits for every position)."""
+    per_tok_linear = layers * (8 * d * d + 6 * d * f)
     per_tok_attn = layers * 2 * d * n_tok
     per_tok_lora = layers * 2 * lora_r * (4 * 2 * d + 3 * (d + f))
     passes = 2 if lora_r else 3
-    return n_tok * (passes * per_tok_linear + 3 * per_tok_attn + 3 * per_tok_lora)
+    head = (n_tok if n_tgt is None else n_tgt) * passes * 2 * d * V
+    return n_tok * (passes * per_tok_linear + 3 * per_tok_attn + 3 * per_tok_lora) + head
 
 
-def flops_per_pair(L: int, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000, lora_r: int = 0) -> float:
+def flops_per_pair(L: int, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000, lora_r: int = 0,
+                   n_tgt: float = None) -> float:
     """algorithmic FLOPs of one pair (two sequences of L tokens), CLIP once per pair (forward
-    only) + projector (fwd+bwd).  Full fine-tune at L = 2048: 169.4 TFLOP."""
-    return 2 * flops_per_seq(L, layers, d, f, V, lora_r) + 0.366e12 + 3 * 0.024e12
+    only) + projector (fwd+bwd).  Full fine-tune at L = 2048: 169.4 TFLOP (n_tgt None = LM head on every position)."""
+    return 2 * flops_per_seq(L, layers, d, f, V, lora_r, n_tgt) + 0.366e12 + 3 * 0.024e12
 
 
 class GemmTimer:
@@ -114,46 +118,64 @@ class GemmTimer:
                     flops=tot_fl, alg_bytes=alg_bytes)
 
 
-def cpu_baseline(L: int, seed: int = 0):
-    """The oracle (a port of the reference's step) timed on the host cores, on a bounded sample:
-    full-width LLaVA-1.5-7B shapes at reduced depth, ONE pair, one fwd+bwd+AdamW step; per-layer slopes
-    extrapolated linearly to 32 LLM / 23 CLIP layers (BASELINE.md section 2 method)."""
+def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
+    """The oracle (a port of the reference's step) timed on THIS box's host cores at BASELINE config 1's shape
+    (BASELINE.md section 2): 4 synthetic 336-px pairs, text length 512 -> spliced length 1087, fp32, one fwd + bwd + clip +
+    AdamW step at full 7B widths; bounded sample = depths 1 and 2 of the language model (CLIP at full depth), the per-layer
+    slope extrapolated linearly to 32 layers.  The reference's OWN functions, timed the same way in the build container
+    (tools/cpu_reference_baseline.py -> profiles/r02_cpu_reference_baseline.json), ride along as ``reference_run``."""
     from oracle import dpo_oracle as O
     cores = os.cpu_count() or 1
     threads = min(cores, 128)
     torch.set_num_threads(threads)
-    T = L - 575
-
-    phases = {}
-
-    def run(layers, clip_layers):
-        cfg = O.LlavaCfg(layers=layers, clip_layers=clip_layers, model_max_length=L)
+    res = {}
+    for depth in (1, 2):
+        cfg = O.LlavaCfg(layers=depth, model_max_length=2048)
         W = O.make_weights(cfg, seed=seed, bf16_round=False)
-        batch = O.make_synthetic_batch(cfg, 1, T, 64, seed=seed, ragged=False)
-        t0 = time.time()
-        O.dpo_train_step(batch, W, cfg, {}, lr=5e-7, step=1, sft_weight=0.0, dpo_weight=1.0, timings=phases)
-        return time.time() - t0
+        batch = O.make_synthetic_batch(cfg, pairs, text_len, 64, seed=seed, ragged=False)
+        ph = {}
+        O.dpo_train_step(batch, W, cfg, {}, lr=5e-7, step=1, sft_weight=0.0, dpo_weight=1.0, timings=ph)
+        res[depth] = ph
+        del W
+    per_layer = {k: max(res[2][k] - res[1][k], 0.0) for k in ("fwd_s", "bwd_s", "opt_s")}
+    fixed = {k: max(res[1][k] - per_layer[k], 0.0) for k in per_layer}
+    full = {k: fixed[k] + 32 * per_layer[k] for k in per_layer}
+    step = sum(full.values())
+    out = dict(value=pairs / step, unit="pairs/s", cores=threads, kind="port",
+               sample=f"oracle fp32 step, config 1 ({pairs} pairs, T={text_len}, L={text_len + 575}), depths 1,2 -> 32 layers: {step:.0f} s",
+               host_cores=cores, step_s_extrapolated=step,
+               phases_s={k[:-2]: round(v, 2) for k, v in full.items()},
+               measured_s={str(d): {k[:-2]: round(v, 2) for k, v in res[d].items()} for d in res})
+    try:
+        with open(os.path.join(REPO, "profiles", "r02_cpu_reference_baseline.json")) as fh:
+            ref = json.load(fh)
+        out["reference_run"] = dict(kind="reference", where="build container", cores=ref["cores"], cpu=ref["cpu"],
+                                    value=ref["pairs_per_s"], unit="pairs/s", step_s_extrapolated=ref["extrapolated_32_layers_s"]["step"])
+    except Exception:
+        pass
+    return out
 
-    t11 = run(1, 2)     # 1 LLM layer, 1 CLIP layer used (select_layer = -2)
-    t21 = run(2, 2)     # + 1 LLM layer
-    llm = max(t21 - t11, 1e-6)
-    # CLIP per-layer cost from a forward-only micro-timing (the tower is frozen): 2 images like trainers.py:190
-    cfgc1, cfgc2 = O.LlavaCfg(layers=0, vocab=64, clip_layers=2), O.LlavaCfg(layers=0, vocab=64, clip_layers=3)
-    Wc = {k: v for k, v in O.make_weights(cfgc2, seed=seed, bf16_round=False).items() if k.startswith(O.VT)}
-    px = torch.randn(2, 3, 336, 336)
-    with torch.no_grad():
-        t0 = time.time(); O.clip_vision_features(px, Wc, cfgc1); tc1 = time.time() - t0
-        t0 = time.time(); O.clip_vision_features(px, Wc, cfgc2); tc2 = time.time() - t0
-    clip = max(tc2 - tc1, 0.0)
-    fixed = max(t11 - llm - clip, 0.0)
-    step = fixed + 32 * llm + 23 * clip
-    t12 = tc2
-    return dict(value=1.0 / step, unit="pairs/s", cores=threads, kind="port",
-                sample=(f"oracle/dpo_oracle.py fwd+bwd+AdamW, fp32, 1 pair, L={L}, full 7B widths at depth "
-                        f"(1,1),(2,1) LLM/CLIP layers: {t11:.1f}s,{t21:.1f}s (+ CLIP forward micro-timing {t12:.2f}s) -> per-layer "
-                        f"{llm:.2f}s LLM, {clip:.2f}s CLIP, fixed {fixed:.2f}s; extrapolated to 32/23 layers = "
-                        f"{step:.1f}s per pair on {threads} threads of {cores} host cores; phases of the depth-2 sample: forward "
-                        f"{phases.get('fwd_s', 0):.1f}s, backward {phases.get('bwd_s', 0):.1f}s, clip+AdamW {phases.get('opt_s', 0):.1f}s"))
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: re-run this script under torch.distributed.run with one rank per
+    GPU (the command line the driver itself uses) and pass its output / exit code through.  Refuses when the node has
+    fewer than N GPUs - a line with n_gpus < N is never printed."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node; refusing to measure fewer ranks")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -170,13 +192,17 @@ def main():
     ap.add_argument("--lora-r", type=int, default=64)
     ap.add_argument("--gradient-checkpointing", action="store_true", help="re-run each decoder layer in backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dp-probe", action="store_true",
+                    help="skip the 1-rank RCCL probe (steps re-timed with the bucketed all-reduce forced on)")
     ap.add_argument("--no-gemm-timer", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))                 # no launcher: spawn one rank per GPU ourselves
     from rlaif_v_amd.dist import init_process_group_from_env, BucketedAllReduce
     rank, local, world = init_process_group_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -228,17 +254,48 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    dp_probe = None
+    if world == 1 and not args.no_dp_probe:
+        # the data-parallel exchange on ONE rank: the same bucketed all-reduce schedule the N-GPU run issues (RCCL kernels
+        # on RCCL's stream, overlapped with backward, optimizer waits on the handles), forced on in a 1-rank group.  It
+        # prices the launch / stream / CU-sharing side of the overlap; the xGMI transfer itself needs >= 2 GPUs.
+        try:
+            os.environ.update(RANK="0", LOCAL_RANK=str(local), WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                              MASTER_PORT=str(_free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            red = BucketedAllReduce(model.store.flat_g, force=True)
+            sent = []
+            _launch = red._launch
+            red._launch = lambda a, b: (sent.append(b - a), _launch(a, b))[1]
+            trainer.reducer, trainer._reduce_hook = red, red.on_bucket_ready
+            model.grad_ready_hook = trainer._bucket_ready
+            if not args.no_gemm_timer:
+                timer._restore()
+            one_step()
+            torch.cuda.synchronize()
+            sent.clear()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                one_step()
+            torch.cuda.synchronize()
+            ms_forced = (time.perf_counter() - t1) / 2 * 1e3
+            dp_probe = dict(ms_per_step=ms_forced, collectives_per_step=len(sent) // 2,
+                            bytes_per_step=sum(sent) // 2 * model.store.flat_g.element_size())
+            dist.destroy_process_group()
+        except Exception as e:          # the probe must never cost the headline line
+            dp_probe = dict(error=repr(e)[:200])
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         pairs_per_s = B * world * args.steps / dt
         lr_ = args.lora_r if args.lora else 0
-        fp_nominal = flops_per_pair(L, layers=args.layers, lora_r=lr_)
-        # shared-prefix reuse: the prefix of each pair is computed once -> subtract its work once per pair
-        # (report the MFMA fraction on the FLOPs actually required)
+        fp_nominal = flops_per_pair(L, layers=args.layers, lora_r=lr_)       # LM head on every position
+        # FLOPs actually required (report the MFMA fraction on these): the LM head runs only on
+        # the rows whose next label is a target, and the shared prefix of each pair is computed once
         plan = model.last_out.plan
         shared = plan.shared_len or [0] * B
-        saved = sum(flops_per_seq(p, layers=args.layers, lora_r=lr_) for p in shared) / max(len(shared), 1)
-        fp = fp_nominal - saved
+        saved = sum(flops_per_seq(p, layers=args.layers, lora_r=lr_, n_tgt=0) for p in shared) / max(len(shared), 1)
+        fp = flops_per_pair(L, layers=args.layers, lora_r=lr_, n_tgt=plan.n_sel / (2.0 * B)) - saved
         step_tflops_per_gpu = fp * (pairs_per_s / world) / 1e12
         line = {
             "metric": "preference-pairs/sec (DPO step) LLaVA-1.5-7B bf16", "value": pairs_per_s, "unit": "pairs/s",
@@ -274,8 +331,12 @@ def main():
                                                 "operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
                                 "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
                                 "gemm_ms_per_step": g["total_ms"] / args.steps}
+        if dp_probe is not None:
+            if "ms_per_step" in dp_probe:
+                dp_probe["exposed_ms_per_step"] = dp_probe["ms_per_step"] - ms_per_step
+            line["dp_overlap_probe_1rank"] = dp_probe
         if world == 1 and not args.no_cpu_baseline and not args.lora:     # the CPU leg times the full-FT oracle step
-            line["cpu_baseline"] = cpu_baseline(L)
+            line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

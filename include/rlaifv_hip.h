@@ -122,11 +122,13 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
                 void* stream);
 /* kv_group (both calls): grouped-query attention as in HF Mistral / Llama-3 (`repeat_kv`): H query heads share
  * H / kv_group key/value heads, query head h reads kv head h / kv_group (K at k_col0 + (h / kv_group) * hd); 1 = MHA.
- * backward (hd = 128): delta = rv_attn_delta(dO, O).  Writes dQ, dK, dV into dqkv at the column offsets of
- * qkv.  Deterministic (no atomics): one kernel per 128-query block for dQ, one per 128-key block for dK/dV. */
+ * backward (hd = 128): O = the forward output (rv_attn_fwd's `out`), delta = [S, H, L] fp32 WORKSPACE: the dQ kernel fills
+ * it with rowsum(dO * O) (what rv_attn_delta computes) on the fly and the dK/dV kernel reads it.  Writes dQ, dK, dV into
+ * dqkv at the column offsets of qkv.  Deterministic (no atomics): one kernel per 128-query block for dQ, one per 128-key
+ * block for dK/dV.  Packed rows: key tiles / query tiles that a whole block cannot see are never fetched. */
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
-                const float* lse, const float* delta, void* dqkv, long lddq, int S, int L, int H, int hd, int causal,
-                float scale, const int* seg_sh, const int* seg_e1, int kv_group, void* stream);
+                const void* O, long ldo, const float* lse, float* delta, void* dqkv, long lddq, int S, int L, int H,
+                int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group, void* stream);
 int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
                   void* stream);
 
@@ -192,6 +194,9 @@ int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float pr
                  void* stream);
 int rv_adamw_step(void* p, float* master, float* m, float* v, const void* g, long n, float lr, float beta1, float beta2,
                   float eps, float wd, int step, const float* clip, void* stream);
+/* --gradient_accumulation_steps (HF Trainer, script/train/llava15_train.sh:23): fp32 accumulation of the bf16 micro-batch
+ * gradients.  mode 0: acc = g;  1: acc += g;  2: g = bf16((acc + g) * scale)  (scale = 1 / accumulation steps). */
+int rv_grad_accum(float* acc, void* g, long n, int mode, float scale, void* stream);
 
 #ifdef __cplusplus
 }

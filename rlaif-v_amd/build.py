@@ -32,16 +32,21 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_extension(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+def build_extension(force: bool = False, verbose: bool = True, defines=(), tag: str = "") -> str:
+    """The shipped library: ``build_extension()``.  ``defines`` / ``tag`` build a SEPARATE experiment library
+    (librlaifv_hip<tag>.so, selected with RV_HIP_LIB for A/B runs) - e.g. defines=("RV_GEMM_EXPERIMENTS",) compiles the
+    ablation / schedule-experiment GEMM variants, which the shipped library does not contain."""
+    bdir = os.path.join(HERE, "build" + tag)
+    os.makedirs(bdir, exist_ok=True)
     hipcc = _hipcc()
+    lib = LIB if not tag else LIB.replace(".so", f"{tag}.so")
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        o = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", s, "-o", o])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
@@ -49,15 +54,18 @@ def build_extension(force: bool = False, verbose: bool = True) -> str:
                     raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + res.stderr[-4000:])
                 if verbose:
                     print("[build]", os.path.basename(cmd[-1]), file=sys.stderr)
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or jobs or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n" + res.stderr[-4000:])
         if verbose:
-            print("[build] linked", LIB, file=sys.stderr)
-    return LIB
+            print("[build] linked", lib, file=sys.stderr)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_extension(force="--force" in sys.argv))
+    if "--experiments" in sys.argv:
+        print(build_extension(force="--force" in sys.argv, defines=("RV_GEMM_EXPERIMENTS",), tag="_exp"))
+    else:
+        print(build_extension(force="--force" in sys.argv))

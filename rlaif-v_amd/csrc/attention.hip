@@ -180,18 +180,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 
     const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
     const int nt = (kv_end + 63) / 64;
-    dma.issue(kbase, ld, tok0, 0, L, smem, wave);
-    dma.issue(vbase, ld, tok0, 0, L, smem + TILE, wave);
+    // A query block that lies entirely in the rejected branch never sees the key tiles that lie entirely in the chosen
+    // branch [sh, e1): those tiles are not fetched at all (block-uniform: DMA and barriers are workgroup-wide).  The loop
+    // runs over the nte remaining tiles; the LDS stage alternates with the loop index, not the tile index.
+    int skip_lo = nt, skip_n = 0;
+    if (q0 >= e1 && e1 > sh) {
+      const int lo = (sh + 63) >> 6, hi = e1 >> 6;
+      if (hi > lo) { skip_lo = lo; skip_n = hi - lo; }
+    }
+    const int nte = nt - skip_n;
+    dma.issue(kbase, ld, tok0, (skip_lo == 0 ? skip_n : 0) * 64, L, smem, wave);
+    dma.issue(vbase, ld, tok0, (skip_lo == 0 ? skip_n : 0) * 64, L, smem + TILE, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    for (int i = 0; i < nte; ++i) {
+      const int t = i < skip_lo ? i : i + skip_n;
       const int k0 = t * 64;
-      const uint8_t* Ks = smem + (t & 1) * STAGE;
+      const uint8_t* Ks = smem + (i & 1) * STAGE;
       const uint8_t* Vs = Ks + TILE;
-      if (t + 1 < nt) {
-        dma.issue(kbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE, wave);
-        dma.issue(vbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE + TILE, wave);
+      if (i + 1 < nte) {
+        const int kn = ((i + 1 < skip_lo) ? i + 1 : i + 1 + skip_n) * 64;
+        dma.issue(kbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE, wave);
+        dma.issue(vbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE + TILE, wave);
       }
       if (!(CAUSAL && k0 > q0w + 31) && !(q0w >= e1 && k0 >= sh && k0 + 63 < e1)) {
         f32x16_t sacc[2];
@@ -281,8 +292,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                               int k_col0, int v_col0, const bf16_t* __restrict__ dO,
-                                                              long lddo, const float* __restrict__ lse,
-                                                              const float* __restrict__ delta,
+                                                              long lddo, const bf16_t* __restrict__ O, long ldo,
+                                                              const float* __restrict__ lse,
+                                                              float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
                                                               int nx, float scale, const int* __restrict__ seg_sh,
                                                               const int* __restrict__ seg_e1, int kv_group) {
@@ -327,25 +339,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
       }
     }
     const float lse_q = lse[((long)s * H + h) * L + qc] * LOG2E;
-    const float delta_q = delta[((long)s * H + h) * L + qc];
+    // delta[q] = sum_e dO[q][e] * O[q][e] (the softmax-backward row term) is computed HERE from the dO fragments the
+    // kernel holds anyway (a lane owns 64 of the row's 128 columns, its partner lane^32 the rest) and published for the
+    // dK/dV kernel, which runs after this one on the same stream - no separate attn_delta pass over dO and O.
+    float delta_q = 0.f;
+    {
+      const bf16_t* op = O + (tok0 + qc) * ldo + h * HD + 8 * half;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t of = *(const bf16x8_t*)(op + 16 * ks);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta_q = fmaf(bf2f((bf16_t)dof[ks][j]), bf2f((bf16_t)of[j]), delta_q);
+      }
+      delta_q += __shfl_xor(delta_q, 32, 64);
+      if (q < L && half == 0) delta[((long)s * H + h) * L + q] = delta_q;
+    }
     f32x16_t dq[ET];
 #pragma unroll
     for (int e = 0; e < ET; ++e) zero16(dq[e]);
 
     const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
     const int nt = (kv_end + 63) / 64;
-    dma.issue(kbase, ld, tok0, 0, L, smem, wave);
-    dma.issue(vbase, ld, tok0, 0, L, smem + TILE, wave);
+    int skip_lo = nt, skip_n = 0;           // chosen-branch key tiles a rejected-branch query block never sees (see forward)
+    if (q0 >= e1 && e1 > sh) {
+      const int lo = (sh + 63) >> 6, hi = e1 >> 6;
+      if (hi > lo) { skip_lo = lo; skip_n = hi - lo; }
+    }
+    const int nte = nt - skip_n;
+    dma.issue(kbase, ld, tok0, (skip_lo == 0 ? skip_n : 0) * 64, L, smem, wave);
+    dma.issue(vbase, ld, tok0, (skip_lo == 0 ? skip_n : 0) * 64, L, smem + TILE, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    for (int i = 0; i < nte; ++i) {
+      const int t = i < skip_lo ? i : i + skip_n;
       const int k0 = t * 64;
-      const uint8_t* Ks = smem + (t & 1) * STAGE;
+      const uint8_t* Ks = smem + (i & 1) * STAGE;
       const uint8_t* Vs = Ks + TILE;
-      if (t + 1 < nt) {
-        dma.issue(kbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE, wave);
-        dma.issue(vbase, ld, tok0, k0 + 64, L, smem + ((t + 1) & 1) * STAGE + TILE, wave);
+      if (i + 1 < nte) {
+        const int kn = ((i + 1 < skip_lo) ? i + 1 : i + 1 + skip_n) * 64;
+        dma.issue(kbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE, wave);
+        dma.issue(vbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE + TILE, wave);
       }
       if (!(CAUSAL && k0 > q0w + 31) && !(q0w >= e1 && k0 >= sh && k0 + 63 < e1)) {
 #pragma unroll
@@ -520,7 +554,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     for (int e = 0; e < ET; ++e) { mfma_agpr_zero(dk[e]); mfma_agpr_zero(dv[e]); }
 
     const int t_begin = CAUSAL ? (kv0 / 64) : 0;
-    const int nt = (L + 63) / 64;
+    // a key block that lies entirely in the chosen branch [sh, e1) is invisible to every rejected-branch query (>= e1):
+    // its query loop ends at e1 instead of L (no DMA, no barrier for the tiles behind it)
+    const int nt = (kv0 >= sh && kv0 + 127 < e1) ? min((L + 63) / 64, (e1 + 63) / 64) : (L + 63) / 64;
     for (int gq = 0; gq < kv_group; ++gq) {
     const int hq = h * kv_group + gq;
     issue_tile(hq, t_begin, 0);
@@ -658,10 +694,11 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
 }
 
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
-                const float* lse, const float* delta, void* dqkv, long lddq, int S, int L, int H, int hd, int causal,
-                float scale, const int* seg_sh, const int* seg_e1, int kv_group,
+                const void* O, long ldo, const float* lse, float* delta, void* dqkv, long lddq, int S, int L, int H,
+                int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
                 void* stream) {
   RV_REQUIRE(hd == 128, "rv_attn_bwd: head dim must be 128");
+  RV_REQUIRE(O != nullptr && delta != nullptr && ldo % 8 == 0, "rv_attn_bwd: O (forward output) and the delta workspace are required");
   RV_REQUIRE(kv_group >= 1 && H % kv_group == 0, "rv_attn_bwd: kv_group must divide the number of query heads");
   RV_REQUIRE((seg_sh == nullptr) == (seg_e1 == nullptr), "rv_attn_bwd: seg_sh and seg_e1 go together");
   RV_REQUIRE(ld % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0, "rv_attn_bwd: alignment");
@@ -686,17 +723,19 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   // dQ: one workgroup per (query head, query block); dK/dV: per (KEY/VALUE head, key block), looping over its query heads
   const int Hkv = H / kv_group;
   dim3 grid_kv(nxr * Hkv * S);
-#define BWD_ARGS(HH) (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo, lse, delta, (bf16_t*)dqkv, lddq, L, HH, nx, scale, seg_sh, seg_e1, kv_group
+#define BWD_HEAD (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo
+#define BWD_TAIL(HH) (bf16_t*)dqkv, lddq, L, HH, nx, scale, seg_sh, seg_e1, kv_group
   if (causal) {
-    hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_ARGS(H));
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_HEAD, (const bf16_t*)O, ldo, lse, delta, BWD_TAIL(H));
     RV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_ARGS(Hkv));
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, block, DQ_LDS, st, BWD_ARGS(H));
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, block, DQ_LDS, st, BWD_HEAD, (const bf16_t*)O, ldo, lse, delta, BWD_TAIL(H));
     RV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_ARGS(Hkv));
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
   }
-#undef BWD_ARGS
+#undef BWD_HEAD
+#undef BWD_TAIL
   RV_CHECK_LAUNCH();
   return 0;
 }

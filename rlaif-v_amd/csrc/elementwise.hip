@@ -533,6 +533,32 @@ __global__ void gradnorm_finish_kernel(const float* __restrict__ partial, int np
   }
 }
 
+// Gradient accumulation over micro-batches (HF Trainer --gradient_accumulation_steps): fp32 side buffer.
+//   mode 0: acc = g            (first micro-batch: no zeroing pass)
+//   mode 1: acc += g           (middle micro-batches)
+//   mode 2: g = bf16((acc + g) * scale)   (last micro-batch: the averaged gradient lands where all-reduce / AdamW read it)
+__global__ void grad_accum_kernel(float* __restrict__ acc, bf16_t* __restrict__ g, long n8, int mode, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float gf[8];
+    unpack8(((const uint4*)g)[i], gf);
+    if (mode == 0) {
+      ((float4*)acc)[2 * i] = make_float4(gf[0], gf[1], gf[2], gf[3]);
+      ((float4*)acc)[2 * i + 1] = make_float4(gf[4], gf[5], gf[6], gf[7]);
+      continue;
+    }
+    const float4 a0 = ((const float4*)acc)[2 * i], a1 = ((const float4*)acc)[2 * i + 1];
+    float s[8] = {a0.x + gf[0], a0.y + gf[1], a0.z + gf[2], a0.w + gf[3], a1.x + gf[4], a1.y + gf[5], a1.z + gf[6], a1.w + gf[7]};
+    if (mode == 1) {
+      ((float4*)acc)[2 * i] = make_float4(s[0], s[1], s[2], s[3]);
+      ((float4*)acc)[2 * i + 1] = make_float4(s[4], s[5], s[6], s[7]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] *= scale;
+      ((uint4*)g)[i] = pack8(s);
+    }
+  }
+}
+
 // AdamW with decoupled weight decay on fp32 master weights; writes the bf16 working copy.
 __global__ void adamw_kernel(bf16_t* __restrict__ p, float* __restrict__ master, float* __restrict__ m,
                              float* __restrict__ v, const bf16_t* __restrict__ g, long n8, float lr, float b1,
@@ -906,6 +932,15 @@ int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float pr
   RV_CHECK_LAUNCH();
   hipLaunchKernelGGL(gradnorm_finish_kernel, dim3(1), dim3(256), 0, STREAM(stream), partial, 1024, max_norm, pre_scale,
                      out2);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_grad_accum(float* acc, void* g, long n, int mode, float scale, void* stream) {
+  RV_REQUIRE(n % 8 == 0 && mode >= 0 && mode <= 2, "rv_grad_accum: n % 8 == 0, mode in 0..2");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(grad_accum_kernel, dim3(grid_for(n / 8, 256, 8192)), dim3(256), 0, STREAM(stream), acc, (bf16_t*)g,
+                     n / 8, mode, scale);
   RV_CHECK_LAUNCH();
   return 0;
 }

@@ -156,12 +156,18 @@ static int dispatch(const GemmShape& g, const Epi& epi, int variant, void* strea
     const long t256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
     variant = (t256 >= 192) ? 3 : 1;
   }
+#ifdef RV_GEMM_EXPERIMENTS
+  // Experiment builds only (rlaif-v_amd/build.py --experiments -> librlaifv_hip_exp.so): the ablations return WRONG
+  // results by construction and the schedule variants lost their A/B runs; none of them is in the shipped library.
   if (variant == 101) return launch_gemm256<Epi, true, 1>(g, epi, (hipStream_t)stream);   // ablation: no DMA
   if (variant == 102) return launch_gemm256<Epi, true, 2>(g, epi, (hipStream_t)stream);   // ablation: stale ds_reads
   if (variant == 103) return launch_gemm256<Epi, true, 3>(g, epi, (hipStream_t)stream);   // ablation: L2-resident DMA
   if (variant == 6) return launch_gemm256<Epi, true, 0, 3, 1>(g, epi, (hipStream_t)stream);
   if (variant == 5) return launch_gemm256x64<Epi>(g, epi, (hipStream_t)stream);
   if (variant == 4) return launch_gemm256<Epi, true, 0, 4>(g, epi, (hipStream_t)stream);
+#else
+  if (variant > 3) { rv_set_error("GEMM variant: 0..3 (experiment variants need an RV_GEMM_EXPERIMENTS build)"); return 1; }
+#endif
   if (variant == 3) return launch_gemm256<Epi, true>(g, epi, (hipStream_t)stream);
   if (variant == 2) return launch_gemm256<Epi, false>(g, epi, (hipStream_t)stream);
   if (variant == 1) return launch_gemm<1, Epi>(g, epi, (hipStream_t)stream);
@@ -182,7 +188,7 @@ extern "C" {
 const char* rv_last_error(void) { return g_err; }
 
 int rv_set_gemm_variant(int variant) {
-  RV_REQUIRE(variant >= -1 && variant <= 6, "rv_set_gemm_variant: -1 (auto), 0..6");
+  RV_REQUIRE(variant >= -1 && variant <= 3, "rv_set_gemm_variant: -1 (auto), 0..3");
   g_default_variant = variant;
   return 0;
 }

@@ -85,12 +85,34 @@ def lib() -> HipLib:
     return _LIB
 
 
-def stream_ptr() -> int:
-    """hipStream_t of torch's current stream on the current device."""
+def stream_ptr(device=None) -> int:
+    """hipStream_t of torch's current stream on ``device`` (default: the current device)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_DEBUG_ARGS = os.environ.get("RV_DEBUG_ARGS", "0") != "0"
 
 
 def call(name: str, *args) -> None:
-    """Launch ``name`` on torch's current HIP stream (appended as the last argument)."""
-    lib().call(name, *args, stream_ptr())
+    """Launch ``name`` on torch's current HIP stream OF THE TENSORS' DEVICE (appended as the last argument).  A kernel
+    launch goes to the calling thread's current HIP device, so when the first tensor argument lives on another device the
+    call is wrapped in ``torch.cuda.device`` - raw pointers of cuda:1 never meet a stream of cuda:0.  RV_DEBUG_ARGS=1
+    additionally checks that every tensor argument is on that device and dense in its last dimension."""
+    import torch
+    dev = None
+    for a in args:
+        if hasattr(a, "data_ptr"):
+            if dev is None:
+                dev = a.device
+                if not _DEBUG_ARGS:
+                    break
+            elif a.device != dev:
+                raise ValueError(f"{name}: tensor arguments on different devices ({dev} vs {a.device})")
+            if _DEBUG_ARGS and a.dim() > 0 and a.stride(-1) != 1 and a.numel() > 1:
+                raise ValueError(f"{name}: tensor argument with non-unit innermost stride {a.stride()}")
+    if dev is None or dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+        lib().call(name, *args, stream_ptr(dev if dev is not None and dev.type == "cuda" else None))
+        return
+    with torch.cuda.device(dev):
+        lib().call(name, *args, stream_ptr(dev))

@@ -318,7 +318,8 @@ class LlavaDPOModel:
         self.gradient_checkpointing = False
         self.clip: Dict[str, torch.Tensor] = {}
         self.training = True
-        self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._rope_cache: Optional[Tuple[int, torch.Tensor, torch.Tensor]] = None     # ONE table, grown geometrically
+        self.dropout_rank = 0           # data-parallel rank: mixed into the LoRA dropout seeds (set by the trainer)
         self.grad_ready_hook = None     # callable(name, start, end) fired when a slice of flat_g is final
         # compute the prefix shared by the chosen and rejected sequence of a pair once (splice.build_packed_plan)
         self.share_prefix = os.environ.get("RV_SHARE_PREFIX", "1") != "0"
@@ -488,9 +489,12 @@ class LlavaDPOModel:
 
     # ------------------------------------------------------------------ vision
     def _rope(self, L: int):
-        if L not in self._rope_cache:
-            self._rope_cache[L] = ops.rope_tables(L, self.cfg.head_dim, self.cfg.rope_theta, self.device)
-        return self._rope_cache[L]
+        """cos/sin rows 0..L-1.  The kernels index the table by position, so one table for the largest length seen so far
+        serves every batch (a table per distinct L would grow without bound with ragged / packed batches)."""
+        if self._rope_cache is None or self._rope_cache[0] < L:
+            n = max(L, self.cfg.model_max_length, 2 * self._rope_cache[0] if self._rope_cache else 0)
+            self._rope_cache = (n,) + ops.rope_tables(n, self.cfg.head_dim, self.cfg.rope_theta, self.device)
+        return self._rope_cache[1], self._rope_cache[2]
 
     def clip_features(self, pixels: torch.Tensor) -> torch.Tensor:
         """CLIPVisionTower.forward + feature_select('patch') (clip_encoder.py:36-58): [B*P, clip_hidden]."""
@@ -551,7 +555,7 @@ class LlavaDPOModel:
         return y, t, (xd if self.keep_dropped_inputs else None)
 
     def _dropout_seed(self, layer: int, slot: int) -> int:
-        return (self._cur_drop_step * 1000003 + layer * 8 + slot) & 0x7FFFFFFF
+        return (self._cur_drop_step * 1000003 + self.dropout_rank * 7919 + layer * 8 + slot) & 0x7FFFFFFF
 
     def _proj_bwd(self, dy: torch.Tensor, xin: torch.Tensor, t: Optional[torch.Tensor], i: int, grp: str,
                   drop_slot: int = 0, xd: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -768,6 +772,32 @@ class LlavaDPOModel:
         out.ctx = {}
 
     # ------------------------------------------------------------------ reference-style surface
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, images=None, **kwargs):
+        """``LlavaLlamaForCausalLM.forward(inputs_embeds=, labels=None).logits`` - the call get_beta_and_logps makes after
+        the splice (muffin/train/trainers.py:221-225, llava/model/language_model/llava_llama.py:57-102).  Debug / evaluation
+        surface for SMALL inputs: it materialises [S, L, V] logits, which the training path never does (forward_logps fuses
+        the LM head with the log-softmax).  Forward only; pure causal mask, positions 0..L-1, like the reference call."""
+        from types import SimpleNamespace
+        if inputs_embeds is None:
+            raise NotImplementedError("forward() takes inputs_embeds (prepare_inputs_labels_for_multimodal builds them)")
+        if labels is not None or attention_mask is not None or past_key_values is not None:
+            raise NotImplementedError("the DPO call site passes labels=None, attention_mask=None, no cache")
+        cfg, st = self.cfg, self.store
+        S, L, d = inputs_embeds.shape
+        if S * L * cfg.vocab * 2 > (16 << 30):
+            raise ValueError("forward(): logits would exceed 16 GB - use forward_logps (fused LM head) for training shapes")
+        x = inputs_embeds.to(self.device, BF16).reshape(S * L, d).contiguous()
+        plan = SimpleNamespace(S=S, L=L, pos=None, seg=None)
+        cos, sin = self._rope(L)
+        for i in range(cfg.layers):
+            x, _ = self._layer_fwd(i, x, plan, cos, sin, False)
+        h, _ = ops.rmsnorm_fwd(x, st.p("model.norm.weight"), cfg.rms_eps, want_rstd=False)
+        logits = ops.gemm_nt(h, st.p("lm_head.weight"))
+        return SimpleNamespace(logits=logits.view(S, L, cfg.vocab), loss=None)
+
+    __call__ = forward
+
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
                                              images):
         """Same 6-tuple contract as llava_arch.py:150-330 (embeds materialised by rv_splice_fwd)."""

@@ -314,10 +314,9 @@ def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv:
     _chk2d(qkv, "qkv"), _chk2d(o, "o"), _chk2d(do, "do")
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
-    delta = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
-    hip.call("rv_attn_delta", do, do.stride(0), o, o.stride(0), delta, S, L, H, hd)
-    hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, do, do.stride(0), lse, delta, dqkv,
-             dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None,
+    delta = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)      # workspace: filled by the dQ kernel
+    hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, do, do.stride(0), o, o.stride(0), lse, delta,
+             dqkv, dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None,
              seg[1] if seg else None, int(kv_group))
     return dqkv
 
@@ -445,6 +444,13 @@ def grad_norm(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = N
         out2 = torch.empty(2, dtype=torch.float32, device=g.device)
     hip.call("rv_grad_norm", g, g.numel(), partial, float(max_norm), float(pre_scale), out2)
     return out2
+
+
+def grad_accum(acc: torch.Tensor, g: torch.Tensor, mode: int, scale: float = 1.0):
+    """fp32 gradient accumulation over micro-batches: mode 0 acc = g, 1 acc += g, 2 g = bf16((acc + g) * scale)."""
+    if acc.dtype != torch.float32 or g.dtype != BF16 or acc.numel() != g.numel() or not (acc.is_contiguous() and g.is_contiguous()):
+        raise ValueError("grad_accum: fp32 accumulator and bf16 gradient slice of equal length required")
+    hip.call("rv_grad_accum", acc, g, g.numel(), int(mode), float(scale))
 
 
 def adamw_step(p, master, m, v, g, lr, beta1, beta2, eps, wd, step: int, clip: Optional[torch.Tensor] = None):

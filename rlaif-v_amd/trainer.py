@@ -54,6 +54,8 @@ class TrainingArguments:
     bf16: bool = True
     seed: int = 42
     gradient_checkpointing: bool = False
+    dataloader_num_workers: int = 0
+    per_device_eval_batch_size: int = 8
     # LoRA flags of muffin/train/train_llava15_lora.py:111-116 (same names and defaults)
     fully_tune: bool = False
     lora_enable: bool = False
@@ -111,6 +113,24 @@ def cosine_lr(step: int, total: int, base_lr: float, warmup_ratio: float) -> flo
         return base_lr * step / max(1, warm)
     prog = (step - warm) / max(1, total - warm)
     return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
+def lr_at(kind: str, step: int, total: int, base_lr: float, warmup_ratio: float) -> float:
+    """transformers.get_scheduler for the types the reference's scripts can select (`--lr_scheduler_type`, HF default
+    "linear"; llava15_train.sh:34 passes "cosine").  ``step`` = optimizer steps already taken.  Anything else raises instead
+    of silently running a different schedule."""
+    if kind == "cosine":
+        return cosine_lr(step, total, base_lr, warmup_ratio)
+    if kind == "constant":
+        return base_lr
+    warm = math.ceil(total * warmup_ratio)
+    if kind in ("linear", "constant_with_warmup"):
+        if step < warm:
+            return base_lr * step / max(1, warm)
+        if kind == "constant_with_warmup":
+            return base_lr
+        return base_lr * max(0.0, (total - step) / max(1, total - warm))
+    raise NotImplementedError(f"lr_scheduler_type {kind!r}: supported are cosine, linear, constant, constant_with_warmup")
 
 
 def dpo_loss(policy_chosen_logps, policy_rejected_logps, reference_chosen_logps, reference_rejected_logps,
@@ -194,13 +214,36 @@ class LLaVA15DPOTrainer:
         self.args = args or TrainingArguments()
         self.train_dataset, self.eval_dataset, self.data_collator = train_dataset, eval_dataset, data_collator
         self.reducer = reducer or GradReducer()
-        self.model.grad_ready_hook = self.reducer.on_bucket_ready \
+        a = self.args
+        if a.gradient_accumulation_steps < 1:
+            raise ValueError("gradient_accumulation_steps must be >= 1")
+        lr_at(a.lr_scheduler_type, 0, max(1, a.max_steps), 1.0, a.warmup_ratio)      # unsupported schedule: fail now
+        self._reduce_hook = self.reducer.on_bucket_ready \
             if (self.reducer.world_size > 1 or getattr(self.reducer, "force", False)) else None
-        if self.args.gradient_checkpointing:
+        # --gradient_accumulation_steps (HF Trainer; script/train/llava15_train.sh:23 passes 1): micro-batch gradients are
+        # summed in an fp32 side buffer; on the last micro-batch each finished slice of flat_g is replaced by the mean and
+        # only then handed to the all-reduce (DDP no_sync semantics: one exchange per optimizer step)
+        self._micro = 0                     # micro-batches already accumulated in the current window
+        self._finalize_accum = False
+        self._gacc: Optional[torch.Tensor] = None
+        self._loss_window: Optional[torch.Tensor] = None
+        self.model.grad_ready_hook = self._bucket_ready if (self._reduce_hook or a.gradient_accumulation_steps > 1) else None
+        rank = int(os.environ.get("RANK", "0"))
+        if getattr(self.model, "lora", None) is not None:
+            self.model.dropout_rank = rank              # LoRA dropout masks must differ across data-parallel ranks
+        if a.gradient_checkpointing:
             self.model.gradient_checkpointing = True
-        self.state = dict(global_step=0, log_history=[])
+        self.state = dict(global_step=0, log_history=[], epoch=0, batches_in_epoch=0)
         self._clip = torch.zeros(2, dtype=torch.float32, device=model.device)
         self._pending_metrics: Optional[torch.Tensor] = None
+
+    def _bucket_ready(self, name: str, start: int, end: int):
+        """model.backward fires this when flat_g[start:end] is final for the current micro-batch."""
+        if self._finalize_accum and end > start:
+            ops.grad_accum(self._gacc[start:end], self.model.store.flat_g[start:end], 2,
+                           1.0 / self.args.gradient_accumulation_steps)
+        if self._reduce_hook is not None and (self._finalize_accum or self.args.gradient_accumulation_steps == 1):
+            self._reduce_hook(name, start, end)
 
     # ---------------------------------------------------------------- loss
     def compute_loss(self, model: LlavaDPOModel, inputs: dict, return_outputs: bool = False,
@@ -241,9 +284,7 @@ class LLaVA15DPOTrainer:
     # ---------------------------------------------------------------- optimisation
     def current_lr(self) -> float:
         a = self.args
-        if a.lr_scheduler_type == "constant":
-            return a.learning_rate
-        return cosine_lr(self.state["global_step"], a.max_steps, a.learning_rate, a.warmup_ratio)
+        return lr_at(a.lr_scheduler_type, self.state["global_step"], a.max_steps, a.learning_rate, a.warmup_ratio)
 
     def optimizer_step(self, lr: Optional[float] = None):
         """clip_grad_norm_(max_grad_norm) + AdamW on the flat buffers, then refresh the W^T copies."""
@@ -261,12 +302,28 @@ class LLaVA15DPOTrainer:
         self.state["global_step"] = step
 
     def training_step(self, inputs: dict) -> torch.Tensor:
-        """forward + backward (+ overlapped gradient all-reduce) + optimizer; returns the device loss."""
+        """forward + backward (+ overlapped gradient all-reduce) of ONE micro-batch; the optimizer runs when the
+        accumulation window (``gradient_accumulation_steps`` micro-batches) is complete.  Returns the device loss (mean
+        over the window once it closes, HF's reporting convention)."""
         self.model.train()
+        ga, st = self.args.gradient_accumulation_steps, self.model.store
+        last = self._micro == ga - 1
+        self._finalize_accum = ga > 1 and last
         loss = self.compute_loss(self.model, inputs)
         self.model.backward(self.model.last_out, self.model.last_coef)
+        if ga == 1:
+            self.optimizer_step()
+            return loss
+        self._loss_window = loss.detach().clone() if self._micro == 0 else self._loss_window + loss.detach()
+        if not last:
+            if self._gacc is None:
+                self._gacc = torch.empty(st.n_train, dtype=torch.float32, device=self.model.device)
+            ops.grad_accum(self._gacc, st.flat_g, 0 if self._micro == 0 else 1)
+            self._micro += 1
+            return loss
+        self._micro, self._finalize_accum = 0, False
         self.optimizer_step()
-        return loss
+        return self._loss_window / ga
 
     # ---------------------------------------------------------------- loop / logging / saving
     def log(self, logs: Dict[str, float]):
@@ -275,14 +332,62 @@ class LLaVA15DPOTrainer:
         if int(os.environ.get("RANK", "0")) == 0:
             print(json.dumps(logs), flush=True)
 
-    def get_train_dataloader(self):
-        from torch.utils.data import DataLoader, RandomSampler
+    def _rank_indices(self, dataset, epoch: int, shuffle: bool, batch_size: int) -> List[int]:
+        """This rank's sample indices for one pass: a permutation seeded with seed + epoch (a new order every epoch, the same
+        on every rank), truncated so that every rank gets the same number of full batches, rank-strided."""
         world, rank = self.reducer.world_size, int(os.environ.get("RANK", "0"))
-        g = torch.Generator().manual_seed(self.args.seed)
-        sampler = RandomSampler(self.train_dataset, generator=g)       # ZephyrTrainer._get_train_sampler (:45-51)
-        idx = list(iter(sampler))[rank::world]                         # rank-strided shard of one permutation
-        return DataLoader(self.train_dataset, batch_size=self.args.per_device_train_batch_size,
-                          sampler=idx, collate_fn=self.data_collator, drop_last=True)
+        n = len(dataset)
+        if shuffle:
+            from torch.utils.data import RandomSampler
+            g = torch.Generator().manual_seed(self.args.seed + epoch)
+            perm = list(iter(RandomSampler(dataset, generator=g)))      # ZephyrTrainer._get_train_sampler (trainers.py:45-51)
+        else:
+            perm = list(range(n))
+        n_batches = (n // world) // batch_size
+        if n_batches == 0:
+            raise ValueError(f"dataset of {n} samples gives rank {rank} of {world} no full batch of {batch_size}")
+        return perm[rank:(n // world) * world:world][:n_batches * batch_size]
+
+    def get_train_dataloader(self, epoch: Optional[int] = None, skip_batches: int = 0):
+        from torch.utils.data import DataLoader
+        bs = self.args.per_device_train_batch_size
+        state = getattr(self, "state", None) or {}
+        idx = self._rank_indices(self.train_dataset, state.get("epoch", 0) if epoch is None else epoch, True, bs)
+        idx = idx[skip_batches * bs:]                 # resume: the batches this epoch already consumed
+        nw = int(getattr(self.args, "dataloader_num_workers", 0) or 0)
+        return DataLoader(self.train_dataset, batch_size=bs, sampler=idx, collate_fn=self.data_collator, drop_last=True,
+                          num_workers=nw)
+
+    def get_eval_dataloader(self, eval_dataset=None):
+        from torch.utils.data import DataLoader
+        ds = eval_dataset if eval_dataset is not None else self.eval_dataset
+        if ds is None:
+            raise ValueError("evaluate() needs an eval_dataset")
+        bs = min(int(getattr(self.args, "per_device_eval_batch_size", 8)), max(1, len(ds) // self.reducer.world_size))
+        idx = self._rank_indices(ds, 0, False, bs)
+        return DataLoader(ds, batch_size=bs, sampler=idx, collate_fn=self.data_collator, drop_last=True,
+                          num_workers=int(getattr(self.args, "dataloader_num_workers", 0) or 0))
+
+    def evaluate(self, eval_dataset=None) -> Dict[str, float]:
+        """The evaluation pass of the HF Trainer over ``compute_loss`` with ``model.training == False``: the reference
+        then logs the same preference metrics under ``*_test/*`` (trainers.py:303).  Forward only (no activations kept);
+        returns the batch-mean of every metric plus ``eval_loss``, averaged over ranks."""
+        was_training = self.model.training
+        self.model.eval()
+        tot, n = None, 0
+        try:
+            for batch in self.get_eval_dataloader(eval_dataset):
+                loss = self.compute_loss(self.model, batch)
+                v = torch.cat([self._pending_metrics, loss.detach().reshape(1)])
+                tot = v if tot is None else tot + v
+                n += 1
+        finally:
+            self.model.train(was_training)
+        self._pending_metrics, self._pending_task = tot[:7] / n, "test"
+        m = self.pop_metrics()
+        m["eval_loss"] = float(self.reducer.reduce_metrics(tot[7:] / n)[0])
+        self.log(m)
+        return m
 
     def train(self, resume_from_checkpoint=None):
         a = self.args
@@ -290,8 +395,12 @@ class LLaVA15DPOTrainer:
             self.load_checkpoint(resume_from_checkpoint)
         t0 = time.time()
         while self.state["global_step"] < a.max_steps:
-            for batch in self.get_train_dataloader():
+            done = False
+            for batch in self.get_train_dataloader(self.state["epoch"], self.state["batches_in_epoch"]):
                 loss = self.training_step(batch)
+                self.state["batches_in_epoch"] += 1
+                if self._micro != 0:
+                    continue                               # inside an accumulation window: no optimizer step yet
                 step = self.state["global_step"]
                 if step % a.logging_steps == 0:
                     m = self.pop_metrics()
@@ -302,7 +411,11 @@ class LLaVA15DPOTrainer:
                 if a.save_steps and step % a.save_steps == 0:
                     self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{step}"))
                 if step >= a.max_steps:
+                    done = True
                     break
+            if not done:                                   # the pass over this rank's shard is complete
+                self.state["epoch"] += 1
+                self.state["batches_in_epoch"] = 0
         return dict(train_runtime=time.time() - t0, global_step=self.state["global_step"])
 
     def _save(self, output_dir: str, state_dict=None):
@@ -329,8 +442,10 @@ class LLaVA15DPOTrainer:
             return
         os.makedirs(path, exist_ok=True)
         st = self.model.store
-        torch.save(dict(master=st.flat_master.cpu(), m=st.flat_m.cpu(), v=st.flat_v.cpu(), state=self.state),
-                   os.path.join(path, "optimizer.pt"))
+        # data position (epoch + batches consumed in it) rides in self.state; the LoRA dropout counter too, so that a
+        # resumed run draws the masks the uninterrupted run would have drawn
+        torch.save(dict(master=st.flat_master.cpu(), m=st.flat_m.cpu(), v=st.flat_v.cpu(), state=self.state,
+                        dropout_step=int(self.model._dropout_step)), os.path.join(path, "optimizer.pt"))
         self._save(path)
 
     def load_checkpoint(self, path: str):
@@ -339,4 +454,6 @@ class LLaVA15DPOTrainer:
         st.flat_master.copy_(blob["master"]), st.flat_m.copy_(blob["m"]), st.flat_v.copy_(blob["v"])
         ops.cast_f32_to_bf16(st.flat_master, st.train_p)
         st.refresh_transposes(trainable_only=True)
-        self.state = blob["state"]
+        self.state = dict(dict(epoch=0, batches_in_epoch=0), **blob["state"])
+        self.model._dropout_step = int(blob.get("dropout_step", 0))
+        self._micro = 0

@@ -123,8 +123,19 @@ def run_case(name, cfg, n_pairs, text_len, prompt_len, seed, dpo_use_average=Fal
     print(name, "loss", float(loss), "logp", lp.tolist(), "->", path, os.path.getsize(path), "bytes")
 
 
+def fullwidth_cfg() -> "O.LlavaCfg":
+    """LLaVA-1.5-7B widths (d 4096, f 11008, V 32000, 32 heads; CLIP-ViT-L/14-336: 1024 wide, 24 layers, 336 px -> 576
+    patches) at TWO language-model layers: what the reference runs in about a minute on 8 vCPUs."""
+    return O.LlavaCfg(layers=2, model_max_length=2048)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if "--full-width" in sys.argv:
+        # production widths through the reference classes themselves: pins the oracle (and through it the HIP path) at
+        # the tile shapes the 7B step really uses, not only at hidden 256 / 512
+        run_case("fullwidth_l2_b2", fullwidth_cfg(), n_pairs=2, text_len=96, prompt_len=40, seed=21)
+        sys.exit(0)
     # grouped-query attention (num_key_value_heads < heads) through the same reference classes
     run_case("tiny_b2_gqa", O.tiny_gqa_cfg(), n_pairs=2, text_len=40, prompt_len=12, seed=4)
     if "--gqa-only" in sys.argv:

@@ -1,0 +1,191 @@
+"""Numeric parity AT the BASELINE.json configurations (VERDICT r1 "what's missing" #4):
+
+  * config 1 shape - 4 synthetic 336-px pairs, text length T = 512 -> spliced length L = 1087, full 7B widths, CLIP-L/14-336 at
+    full depth, 4 language-model layers: HIP forward + backward vs the fp32 CPU oracle run on the GPU box's host cores;
+  * config 2 at FULL DEPTH - 32 layers, L = 2048, one pair: forward log-probs / DPO loss vs the fp32 oracle (27 GB of fp32
+    weights on the host, a few minutes);
+  * the full-width golden produced by the REFERENCE ITSELF (tests/golden/fullwidth_l2_b2.pt): HIP forward + backward.
+
+Bars (north_star): token indexing bit exact; sequence log-prob sums and the DPO loss within 1e-3 RELATIVE; per-token
+log-probs within 3e-2; gradients: per-tensor norm within 3 %, direction cosine >= 0.99.  The measured numbers are written to
+gpurun_out/parity_r02.json (copied to profiles/ by hand).
+"""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dpo_oracle as O  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _need_big_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2**30:
+        pytest.skip("needs the 288 GB part")
+
+
+def _host_ram_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 2**20
+    except OSError:
+        pass
+    return 0.0
+
+
+def _record(key, value):
+    path = os.path.join(REPO, "gpurun_out", "parity_r02.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    blob = {}
+    if os.path.exists(path):
+        try:
+            blob = json.load(open(path))
+        except ValueError:
+            blob = {}
+    blob[key] = value
+    json.dump(blob, open(path, "w"), indent=1)
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _model(cfg, W):
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)), with_optimizer=False)
+    model.load_state_dict(W)
+    return model
+
+
+def _trainer(model):
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    return LLaVA15DPOTrainer(model=model, args=TrainingArguments())
+
+
+def _check_forward(out, loss, ref, tag):
+    lp, lp_ref = out.seq_logp.cpu(), ref["log_prob"].detach()
+    rel = ((lp - lp_ref).abs() / lp_ref.abs()).max().item()
+    mask = ref["labels"][:, 1:] != -100
+    tok_err = (out.per_token_logp.cpu() - ref["per_token_logps"].detach()[mask]).abs().max().item()
+    loss_rel = abs(float(loss) - float(ref["loss"])) / abs(float(ref["loss"]))
+    print(f"[{tag}] seq log-prob {lp.tolist()} vs oracle {lp_ref.tolist()}: max rel err {rel:.2e}; per-token max err "
+          f"{tok_err:.2e}; loss {float(loss):.6f} vs {float(ref['loss']):.6f} (rel {loss_rel:.2e})")
+    assert torch.equal(out.plan.tgt.cpu().long(), ref["labels"][:, 1:][mask])          # token indexing: bit exact
+    assert out.seq_cnt.cpu().tolist() == mask.sum(1).float().tolist()
+    assert rel <= 1e-3 and tok_err <= 3e-2 and loss_rel <= 1e-3
+    return dict(seq_logp=lp.tolist(), seq_logp_oracle=lp_ref.tolist(), seq_logp_max_rel_err=rel, per_token_max_abs_err=tok_err,
+                loss=float(loss), loss_oracle=float(ref["loss"]), loss_rel_err=loss_rel)
+
+
+@pytest.mark.timeout(1500)
+def test_config1_shape_vs_oracle():
+    """BASELINE config 1's batch (4 pairs, T = 512 -> L = 1087) at 4 layers of full width: forward AND backward."""
+    _need_big_gpu()
+    cfg = O.LlavaCfg(layers=4, model_max_length=2048)
+    W = O.make_weights(cfg, seed=31)
+    model = _model(cfg, W)
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, 4, 512, 64, seed=31, ragged=True)
+    assert batch["concatenated_input_ids"].shape == (8, 512)
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    model.backward(out, model.last_coef)
+    grads = model.grads_state_dict()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(128, os.cpu_count() or 8))
+    for k in O.trainable_names(cfg):
+        W[k].requires_grad_(True)
+    t0 = time.time()
+    ref = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)
+    ref["loss"].backward()
+    t_cpu = time.time() - t0
+    assert ref["labels"].shape == (8, 1087)
+    rec = _check_forward(out, loss, ref, "config-1 shape, 4 layers")
+    worst_norm, worst_cos = 0.0, 1.0
+    for k in O.trainable_names(cfg):
+        g_ref = W[k].grad
+        n_ref = float(g_ref.double().norm())
+        if n_ref < 1e-9:
+            continue
+        rel = abs(float(grads[k].double().norm()) - n_ref) / n_ref
+        c = _cos(grads[k], g_ref)
+        worst_norm, worst_cos = max(worst_norm, rel), min(worst_cos, c)
+        assert rel <= 3e-2 and c >= 0.99, (k, rel, c)
+    print(f"  backward: worst per-tensor grad-norm rel err {worst_norm:.2e}, worst cosine {worst_cos:.5f}; oracle fwd+bwd {t_cpu:.1f} s")
+    rec.update(grad_worst_norm_rel_err=worst_norm, grad_worst_cosine=worst_cos, oracle_fwd_bwd_s=t_cpu, layers=4, pairs=4,
+               L=1087, threads=torch.get_num_threads())
+    _record("config1_shape_4layers", rec)
+
+
+@pytest.mark.timeout(2400)
+def test_full_depth_7b_forward_vs_oracle():
+    """BASELINE config 2 at full depth: all 32 layers, L = 2048, one pair - forward log-probs and loss vs the fp32 oracle."""
+    _need_big_gpu()
+    if _host_ram_gb() < 120:
+        pytest.skip("the fp32 oracle of the 7B model needs ~100 GB of host RAM")
+    cfg = O.LlavaCfg(model_max_length=2048)
+    t0 = time.time()
+    W = O.make_weights(cfg, seed=32)
+    t_w = time.time() - t0
+    model = _model(cfg, W)
+    model.eval()
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, 1, 2048 - 575, 64, seed=32, ragged=True)
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    assert out.plan.L > 2048 and out.plan.S == 1                     # packed pair
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(128, os.cpu_count() or 8))
+    t0 = time.time()
+    with torch.no_grad():
+        ref = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)
+    t_cpu = time.time() - t0
+    assert ref["labels"].shape == (2, 2048)
+    rec = _check_forward(out, loss, ref, "full depth 7B, L = 2048")
+    print(f"  weights {t_w:.0f} s, oracle forward {t_cpu:.0f} s on {torch.get_num_threads()} threads")
+    rec.update(oracle_fwd_s=t_cpu, layers=32, pairs=1, L=2048, threads=torch.get_num_threads())
+    _record("config2_full_depth_forward", rec)
+
+
+@pytest.mark.parametrize("share_prefix", [False, True])
+def test_fullwidth_reference_golden(golden_dir, share_prefix, monkeypatch):
+    """Production widths through the reference classes themselves (tests/golden/make_golden.py --full-width)."""
+    _need_big_gpu()
+    g = torch.load(os.path.join(golden_dir, "fullwidth_l2_b2.pt"), weights_only=False)
+    monkeypatch.setenv("SFT_weight", str(g["sft_weight"]))
+    monkeypatch.setenv("DPO_weight", "1.0")
+    cfg = O.LlavaCfg(**g["cfg"])
+    model = _model(cfg, O.make_weights(cfg, seed=g["seed"]))
+    model.share_prefix = share_prefix
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, g["n_pairs"], g["text_len"], g["prompt_len"], seed=g["seed"])
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    ref = dict(log_prob=g["log_prob"], labels=g["labels"], per_token_logps=g["per_token_logps"], loss=g["loss"])
+    rec = _check_forward(out, loss, ref, f"full-width reference golden, share_prefix={share_prefix}")
+    if not share_prefix:
+        assert torch.equal(out.plan.labels.cpu(), g["labels"])
+    model.backward(out, model.last_coef)
+    grads = model.grads_state_dict()
+    worst = 0.0
+    for k, n_ref in g["grad_norms"].items():
+        if k not in grads:
+            assert "vision_tower" in k, k
+            continue
+        rel = abs(float(grads[k].double().norm()) - n_ref) / max(n_ref, 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 3e-2 or n_ref < 1e-6, (k, rel)
+    for k, gr in g["grad_full"].items():
+        assert _cos(grads[k], gr) >= 0.99, k
+    assert _cos(grads["model.embed_tokens.weight"].double().sum(-1), g["grad_embed_rowsum"]) >= 0.99
+    rec.update(grad_worst_norm_rel_err=worst)
+    _record(f"fullwidth_reference_golden_share{int(share_prefix)}", rec)

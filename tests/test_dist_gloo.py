@@ -62,6 +62,7 @@ def _worker(rank, world, port, q, lora=False):
     from rlaif_v_amd.trainer import TrainingArguments
     tr.args, tr.reducer, tr.train_dataset, tr.data_collator = TrainingArguments(per_device_train_batch_size=1), red, \
         list(range(10)), (lambda x: x)
+    tr.state = dict(global_step=0, epoch=0, batches_in_epoch=0)
     idx = [b[0] for b in tr.get_train_dataloader()]
     gathered = [None] * world
     dist.all_gather_object(gathered, idx)

@@ -334,3 +334,70 @@ def test_entrypoint_flag_surface():
     assert T.ModelArguments().mm_vision_select_layer == -1 and T.TrainingArguments().task == "LM"
     with pytest.raises(NotImplementedError):
         T.init_model(T.ModelArguments(), T.DataArguments(), T.TrainingArguments(task="LM"))
+
+
+def _bare_trainer(n, world=1, rank=0, bs=1, seed=42, **kw):
+    """A trainer shell for the host-side loop logic (no model, no GPU)."""
+    from rlaif_v_amd.trainer import GradReducer, LLaVA15DPOTrainer, TrainingArguments
+    tr = LLaVA15DPOTrainer.__new__(LLaVA15DPOTrainer)
+    tr.args = TrainingArguments(per_device_train_batch_size=bs, seed=seed, **kw)
+    tr.reducer = GradReducer()
+    tr.reducer.world_size = world
+    tr.train_dataset, tr.data_collator = list(range(n)), (lambda x: x)
+    tr.state = dict(global_step=0, log_history=[], epoch=0, batches_in_epoch=0)
+    os.environ["RANK"] = str(rank)
+    return tr
+
+
+def test_sampler_reshuffles_every_epoch_and_resumes_mid_epoch(monkeypatch):
+    """HF Trainer semantics the shipped script relies on (4 epochs over the data, auto-resume from checkpoint-*): a new
+    permutation per epoch, identical on every rank; a resumed run skips the batches its epoch already consumed; ranks get
+    equally many full batches; a rank without a single full batch raises instead of spinning."""
+    monkeypatch.setenv("RANK", "0")
+    tr = _bare_trainer(23, bs=2)
+    e0 = [b for b in tr.get_train_dataloader(0)]
+    e1 = [b for b in tr.get_train_dataloader(1)]
+    assert len(e0) == len(e1) == 11 and e0 != e1                       # reshuffled
+    assert [b for b in tr.get_train_dataloader(0)] == e0               # deterministic in (seed, epoch)
+    assert [b for b in tr.get_train_dataloader(0, skip_batches=4)] == e0[4:]        # resume position
+    flat = sorted(x for b in e0 for x in b)
+    assert len(set(flat)) == 22                                        # a permutation, drop_last
+    # world 3: disjoint equal shards of ONE permutation
+    shards = []
+    for r in range(3):
+        t = _bare_trainer(23, world=3, rank=r, bs=2)
+        shards.append([x for b in t.get_train_dataloader(5) for x in b])
+    assert all(len(s) == 6 for s in shards) and len(set(sum(shards, []))) == 18
+    os.environ["RANK"] = "0"
+    with pytest.raises(ValueError, match="no full batch"):
+        _bare_trainer(3, world=2, rank=0, bs=2).get_train_dataloader(0)
+
+
+def test_lr_schedules_and_rejected_flags():
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments, cosine_lr, lr_at
+    assert lr_at("cosine", 10, 100, 1.0, 0.05) == cosine_lr(10, 100, 1.0, 0.05)
+    assert lr_at("constant", 0, 100, 2.0, 0.5) == 2.0
+    assert lr_at("linear", 0, 100, 1.0, 0.1) == 0.0 and lr_at("linear", 5, 100, 1.0, 0.1) == 0.5
+    assert abs(lr_at("linear", 55, 100, 1.0, 0.1) - 0.5) < 1e-12 and lr_at("linear", 100, 100, 1.0, 0.1) == 0.0
+    assert lr_at("constant_with_warmup", 50, 100, 3.0, 0.1) == 3.0
+    # HF's own schedules agree (transformers is installed)
+    import transformers
+    p = torch.nn.Parameter(torch.zeros(1))
+    for kind in ("linear", "cosine", "constant_with_warmup"):
+        opt = torch.optim.SGD([p], lr=1.0)
+        sch = transformers.get_scheduler(kind, opt, num_warmup_steps=10, num_training_steps=100)
+        for step in range(0, 100, 7):
+            assert abs(sch.get_last_lr()[0] - lr_at(kind, step, 100, 1.0, 0.1)) < 1e-9, (kind, step)
+            for _ in range(7):
+                opt.step(), sch.step()
+    with pytest.raises(NotImplementedError, match="lr_scheduler_type"):
+        lr_at("polynomial", 1, 10, 1.0, 0.0)
+
+    class _M:                       # constructor-time validation needs no device
+        device = "cpu"
+        training = True
+        lora = None
+    with pytest.raises(NotImplementedError):
+        LLaVA15DPOTrainer(model=_M(), args=TrainingArguments(lr_scheduler_type="inverse_sqrt"))
+    with pytest.raises(ValueError):
+        LLaVA15DPOTrainer(model=_M(), args=TrainingArguments(gradient_accumulation_steps=0))

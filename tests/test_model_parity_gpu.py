@@ -3,8 +3,8 @@
 
 Bars (bf16 storage / fp32 accumulation vs an fp32 reference):
   * token indexing (spliced labels, selected rows, targets): BIT EXACT;
-  * per-token log-probs: |err| <= 3e-2;  sequence log-prob sums: relative 1e-3 (north_star tolerance) plus
-    5e-2 absolute;  DPO loss: 2e-3 relative + 2e-3 absolute;
+  * per-token log-probs: |err| <= 3e-2;  sequence log-prob sums and the DPO loss: 1e-3 RELATIVE (the north_star
+    tolerance; measured on MI355X: 1e-5 .. 1e-4);
   * gradients: per-tensor norm within 3 %, direction cosine >= 0.995 for the tensors stored in the fixture.
 """
 import os
@@ -76,9 +76,9 @@ def test_forward_matches_reference_golden(golden_dir, name, monkeypatch, share_p
     print(f"[{name}] per-token max err {err_tok:.3e}; seq logp err {err_lp.tolist()} of {ref_lp.tolist()}; "
           f"loss {float(loss):.6f} vs {float(g['loss']):.6f}")
     assert err_tok <= 3e-2
-    assert bool((err_lp <= 1e-3 * ref_lp.abs() + 5e-2).all())
-    torch.testing.assert_close(out.per_pair[0].cpu(), g["losses"], rtol=2e-3, atol=2e-3 + 0.1 * 5e-2)
-    torch.testing.assert_close(loss.cpu(), g["loss"], rtol=2e-3, atol=2e-3 + 0.1 * 5e-2)
+    assert bool((err_lp <= 1e-3 * ref_lp.abs()).all())
+    torch.testing.assert_close(out.per_pair[0].cpu(), g["losses"], rtol=1e-3, atol=1e-3)     # per-pair terms can be ~0
+    torch.testing.assert_close(loss.cpu(), g["loss"], rtol=1e-3, atol=0.0)
     torch.testing.assert_close(out.per_pair[1].cpu(), g["chosen_rewards"], rtol=2e-3, atol=1e-2)
     torch.testing.assert_close(out.per_pair[2].cpu(), g["rejected_rewards"], rtol=2e-3, atol=1e-2)
 
@@ -127,7 +127,7 @@ def test_training_step_matches_oracle():
         loss = tr.training_step(dict(batch))
         out_o, grads_o, gn_o = O.dpo_train_step(batch, Wo, cfg, state, lr=1e-3, step=step, sft_weight=0.0,
                                                 dpo_weight=1.0)
-        assert abs(float(loss) - float(out_o["loss"])) <= 2e-3 * abs(float(out_o["loss"])) + 7e-3
+        assert abs(float(loss) - float(out_o["loss"])) <= 1e-3 * abs(float(out_o["loss"])) * (1 if step == 1 else 3)
         gn = float(tr._clip[0])
         assert abs(gn - gn_o) <= 3e-2 * gn_o, (gn, gn_o)
         new = model.state_dict()
@@ -162,8 +162,8 @@ def test_full_width_shallow_vs_oracle():
     assert out.plan.S == 1 and out.plan.shared_len[0] > 0            # packed pair (default layout)
     err = (out.seq_logp.cpu() - ref["log_prob"].detach()).abs()
     print("full-width shallow: seq logp", out.seq_logp.tolist(), "ref", ref["log_prob"].tolist())
-    assert bool((err <= 1e-3 * ref["log_prob"].detach().abs() + 5e-2).all())
-    assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])) + 7e-3
+    assert bool((err <= 1e-3 * ref["log_prob"].detach().abs()).all())
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-3 * abs(float(ref["loss"]))
     ref["loss"].backward()
     model.backward(out, model.last_coef)
     grads = model.grads_state_dict()
@@ -206,8 +206,8 @@ def test_reference_logp_precompute(tmp_path, golden_dir):
         ref = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)
     for i in range(B):
         win_lp, win_avg, win_tok, rej_lp, rej_avg, rej_tok = logps[i]
-        assert abs(win_lp - float(ref["log_prob"][i])) <= 1e-3 * abs(float(ref["log_prob"][i])) + 5e-2
-        assert abs(rej_lp - float(ref["log_prob"][B + i])) <= 1e-3 * abs(float(ref["log_prob"][B + i])) + 5e-2
+        assert abs(win_lp - float(ref["log_prob"][i])) <= 1e-3 * abs(float(ref["log_prob"][i]))
+        assert abs(rej_lp - float(ref["log_prob"][B + i])) <= 1e-3 * abs(float(ref["log_prob"][B + i]))
         assert abs(win_avg - float(ref["average_log_prob"][i])) <= 5e-3
         # every position, incl. masked ones (log-prob of token id 0 there), in the reference's per-token layout
         n = len(win_tok)
@@ -312,7 +312,7 @@ def test_full_size_7b_properties():
     assert out2.plan.S == 4 and out2.plan.L == 2048
     assert torch.equal(cnt, cnt_plain)
     assert torch.equal(cnt, (labels[:, 1:] != -100).sum(1).float())                             # (iv)
-    tol = 1e-3 * lp_plain.abs() + 5e-2
+    tol = 1e-3 * lp_plain.abs()
     assert bool(((lp_packed - lp_plain).abs() <= tol).all()), (lp_packed, lp_plain)             # (ii)
     # (i) pair 0 alone, and with 37 extra right-pad tokens (pad id 0, label -100)
     sel = torch.tensor([0, 2])
@@ -362,7 +362,7 @@ def test_minicpm_label_convention_matches_oracle():
         lp, avg = O.get_batch_logps_minicpm(O.llama_logits(emb, W, cfg), lab)
         lp_std, _ = O.get_batch_logps(O.llama_logits(emb, W, cfg), lab)
     assert out.seq_cnt.cpu().tolist() == (lab[:, :-1] != -100).sum(1).float().tolist()
-    assert bool(((out.seq_logp.cpu() - lp).abs() <= 1e-3 * lp.abs() + 5e-2).all()), (out.seq_logp, lp)
+    assert bool(((out.seq_logp.cpu() - lp).abs() <= 1e-3 * lp.abs()).all()), (out.seq_logp, lp)
     assert (lp - lp_std).abs().max() > 0.1              # the two conventions really differ (a random-init model: not by much)
     # forward_DPO (trainers.py:66-88): the generic branch's three return modes
     from rlaif_v_amd.trainer import compute_weighted_logp, forward_DPO
@@ -370,8 +370,8 @@ def test_minicpm_label_convention_matches_oracle():
     got_avg = forward_DPO(model, ids, labs, None, imgs, dpo_use_average=True, is_minicpm=True).cpu()
     assert bool(((got_avg - avg).abs() <= 2e-3 * avg.abs() + 5e-3).all())
     got_std = forward_DPO(model, ids, labs, None, imgs).cpu()
-    assert bool(((got_std - lp_std).abs() <= 1e-3 * lp_std.abs() + 5e-2).all())
+    assert bool(((got_std - lp_std).abs() <= 1e-3 * lp_std.abs()).all())
     per_tok = forward_DPO(model, ids, labs, None, imgs, token_weighted=True)
     w = torch.ones(per_tok.shape)
     wl = compute_weighted_logp(per_tok, lab, w, False).cpu()         # unit weights: equals the plain sum
-    assert bool(((wl - lp_std).abs() <= 1e-3 * lp_std.abs() + 5e-2).all())
+    assert bool(((wl - lp_std).abs() <= 1e-3 * lp_std.abs()).all())

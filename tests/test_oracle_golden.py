@@ -121,3 +121,27 @@ def test_logp_reductions_match_reference_functions(golden_dir):
                      (O.compute_weighted_logp(pt, labels, weight, True), "weighted_avg")):
         torch.testing.assert_close(got, g[key], rtol=0, atol=0, equal_nan=True)
     assert torch.isnan(avg[3]) and torch.isnan(avgm[3])
+
+
+def test_oracle_matches_reference_at_full_width(golden_dir):
+    """The oracle pinned at PRODUCTION widths (d 4096, f 11008, V 32000, 32 heads, CLIP-L/14-336 at full depth, 2 LM layers)
+    against the reference classes themselves (tests/golden/make_golden.py --full-width): forward and backward in one pass."""
+    g = _load(golden_dir, "fullwidth_l2_b2")
+    cfg = O.LlavaCfg(**g["cfg"])
+    assert (cfg.hidden, cfg.ffn, cfg.vocab, cfg.clip_hidden, cfg.clip_layers, cfg.image_size) == (4096, 11008, 32000, 1024, 24, 336)
+    W = O.make_weights(cfg, seed=g["seed"])
+    batch = O.make_synthetic_batch(cfg, g["n_pairs"], g["text_len"], g["prompt_len"], seed=g["seed"])
+    for k in O.trainable_names(cfg):
+        W[k].requires_grad_(True)
+    out = O.dpo_step_forward(batch, W, cfg, dpo_use_average=g["dpo_use_average"], sft_weight=g["sft_weight"], dpo_weight=1.0)
+    assert torch.equal(out["labels"], g["labels"])
+    mask = g["labels"][:, 1:] != -100
+    torch.testing.assert_close(out["per_token_logps"][mask].detach(), g["per_token_logps"][mask], rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(out["log_prob"].detach(), g["log_prob"], rtol=2e-5, atol=0)
+    torch.testing.assert_close(out["loss"].detach(), g["loss"], rtol=1e-4, atol=0)
+    out["loss"].backward()
+    for k, ref in g["grad_norms"].items():
+        got = float(W[k].grad.double().norm())
+        assert abs(got - ref) <= 5e-4 * max(ref, 1e-6) + 1e-7, (k, got, ref)
+    for k, ref in g["grad_full"].items():
+        torch.testing.assert_close(W[k].grad, ref, rtol=5e-3, atol=1e-6)

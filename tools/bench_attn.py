@@ -34,11 +34,8 @@ def main():
         o, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d)
         out = torch.empty_like(o)
         t_f = timeit(lambda: ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, 2 * d, out=out))
-        delta = torch.empty(S, H, L, dtype=torch.float32, device=dev)
-        hip.call("rv_attn_delta", do, do.stride(0), o, o.stride(0), delta, S, L, H, hd)
         dqkv = torch.empty_like(qkv)
-        t_b = timeit(lambda: hip.call("rv_attn_bwd", qkv, qkv.stride(0), 0, d, 2 * d, do, do.stride(0), lse,
-                                      delta, dqkv, dqkv.stride(0), S, L, H, hd, 1, 1.0 / math.sqrt(hd), None, None))
+        t_b = timeit(lambda: ops.attn_bwd(qkv, o, do, lse, S, L, H, hd, True, 0, d, 2 * d, dqkv=dqkv))
         fl = 4.0 * S * H * L * L * hd / 2
         print(f"L={L}: fwd {t_f:.3f} ms ({fl / t_f / 1e9:.0f} TF/s)  bwd(dq+dkv) {t_b:.3f} ms ({2.5 * fl / t_b / 1e9:.0f} TF/s)"
               f"  per-L^2: fwd {t_f / L / L * 1e6:.3f} bwd {t_b / L / L * 1e6:.3f}", flush=True)

@@ -1,0 +1,89 @@
+"""Micro-benchmark of the step's dominant kernels at the bench shape (8 packed pairs, 27,664 tokens): the NN / TN GEMMs of
+one decoder layer and the packed-pair attention forward / backward.  Also the target of the PMC passes
+(tools/pmc_hot_kernels.sh).  Usage: python tools/bench_hot_kernels.py [--iters 5] [--only gemm|attn]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rlaif_v_amd import ops  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def timeit(fn, iters, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def packed_attention_inputs(dev, B=8, H=32, hd=128, shared=638, tail=1410):
+    """Rows shaped like the bench's packed pairs: [shared | chosen tail | rejected tail]."""
+    L = shared + 2 * tail
+    d = H * hd
+    qkv = (torch.randn(B * L, 3 * d, device=dev) * 0.5).to(BF)
+    do = (torch.randn(B * L, d, device=dev) * 0.5).to(BF)
+    seg_sh = torch.full((B,), shared, dtype=torch.int32, device=dev)
+    seg_e1 = torch.full((B,), shared + tail, dtype=torch.int32, device=dev)
+    return qkv, do, (seg_sh, seg_e1), L, d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    R = 27664
+    if a.only in ("", "gemm"):
+        for name, N, K in [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]:
+            x = torch.randn(R, K, device=dev).to(BF)
+            wT = (torch.randn(K, N, device=dev) * 0.02).to(BF)
+            out = torch.empty(R, N, device=dev, dtype=BF)
+            ms = timeit(lambda: ops.gemm_nn(x, wT, out=out), a.iters)
+            print(f"nn {name:8s} {R}x{N}x{K}: {ms:.3f} ms {2.0 * R * N * K / ms / 1e9:7.1f} TF/s", flush=True)
+        for name, I, J in [("wqkv", 12288, 4096), ("wo", 4096, 4096), ("wgu", 22016, 4096), ("wdown", 4096, 11008)]:
+            p = torch.randn(R, I, device=dev).to(BF)
+            q = torch.randn(R, J, device=dev).to(BF)
+            out = torch.empty(I, J, device=dev, dtype=BF)
+            ms = timeit(lambda: ops.gemm_tn(p, q, out=out), a.iters)
+            print(f"tn {name:8s} {R}: {I}x{J}: {ms:.3f} ms {2.0 * R * I * J / ms / 1e9:7.1f} TF/s", flush=True)
+    if a.only in ("", "attn"):
+        B, H, hd = 8, 32, 128
+        qkv, do, seg, L, d = packed_attention_inputs(dev, B, H, hd)
+        # algorithmic (q, k) pairs of one packed row: shared causal + each tail sees shared and itself causally
+        sh, tl = int(seg[0][0]), int(seg[1][0] - seg[0][0])
+        pairs = sh * (sh + 1) / 2 + 2 * (tl * sh + tl * (tl + 1) / 2)
+        fl_f = 4.0 * B * H * pairs * hd
+        o, lse = ops.attn_fwd(qkv, B, L, H, hd, True, 0, d, 2 * d, seg=seg)
+        out = torch.empty_like(o)
+        t_f = timeit(lambda: ops.attn_fwd(qkv, B, L, H, hd, True, 0, d, 2 * d, out=out, seg=seg), a.iters)
+        dqkv = torch.empty_like(qkv)
+        t_b = timeit(lambda: ops.attn_bwd(qkv, o, do, lse, B, L, H, hd, True, 0, d, 2 * d, dqkv=dqkv, seg=seg), a.iters)
+        print(f"attn packed L={L} (shared {sh}, tails {tl}): fwd {t_f:.3f} ms ({fl_f / t_f / 1e9:.0f} TF/s algorithmic)  "
+              f"bwd (delta+dq+dkv) {t_b:.3f} ms ({2.5 * fl_f / t_b / 1e9:.0f} TF/s algorithmic)", flush=True)
+        # plain causal rows of the reference layout for comparison (16 x 2048)
+        S2, L2 = 16, 2048
+        qkv2 = (torch.randn(S2 * L2, 3 * d, device=dev) * 0.5).to(BF)
+        do2 = (torch.randn(S2 * L2, d, device=dev) * 0.5).to(BF)
+        o2, lse2 = ops.attn_fwd(qkv2, S2, L2, H, hd, True, 0, d, 2 * d)
+        t_f2 = timeit(lambda: ops.attn_fwd(qkv2, S2, L2, H, hd, True, 0, d, 2 * d, out=o2), a.iters)
+        dq2 = torch.empty_like(qkv2)
+        t_b2 = timeit(lambda: ops.attn_bwd(qkv2, o2, do2, lse2, S2, L2, H, hd, True, 0, d, 2 * d, dqkv=dq2), a.iters)
+        fl2 = 4.0 * S2 * H * (L2 * (L2 + 1) / 2) * hd
+        print(f"attn plain  16 x 2048: fwd {t_f2:.3f} ms ({fl2 / t_f2 / 1e9:.0f} TF/s)  bwd {t_b2:.3f} ms ({2.5 * fl2 / t_b2 / 1e9:.0f} TF/s)",
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()
