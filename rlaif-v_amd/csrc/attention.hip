@@ -228,6 +228,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
               if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) sacc[kt][r] = -INFINITY;
             }
         }
+        // V^T fragments of the first 16 keys are requested NOW: they do not depend on P, so their LDS latency hides under
+        // the softmax VALU work; afterwards the fragments of 16-key group kk+1 are in flight while group kk multiplies.
+        const uint32_t vs_addr = lds_addr_of(Vs);
+        bf16x8_t vA[ET], vB[ET];
+#pragma unroll
+        for (int e = 0; e < ET; ++e) vA[e] = tro.read(vs_addr, 0, e);
         float tmax = -INFINITY;                      // raw-score maximum (c > 0 keeps the order)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -255,17 +261,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
         }
-        const uint32_t vs_addr = lds_addr_of(Vs);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const bf16x8_t pf = pack_frag(sacc[kk >> 1], (kk & 1) * 8);
-          bf16x8_t vfr[ET];
+          bf16x8_t (&vcur)[ET] = (kk & 1) ? vB : vA;
+          bf16x8_t (&vnxt)[ET] = (kk & 1) ? vA : vB;
+          if (kk < 3) {
 #pragma unroll
-          for (int e = 0; e < ET; ++e) vfr[e] = tro.read(vs_addr, kk * 16, e);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int e = 0; e < ET; ++e) vnxt[e] = tro.read(vs_addr, (kk + 1) * 16, e);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ET) : "memory");   // everything older than the 2*ET reads just issued
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int e = 0; e < ET; ++e) o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[e], pf, o[e], 0, 0, 0);
+          for (int e = 0; e < ET; ++e) o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[e], pf, o[e], 0, 0, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -394,6 +404,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
             const bf16x8_t vf = *(const bf16x8_t*)(Vs + boff[ks] + kt * 32 * HD * 2);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
           }
+          // K^T fragments of the first 16 keys: independent of dS, requested before the exp section (latency hidden)
+          const uint32_t ks_addr = lds_addr_of(Ks);
+          bf16x8_t kfr0[ET], kfr1[ET];
+#pragma unroll
+          for (int e = 0; e < ET; ++e) kfr0[e] = tro.read(ks_addr, kt * 32, e);
           const bool need_mask = (k0 + 63 >= L) || (CAUSAL && k0 + 63 > q0w) ||
                                  (q0w + 31 >= e1 && k0 + 63 >= sh && k0 < e1);
           if (need_mask) {
@@ -408,17 +423,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
             const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse_q));   // masked: exp2(-inf) = 0
             sacc[r] = p * (pacc[r] - delta_q);
           }
-          const uint32_t ks_addr = lds_addr_of(Ks);
+          {
+            const bf16x8_t df = pack_frag(sacc, 0);
 #pragma unroll
-          for (int k2 = 0; k2 < 2; ++k2) {
-            const bf16x8_t df = pack_frag(sacc, k2 * 8);
-            bf16x8_t kfr[ET];
+            for (int e = 0; e < ET; ++e) kfr1[e] = tro.read(ks_addr, kt * 32 + 16, e);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ET) : "memory");     // kfr0 landed; kfr1 may still be in flight
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < ET; ++e) kfr[e] = tro.read(ks_addr, kt * 32 + k2 * 16, e);
+            for (int e = 0; e < ET; ++e) dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr0[e], df, dq[e], 0, 0, 0);
+          }
+          {
+            const bf16x8_t df = pack_frag(sacc, 8);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < ET; ++e) dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[e], df, dq[e], 0, 0, 0);
+            for (int e = 0; e < ET; ++e) dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr1[e], df, dq[e], 0, 0, 0);
           }
         }
       }
