@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "librlaifv_hip.so")
 SOURCES = ["gemm.hip", "elementwise.hip", "attention.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm.hpp"), os.path.join(INCLUDE, "rlaifv_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm.hpp"), os.path.join(CSRC, "attn_agpr.inc"), os.path.join(INCLUDE, "rlaifv_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
@@ -41,9 +41,16 @@ def build_extension(force: bool = False, verbose: bool = True, defines=(), tag: 
     hipcc = _hipcc()
     lib = LIB if not tag else LIB.replace(".so", f"{tag}.so")
     objs, jobs = [], []
+    only = tuple(x for x in os.environ.get("RV_BUILD_ONLY", "").split(",") if x)     # experiment builds: sources the defines touch
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(bdir, src.replace(".hip", ".o"))
+        if tag and only and src not in only:
+            o = os.path.join(HERE, "build", src.replace(".hip", ".o"))       # unchanged source: the shipped build's object
+            if not os.path.exists(o):
+                raise RuntimeError("build the shipped library first (its objects are reused by experiment builds)")
+            objs.append(o)
+            continue
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
             jobs.append([hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", s, "-o", o])

@@ -13,6 +13,7 @@
 #include "rlaifv_hip.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -205,15 +206,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         dma.issue(vbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE + TILE, wave);
       }
       if (!(CAUSAL && k0 > q0w + 31) && !(q0w >= e1 && k0 >= sh && k0 + 63 < e1)) {
+        // S^T = K Q^T.  The K fragments are fetched in groups of four explicit ds_read_b128, group g+1 in flight while
+        // group g multiplies (the compiler's own schedule was read / wait / MFMA sixteen times per tile).  Fragment ks of
+        // a row sits at chunk (2 ks + half) ^ swz(row): address = address(ks = 0) ^ (ks << 5).
+        constexpr int NG = KS / 2;                  // a group = fragments (ks, ks + 1) of BOTH 32-key halves: 4 reads, 4 MFMAs
+        const uint32_t ka0 = lds_addr_of(Ks) + boff[0];
         f32x16_t sacc[2];
+        zero16(sacc[0]);
+        zero16(sacc[1]);
+        bf16x8_t kA[4], kB[4];                       // element j of a group: half kt = j & 1, k step 2 g + (j >> 1)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          zero16(sacc[kt]);
+        for (int j = 0; j < 4; ++j) kA[j] = ds_read_b128_asm(ka0 ^ (uint32_t)((j >> 1) << 5), (j & 1) * 32 * HD * 2);
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t kf = *(const bf16x8_t*)(Ks + boff[ks] + kt * 32 * HD * 2);
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+        for (int g = 0; g < NG; ++g) {
+          bf16x8_t (&kcur)[4] = (g & 1) ? kB : kA;
+          bf16x8_t (&knxt)[4] = (g & 1) ? kA : kB;
+          if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              knxt[j] = ds_read_b128_asm(ka0 ^ (uint32_t)((2 * (g + 1) + (j >> 1)) << 5), (j & 1) * 32 * HD * 2);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)     // the two halves alternate: consecutive MFMAs never share an accumulator
+            sacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[j], qf[2 * g + (j >> 1)], sacc[j & 1], 0, 0, 0);
         }
         // The tile needs element masks only when it touches the sequence end, the causal diagonal of this wave
         // or the chosen-branch window of a packed pair; interior tiles (the vast majority) skip ~200 VALU ops.
@@ -392,17 +411,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
         dma.issue(vbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE + TILE, wave);
       }
       if (!(CAUSAL && k0 > q0w + 31) && !(q0w >= e1 && k0 >= sh && k0 + 63 < e1)) {
+        const uint32_t ka0 = lds_addr_of(Ks) + boff[0];       // fragment ks: ka0 ^ (ks << 5); V tile = K tile + TILE
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+          // S^T = K Q^T and dP^T = V dO^T.  Explicit reads, one pair {K[ks], V[ks]} per step in a 3-slot ring: pairs ks+1
+          // and ks+2 are in flight while pair ks multiplies (the compiler's schedule exposed one LDS latency per pair).
           f32x16_t sacc, pacc;
           zero16(sacc);
           zero16(pacc);
+          bf16x8_t fr3[3][2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              fr3[p][j] = ds_read_b128_asm(ka0 ^ (uint32_t)(p << 5), j * TILE + kt * 32 * HD * 2);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t kf = *(const bf16x8_t*)(Ks + boff[ks] + kt * 32 * HD * 2);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
-            const bf16x8_t vf = *(const bf16x8_t*)(Vs + boff[ks] + kt * 32 * HD * 2);
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+            if (ks + 2 < KS) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                fr3[(ks + 2) % 3][j] = ds_read_b128_asm(ka0 ^ (uint32_t)((ks + 2) << 5), j * TILE + kt * 32 * HD * 2);
+              asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            } else if (ks + 1 < KS) {
+              asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr3[ks % 3][0], qf[ks], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr3[ks % 3][1], dof[ks], pacc, 0, 0, 0);
           }
           // K^T fragments of the first 16 keys: independent of dS, requested before the exp section (latency hidden)
           const uint32_t ks_addr = lds_addr_of(Ks);
@@ -678,6 +715,348 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
   }  // pass
 }
 
+
+// =============================================================================================
+// backward, dK/dV, version 3.  Same decomposition, tiles, LDS image and arithmetic as version 2 (bit-identical results);
+// what changes is who schedules the inner loop.  rocprofv3 PMC on version 2 (profiles/r02_pmc_hot_kernels_before.txt):
+// MFMA busy 23 % of cycles, 40 % of the wave's time parked in s_waitcnt, 450 VALU instructions per 64-query tile.  Its ISA
+// shows why: with all 256 architectural VGPRs in use hipcc emits "ds_read_b128 x2, s_waitcnt lgkmcnt(0), MFMA x2" per k
+// step (sixteen exposed LDS latencies per tile: one wave per SIMD, nothing else to run), a v_add per LDS address and
+// 32 v_mov per sub-tile to clear accumulators.  Here:
+//   * K / V fragments live in AGPRs (MFMA reads its B operand from the accumulator file) - 64 VGPRs back;
+//   * every LDS read is an explicit asm read off ONE per-lane base register per fragment column with the buffer / tile /
+//     sub-tile selected by the 16-bit immediate (the tile loop is unrolled by two so the buffer index is static);
+//   * the Q / dO row fragments of a 32-query sub-tile are fetched in two batches of 8 reads: batch 1 is in flight while
+//     batch 0 multiplies, and both batches of the second sub-tile are requested while the first one's dV / dK MFMAs run;
+//   * S / dP accumulate in VGPRs through asm MFMAs whose first instruction takes the inline constant 0 as C.
+// =============================================================================================
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+#include "attn_agpr.inc"
+
+// ABL (experiment builds only, -DRV_ATTN_EXPERIMENTS; results are WRONG by construction): 1 = no exp / dS arithmetic,
+// 2 = no dV / dK MFMAs, 3 = no S / dP MFMAs, 4 = no transposing LDS reads, 5 = no row-fragment LDS reads, 6 = no DMA of the
+// next tile.  Timing deltas against ABL 0 price the stages (cdna_hip_programming.md 5.4 rule 17: values stay live).
+template <bool CAUSAL, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
+                                                               int k_col0, int v_col0,
+                                                               const bf16_t* __restrict__ dO, long lddo,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
+                                                               int nx, float scale, const int* __restrict__ seg_sh,
+                                                               const int* __restrict__ seg_e1, int kv_group) {
+  constexpr int HD = 128, KS = 8, ET = 4;
+  constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64] = 0x8200
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, half = lane >> 5;
+  int bx, h, s;
+  attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
+  const long tok0 = (long)s * L;
+  const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
+  const int nkb = (L + 127) / 128;
+  const float c = scale * LOG2E;
+  const int HQ = H * kv_group;
+
+  int d_row[4], d_chunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d_row[i] = (wave * 4 + i) * 4 + (lane >> 4);
+    d_chunk[i] = (lane & 15) ^ (((d_row[i] & 3) << 2) | ((d_row[i] >> 2) & 3));
+  }
+  const uint32_t ldqb = (uint32_t)(ld * 2), lddob = (uint32_t)(lddo * 2);       // row strides in bytes (L * stride < 2^32: checked by the launcher)
+  // One LDS-DMA piece of tile t into buffer buf: j = 0..7 -> Q piece j>>1 (even j) / dO piece j>>1 (odd j); j = 8: lse and
+  // delta of the tile (wave 0).  An LDS-DMA issue occupies the wave for 60-180 cycles (address path); with one wave per
+  // SIMD nothing else would run meanwhile, so the pieces are issued one by one BETWEEN the MFMAs of the dV / dK segment,
+  // whose matrix work keeps executing underneath.
+  auto issue_piece = [&](int hq, int t, int buf, int j) {
+    if (ABL == 6 && t > 0) return;
+    uint8_t* st = smem + buf * STAGE;
+    // the tile index goes through an opaque scalar: the address arithmetic below is then computed HERE (a handful of
+    // 32-bit VALU in the shadow of the surrounding MFMAs) instead of being hoisted to the top of the tile, where nine
+    // 64-bit addresses stay live across the whole body (the causal instantiation spilled)
+    int qs0 = t * 64;
+    asm volatile("" : "+s"(qs0));
+    if (j < 8) {
+      const int i = j >> 1;
+      const uint32_t r = (uint32_t)min(qs0 + d_row[i], L - 1);           // row inside sequence s (< 2^16)
+      if ((j & 1) == 0) {
+        const char* base = (const char*)(qkv + tok0 * ld + q_col0 + hq * HD);      // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (r * ldqb + d_chunk[i] * 16u)),
+                                         (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
+      } else {
+        const char* base = (const char*)(dO + tok0 * lddo + hq * HD);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (r * lddob + d_chunk[i] * 16u)),
+                                         (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+      }
+    } else if (wave == 0) {
+      const int qq = min(qs0 + lane, L - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse + ((long)s * HQ + hq) * L + qq),
+                                       (__attribute__((address_space(3))) void*)(st + 32768), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta + ((long)s * HQ + hq) * L + qq),
+                                       (__attribute__((address_space(3))) void*)(st + 32768 + 256), 4, 0, 0);
+    }
+  };
+  auto issue_tile = [&](int hq, int t, int buf) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) issue_piece(hq, t, buf, j);
+  };
+
+  // per-lane LDS bases (buffer 0, Q tile, sub-tile 0); everything else is an immediate:
+  //   row fragment ks of row fr:  rb[ks] + BUF*STAGE + isdO*16384 + qt*8192
+  //   transposing read (u, et):    tb[u][et] + BUF*STAGE + isdO*16384 + (qt*32 + k2*16)*256     (all < 65536)
+  const uint32_t lds0 = lds_addr_of(smem);
+  uint32_t rb[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) rb[ks] = lds0 + qtile_off(fr, 2 * ks + half);
+  uint32_t lh = lds0 + 32768u + (uint32_t)(half * 16);   // lse / delta: floats 4*half .. 4*half+3 of each group of 8 queries
+  const int g4 = lane >> 4, s16 = lane & 15;
+  uint32_t tb[2][ET];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+      tb[u][et] = lds0 + qtile_off(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
+                  (uint32_t)((s16 & 1) * 8);
+
+  const int npass = CAUSAL ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int kvb = (pass == 0) ? bx : (nkb - 1 - bx);
+    if (pass == 1 && kvb <= bx) break;
+    const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
+    const int key = kv0w + fr, keyc = min(key, L - 1);
+
+    // B operands of S^T / dP^T: K / V fragments of this wave's 32 keys, loaded STRAIGHT INTO fixed AGPRs (gfx90a+ vector
+    // memory can target the accumulator file); dK / dV accumulate in fixed AGPRs as well (map in attn_agpr.inc).  With
+    // compiler-allocated "a" operands the causal instantiation copied 16-register tiles around every MFMA.
+    {
+      const bf16_t* kp = qkv + (tok0 + keyc) * ld + h * HD + 8 * half;
+      static_for<KS>([&](auto ic) {
+        constexpr int ks = decltype(ic)::value;
+        frag_load<ks>(kp + k_col0 + 16 * ks);
+        frag_load<8 + ks>(kp + v_col0 + 16 * ks);
+      });
+      static_for<8>([&](auto ic) { acc_zero<decltype(ic)::value>(); });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // asm loads are invisible to hipcc's own wait bookkeeping
+    }
+
+    const int t_begin = CAUSAL ? (kv0 / 64) : 0;
+    const int nt = (kv0 >= sh && kv0 + 127 < e1) ? min((L + 63) / 64, (e1 + 63) / 64) : (L + 63) / 64;
+
+    // One 64-query tile out of LDS buffer `buf`.  The per-lane read bases (rb, tb, lh) already point INTO that buffer: they
+    // are flipped by +-STAGE at the end of every tile (17 VALU), so one copy of the body serves both buffers and the
+    // immediates stay compile-time (two unrolled copies made hipcc shuffle the 128 accumulator registers between them).
+    auto tile = [&](const int hq, const int t, const int buf) {
+      constexpr int SB = 0;
+      const int BUF = buf;
+      const int qs0 = t * 64;
+      // the tile fetched meanwhile: t + 1, or once more the last one (into the buffer nobody reads any more) - the DMA
+      // issues inside the MFMA stream stay UNCONDITIONAL: a branch there splits the segment into basic blocks and hipcc
+      // then copies a 16-register accumulator between them at every seam
+      const int tn = min(t + 1, nt - 1);
+      // this wave's 32 keys see nothing of the tile (above the causal diagonal, or rejected-branch queries x chosen-branch
+      // keys): it only issues its share of the next tile's DMA
+      if ((CAUSAL && qs0 + 63 < kv0w) || (qs0 >= e1 && kv0w >= sh && kv0w + 31 < e1)) {
+        issue_tile(hq, tn, BUF ^ 1);
+      } else {
+        bf16x8_t fq[KS], fo[KS];                   // row fragments of the current sub-tile: Q[ks], dO[ks]
+        // batch 0 (k steps 0-3) of sub-tile 0; batch 1 follows behind the first wait
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          fq[ks] = ds_read_b128_asm(rb[ks], SB);
+          fo[ks] = ds_read_b128_asm(rb[ks], SB + 16384);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const int QO = SB + qt * 8192;           // immediate part of this sub-tile's row-fragment reads
+          f32x16_t sacc, pacc;
+          // ---- S^T = Q K^T, dP^T = dO V^T : batch 1 in flight while batch 0 multiplies
+#pragma unroll
+          for (int ks = 4; ks < KS; ++ks) {
+            if (ABL == 5 && qt == 1) continue;
+            fq[ks] = ds_read_b128_asm(rb[ks], QO);
+            fo[ks] = ds_read_b128_asm(rb[ks], QO + 16384);
+          }
+          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // batch 0 landed (8 reads of batch 1 may be in flight)
+          __builtin_amdgcn_sched_barrier(0);
+          smfma_first<0>(sacc, fq[0]);
+          smfma_first<8>(pacc, fo[0]);
+          static_for<3>([&](auto ic) {
+            constexpr int ks = decltype(ic)::value + 1;
+            if (ABL == 3) { asm volatile("" ::"v"(fq[ks]), "v"(fo[ks])); return; }
+            smfma<ks>(sacc, fq[ks]);
+            smfma<8 + ks>(pacc, fo[ks]);
+          });
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // batch 1 landed
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<3>([&](auto ic) {
+            constexpr int ks = decltype(ic)::value + 4;
+            if (ABL == 3) { asm volatile("" ::"v"(fq[ks]), "v"(fo[ks])); return; }
+            smfma<ks>(sacc, fq[ks]);
+            smfma<8 + ks>(pacc, fo[ks]);
+          });
+          smfma_last2(sacc, fq[KS - 1], pacc, fo[KS - 1]);
+          // lse and delta of this lane's 16 queries (4 consecutive floats per accumulator row group): explicit reads
+          // issued AHEAD of the transposing reads - the exp section never waits for a fresh LDS round trip.  Two halves
+          // (rows groups 0-1, then 2-3) to keep the register footprint at 16.
+          f32x4_t lsev[2], delv[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            lsev[j] = ds_read_f32x4_asm(lh, SB + qt * 128 + j * 32);
+            delv[j] = ds_read_f32x4_asm(lh, SB + 256 + qt * 128 + j * 32);
+          }
+          // transposed fragments of the first 16 queries (independent of P / dS): latency hidden by the exp section
+          bf16x8_t dotf0[ET], qtf0[ET], dotf1[ET], qtf1[ET];
+          const int TO = SB + qt * 32 * 256;
+#pragma unroll
+          for (int e = 0; e < ET; ++e) {
+            dotf0[e] = __builtin_shufflevector(ds_tr16_b64_asm(tb[0][e], TO + 16384), ds_tr16_b64_asm(tb[1][e], TO + 16384),
+                                               0, 1, 2, 3, 4, 5, 6, 7);
+            qtf0[e] = __builtin_shufflevector(ds_tr16_b64_asm(tb[0][e], TO), ds_tr16_b64_asm(tb[1][e], TO), 0, 1, 2, 3, 4, 5,
+                                              6, 7);
+          }
+          const int qsub = qs0 + qt * 32;                      // first query of this 32-row sub-tile
+          const bool need_mask = (qsub + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qsub) ||
+                                 (qsub + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
+          if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int qg = qsub + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (qg >= L || key >= L || (CAUSAL && key > qg) || (qg >= e1 && key >= sh && key < e1)) sacc[r] = -INFINITY;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");   // first lse / delta half landed (the 16 transposing reads stay in flight)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            if (ABL == 1) { asm volatile("" ::"v"(lsev[r >> 2]), "v"(delv[r >> 2])); continue; }
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -LOG2E * lsev[r >> 2][r & 3]));
+            sacc[r] = p;
+            pacc[r] = p * (pacc[r] - delv[r >> 2][r & 3]);
+          }
+          // second half: requested now (behind the transposing reads in the LDS queue), consumed after the first pack
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            lsev[j] = ds_read_f32x4_asm(lh, SB + qt * 128 + (j + 2) * 32);
+            delv[j] = ds_read_f32x4_asm(lh, SB + 256 + qt * 128 + (j + 2) * 32);
+          }
+          const bf16x8_t pf0 = pack_frag(sacc, 0), dsf0 = pack_frag(pacc, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 8; r < 16; ++r) {
+            if (ABL == 1) { asm volatile("" ::"v"(lsev[(r >> 2) - 2]), "v"(delv[(r >> 2) - 2])); continue; }
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -LOG2E * lsev[(r >> 2) - 2][r & 3]));
+            sacc[r] = p;
+            pacc[r] = p * (pacc[r] - delv[(r >> 2) - 2][r & 3]);
+          }
+          const bf16x8_t pf1 = pack_frag(sacc, 8), dsf1 = pack_frag(pacc, 8);
+#pragma unroll
+          for (int e = 0; e < ET; ++e)
+            dotf1[e] = __builtin_shufflevector(ds_tr16_b64_asm(tb[0][e], TO + 16384 + 16 * 256),
+                                               ds_tr16_b64_asm(tb[1][e], TO + 16384 + 16 * 256), 0, 1, 2, 3, 4, 5, 6, 7);
+          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // everything older than the 8 reads just issued
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<ET>([&](auto ic) {
+            constexpr int e = decltype(ic)::value;
+            if (ABL == 2) asm volatile("" ::"v"(dotf0[e]), "v"(pf0), "v"(qtf0[e]), "v"(dsf0));
+            if (ABL != 2) acc_mfma<4 + e>(dotf0[e], pf0);
+            if (qt == 0) { __builtin_amdgcn_sched_barrier(0); issue_piece(hq, tn, BUF ^ 1, 2 * e); __builtin_amdgcn_sched_barrier(0); }
+            if (ABL != 2) acc_mfma<e>(qtf0[e], dsf0);
+            if (qt == 0) { __builtin_amdgcn_sched_barrier(0); issue_piece(hq, tn, BUF ^ 1, 2 * e + 1); __builtin_amdgcn_sched_barrier(0); }
+          });
+#pragma unroll
+          for (int e = 0; e < ET; ++e)
+            qtf1[e] = __builtin_shufflevector(ds_tr16_b64_asm(tb[0][e], TO + 16 * 256), ds_tr16_b64_asm(tb[1][e], TO + 16 * 256),
+                                              0, 1, 2, 3, 4, 5, 6, 7);
+          if (qt == 0) {
+            // both batches' worth of registers are free (their MFMAs were issued long ago): request batch 0 of the
+            // second sub-tile now, its latency hides under the remaining dV / dK MFMAs
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              if (ABL == 5) continue;
+              fq[ks] = ds_read_b128_asm(rb[ks], SB + 8192);
+              fo[ks] = ds_read_b128_asm(rb[ks], SB + 8192 + 16384);
+            }
+            asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // dotf1 landed (16 younger reads may be in flight)
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // dotf1 landed
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<ET>([&](auto ic) {
+            if (ABL == 2) { asm volatile("" ::"v"(dotf1[decltype(ic)::value]), "v"(pf1)); return; }
+            acc_mfma<4 + decltype(ic)::value>(dotf1[decltype(ic)::value], pf1);
+          });
+          if (qt == 0) { __builtin_amdgcn_sched_barrier(0); issue_piece(hq, tn, BUF ^ 1, 8); __builtin_amdgcn_sched_barrier(0); }
+          if (qt == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // qtf1 landed (batch 0 of sub-tile 1 may be in flight)
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<ET>([&](auto ic) {
+            if (ABL == 2) { asm volatile("" ::"v"(qtf1[decltype(ic)::value]), "v"(dsf1)); return; }
+            acc_mfma<decltype(ic)::value>(qtf1[decltype(ic)::value], dsf1);
+          });
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      const uint32_t flip = buf ? (uint32_t)(-STAGE) : (uint32_t)STAGE;       // bases follow the buffer of the NEXT tile
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) rb[ks] += flip;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int et = 0; et < ET; ++et) tb[u][et] += flip;
+      lh += flip;
+    };
+
+    for (int gq = 0; gq < kv_group; ++gq) {
+      const int hq = h * kv_group + gq;
+      issue_tile(hq, t_begin, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int t = t_begin; t < nt; ++t) tile(hq, t, (t - t_begin) & 1);
+      if ((nt - t_begin) & 1) {                    // an odd number of tiles leaves the bases in buffer 1: back to buffer 0
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) rb[ks] -= STAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int et = 0; et < ET; ++et) tb[u][et] -= STAGE;
+        lh -= STAGE;
+      }
+    }  // query heads of the group
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
+
+    bf16_t* kp_out = dqkv + (tok0 + keyc) * lddq + h * HD;
+    static_for<ET>([&](auto ic) {
+      constexpr int e = decltype(ic)::value;
+      f32x16_t dk_e, dv_e;
+      acc_read<e>(dk_e);
+      acc_read<4 + e>(dv_e);
+      if (key < L) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          uint2 w;
+          w.x = pack2bf(dk_e[rg * 4 + 0] * scale, dk_e[rg * 4 + 1] * scale);
+          w.y = pack2bf(dk_e[rg * 4 + 2] * scale, dk_e[rg * 4 + 3] * scale);
+          *(uint2*)(kp_out + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
+          w.x = pack2bf(dv_e[rg * 4 + 0], dv_e[rg * 4 + 1]);
+          w.y = pack2bf(dv_e[rg * 4 + 2], dv_e[rg * 4 + 3]);
+          *(uint2*)(kp_out + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
+        }
+      }
+    });
+  }  // pass
+}
+
 }  // namespace
 
 extern "C" {
@@ -721,6 +1100,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   RV_REQUIRE(kv_group >= 1 && H % kv_group == 0, "rv_attn_bwd: kv_group must divide the number of query heads");
   RV_REQUIRE((seg_sh == nullptr) == (seg_e1 == nullptr), "rv_attn_bwd: seg_sh and seg_e1 go together");
   RV_REQUIRE(ld % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0, "rv_attn_bwd: alignment");
+  RV_REQUIRE((double)L * (double)(ld > lddo ? ld : lddo) * 2.0 < 4.0e9, "rv_attn_bwd: one sequence must span < 4 GB of the qkv / dO buffers");
   if (S == 0 || L == 0) return 0;
   const int nb = (L + 127) / 128;
   static int map_mode = -1;
@@ -732,11 +1112,26 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   constexpr int DQ_LDS = 4 * 64 * 256;
   constexpr int DKV_LDS = 2 * (2 * 64 * 256 + 512);
   static bool attr_done = false;
+  static int dkv_version = 3;
+  static int dkv_ablate = 0;
+  (void)dkv_ablate;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+#ifdef RV_ATTN_EXPERIMENTS
+    hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    { const char* a = getenv("RV_DKV_ABLATE"); if (a) dkv_ablate = atoi(a); }
+#endif
+    const char* e = getenv("RV_ATTN_DKV");        // A/B knob: 2 = the compiler-scheduled version-2 kernel
+    if (e && atoi(e) == 2) dkv_version = 2;
     attr_done = true;
   }
   // dQ: one workgroup per (query head, query block); dK/dV: per (KEY/VALUE head, key block), looping over its query heads
@@ -747,11 +1142,22 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_HEAD, (const bf16_t*)O, ldo, lse, delta, BWD_TAIL(H));
     RV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+    if (dkv_version == 2)
+      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+#ifdef RV_ATTN_EXPERIMENTS
+#define RV_ABL_LAUNCH(N) else if (dkv_ablate == N) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, N>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+    RV_ABL_LAUNCH(1) RV_ABL_LAUNCH(2) RV_ABL_LAUNCH(3) RV_ABL_LAUNCH(5) RV_ABL_LAUNCH(6)
+#undef RV_ABL_LAUNCH
+#endif
+    else
+      hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
   } else {
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, block, DQ_LDS, st, BWD_HEAD, (const bf16_t*)O, ldo, lse, delta, BWD_TAIL(H));
     RV_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+    if (dkv_version == 2)
+      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+    else
+      hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
   }
 #undef BWD_HEAD
 #undef BWD_TAIL

@@ -75,6 +75,22 @@ __device__ __forceinline__ bf16x8_t ds_tr16_pair_asm(uint32_t lds_addr, int off_
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)p; }
 
+// ds_read_b128 through inline asm.  hipcc schedules a row-fragment loop "read, s_waitcnt lgkmcnt(0), MFMA" one fragment
+// at a time once registers are tight (attention kernels: 16 exposed LDS latencies per tile, seen in the ISA); explicit
+// reads let the kernel keep a group of fragments in flight behind the MFMAs of the previous group.  Same contract as
+// ds_tr16_b64_asm: the CALLER waits (counted lgkmcnt) and fences with __builtin_amdgcn_sched_barrier(0) before the first use.
+__device__ __forceinline__ bf16x8_t ds_read_b128_asm(uint32_t lds_addr, int imm_offset) {
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(imm_offset) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ f32x4_t ds_read_f32x4_asm(uint32_t lds_addr, int imm_offset) {
+  f32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(imm_offset) : "memory");
+  return v;
+}
+
 // Error plumbing for the C ABI (no exceptions across the boundary).
 void rv_set_error(const char* msg);
 #define RV_CHECK_LAUNCH()                                   \

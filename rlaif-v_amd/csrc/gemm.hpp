@@ -15,6 +15,16 @@
 
 #include "common.hpp"
 
+// Experiment switches (tools/ builds only; the shipped library uses the defaults):
+//   RV_GEMM_PRIO_MODE  0 = s_setprio 1 around every MFMA segment (default), 1 = static: the younger wave group at priority 1
+//                      for the whole main loop, no per-segment flips, 2 = no priority changes at all
+//   RV_GEMM_DMA_SLOT   the MFMA slot (mod 4) after which a wave issues one LDS-DMA piece (default 1)
+#ifndef RV_GEMM_PRIO_MODE
+#define RV_GEMM_PRIO_MODE 0
+#endif
+#ifndef RV_GEMM_DMA_SLOT
+#define RV_GEMM_DMA_SLOT 1
+#endif
 #define GEMM_BM 128
 #define GEMM_BN 128
 #define GEMM_BK 64
@@ -630,6 +640,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   }
   __builtin_amdgcn_s_barrier();
   if (wi == 1) __builtin_amdgcn_s_barrier();
+  if (RV_GEMM_PRIO_MODE == 1 && wi == 1) __builtin_amdgcn_s_setprio(1);     // wi is wave-uniform (readfirstlane)
 
   // STEADY tiles (all but the last DIST+1): the fetched tile p+DIST is neither past the end nor ragged, so its DMA
   // needs no validity select and no branch, and uses pointers advanced once per tile (see gemm_nt_256_kernel)
@@ -677,7 +688,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (RV_GEMM_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);
     const bool dma = (p + DIST < nt);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -687,14 +698,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
         for (int tj = 0; tj < 2; ++tj) {
           acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks][tj], pf[ks][ti], acc[ti][tj], 0, 0, 0);
           const int k = (ks * 4 + ti) * 2 + tj;
-          if ((k & 3) == 1) {
+          if ((k & 3) == RV_GEMM_DMA_SLOT) {
             __builtin_amdgcn_sched_barrier(0);
             if (STEADY) issue_piece_run(p + DIST, k >> 2);
             else if (dma) issue_piece(p + DIST, k >> 2);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-    __builtin_amdgcn_s_setprio(0);
+    if (RV_GEMM_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1016,6 +1027,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+  if (RV_GEMM_PRIO_MODE == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);     // wm is wave-uniform (readfirstlane)
 
   // running sources of the pieces issued in M-seg(p): A tile (p>>1)+2, B tile p+3 (clamped to the last tile at the end:
   // the redundant loads land in stages nobody reads any more)
@@ -1061,7 +1073,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (RV_GEMM_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1070,7 +1082,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
         for (int tn = 0; tn < 2; ++tn) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
           const int k = (ks * 4 + tm) * 2 + tn;
-          if ((k & 3) == 1) {
+          if ((k & 3) == RV_GEMM_DMA_SLOT) {
             const int j = k >> 2;                                  // 0: A, 1: B, 2: A, 3: B
             __builtin_amdgcn_sched_barrier(0);
             if (MODE == 1) {
@@ -1084,7 +1096,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-    __builtin_amdgcn_s_setprio(0);
+    if (RV_GEMM_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);

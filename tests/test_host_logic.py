@@ -401,3 +401,15 @@ def test_lr_schedules_and_rejected_flags():
         LLaVA15DPOTrainer(model=_M(), args=TrainingArguments(lr_scheduler_type="inverse_sqrt"))
     with pytest.raises(ValueError):
         LLaVA15DPOTrainer(model=_M(), args=TrainingArguments(gradient_accumulation_steps=0))
+
+
+def test_dkv3_isa_has_no_compiler_agpr_traffic():
+    """attn_bwd_dkv3_kernel addresses the accumulator file by hard register numbers (csrc/attn_agpr.inc).  That is only
+    sound while hipcc itself never touches AGPRs in that kernel (no spill-to-AGPR, no scratch): audit the generated ISA."""
+    import shutil
+    import subprocess
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    out = subprocess.run(["bash", os.path.join(REPO, "tools", "check_agpr_isa.sh")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-500:]
+    assert "instructions in dkv3: 0" in out.stdout
