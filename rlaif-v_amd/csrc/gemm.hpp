@@ -15,12 +15,18 @@
 
 #include "common.hpp"
 
-// Experiment switches (tools/ builds only; the shipped library uses the defaults):
-//   RV_GEMM_PRIO_MODE  0 = s_setprio 1 around every MFMA segment (default), 1 = static: the younger wave group at priority 1
-//                      for the whole main loop, no per-segment flips, 2 = no priority changes at all
-//   RV_GEMM_DMA_SLOT   the MFMA slot (mod 4) after which a wave issues one LDS-DMA piece (default 1)
-#ifndef RV_GEMM_PRIO_MODE
-#define RV_GEMM_PRIO_MODE 0
+// Wave-priority schedule of the ping-pong kernels, measured A/B on one box (tools/exp_gemm_variants.py,
+// profiles/r02_gemm_variants_ab.log; 27,664-token step shapes):
+//   0 = s_setprio 1 around every MFMA segment, 1 = static: the second wave group at priority 1 for the whole main loop,
+//   2 = no priority changes.  TN (weight gradients): 1 beats 0 by +7.3 / +8.2 % (2: +6.3 / +6.7 %); NN: 2 beats 0 by
+//   +0.6 %, 1 loses 0.5 %.  Defaults below; -DRV_GEMM_PRIO_MODE=n forces one mode on both (experiment builds).
+//   RV_GEMM_DMA_SLOT = the MFMA slot (mod 4) after which a wave issues one LDS-DMA piece (0..3 within +-1 %: default 1).
+#ifdef RV_GEMM_PRIO_MODE
+#define RV_GEMM_PRIO_TN RV_GEMM_PRIO_MODE
+#define RV_GEMM_PRIO_NN RV_GEMM_PRIO_MODE
+#else
+#define RV_GEMM_PRIO_TN 1
+#define RV_GEMM_PRIO_NN 2
 #endif
 #ifndef RV_GEMM_DMA_SLOT
 #define RV_GEMM_DMA_SLOT 1
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   }
   __builtin_amdgcn_s_barrier();
   if (wi == 1) __builtin_amdgcn_s_barrier();
-  if (RV_GEMM_PRIO_MODE == 1 && wi == 1) __builtin_amdgcn_s_setprio(1);     // wi is wave-uniform (readfirstlane)
+  if (RV_GEMM_PRIO_TN == 1 && wi == 1) __builtin_amdgcn_s_setprio(1);     // wi is wave-uniform (readfirstlane)
 
   // STEADY tiles (all but the last DIST+1): the fetched tile p+DIST is neither past the end nor ragged, so its DMA
   // needs no validity select and no branch, and uses pointers advanced once per tile (see gemm_nt_256_kernel)
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (RV_GEMM_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);
+    if (RV_GEMM_PRIO_TN == 0) __builtin_amdgcn_s_setprio(1);
     const bool dma = (p + DIST < nt);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-    if (RV_GEMM_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);
+    if (RV_GEMM_PRIO_TN == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1027,7 +1033,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
-  if (RV_GEMM_PRIO_MODE == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);     // wm is wave-uniform (readfirstlane)
+  if (RV_GEMM_PRIO_NN == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);     // wm is wave-uniform (readfirstlane)
 
   // running sources of the pieces issued in M-seg(p): A tile (p>>1)+2, B tile p+3 (clamped to the last tile at the end:
   // the redundant loads land in stages nobody reads any more)
@@ -1073,7 +1079,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (RV_GEMM_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);
+    if (RV_GEMM_PRIO_NN == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1096,7 +1102,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-    if (RV_GEMM_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);
+    if (RV_GEMM_PRIO_NN == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
