@@ -337,10 +337,19 @@ def main():
             line["dp_overlap_probe_1rank"] = dp_probe
         if world == 1 and not args.no_cpu_baseline and not args.lora:     # the CPU leg times the full-FT oracle step
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio (flushed at exit, i.e. AFTER a Python print): drain it first so
+        # that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -730,13 +730,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 //     batch 0 multiplies, and both batches of the second sub-tile are requested while the first one's dV / dK MFMAs run;
 //   * S / dP accumulate in VGPRs through asm MFMAs whose first instruction takes the inline constant 0 as C.
 // =============================================================================================
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
 #include "attn_agpr.inc"
 
 // ABL (experiment builds only, -DRV_ATTN_EXPERIMENTS; results are WRONG by construction): 1 = no exp / dS arithmetic,

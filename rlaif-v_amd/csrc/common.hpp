@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 typedef uint16_t bf16_t;  // raw bf16 bits
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16, 4 VGPR)
@@ -89,6 +91,16 @@ __device__ __forceinline__ f32x4_t ds_read_f32x4_asm(uint32_t lds_addr, int imm_
   f32x4_t v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(imm_offset) : "memory");
   return v;
+}
+
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}): a loop whose index is a template constant
+// (hard-register asm helpers are selected by it)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
 }
 
 // Error plumbing for the C ABI (no exceptions across the boundary).

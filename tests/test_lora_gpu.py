@@ -72,8 +72,8 @@ def test_lora_forward_backward_vs_oracle(monkeypatch, r, share_prefix):
     err_lp = (out.seq_logp.cpu() - ref["log_prob"].detach()).abs()
     print(f"lora r={r}: per-token err {err_tok:.3e}, seq err {err_lp.tolist()}, loss {float(loss):.6f} vs {float(ref['loss'].detach()):.6f}")
     assert err_tok <= 3e-2
-    assert bool((err_lp <= 1e-3 * ref["log_prob"].abs() + 5e-2).all())
-    assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])) + 7e-3
+    assert bool((err_lp <= 1e-3 * ref["log_prob"].abs()).all())
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-3 * abs(float(ref["loss"]))
     got = model.grads_state_dict()
     assert set(got) == set(grads), (sorted(set(got) ^ set(grads))[:6])
     worst = 1.0
@@ -247,3 +247,41 @@ def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch):
     # and the masks really were applied: the no-dropout oracle differs measurably
     ref0, _ = _oracle_grads(batch, W, cfg, 16 / 64)
     assert (ref0["log_prob"] - ref["log_prob"]).abs().max() > 1e-3
+
+
+def test_lora_full_width_shallow_vs_oracle(monkeypatch):
+    """BASELINE config 5's adapter shapes at production widths: r = 64 on all seven projections of 2 full-width layers
+    (d 4096, f 11008): the fused NN-form LoRA GEMM (256-wide column groups), the split-K adapter gradients and the frozen
+    base, against the fp32 oracle.  (The oracle's adapter arithmetic is pinned to peft only when the wheel is present:
+    tests/golden/make_lora_golden.py; until then this row stays 'parity unpinned' against peft itself.)"""
+    _need_gpu()
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2**30:
+        pytest.skip("needs the 288 GB part")
+    monkeypatch.setenv("SFT_weight", "0.0")
+    monkeypatch.setenv("DPO_weight", "1.0")
+    cfg = O.LlavaCfg(layers=2, clip_layers=3, image_size=112, model_max_length=2048)      # 64 patches, 3-layer CLIP-L width
+    model, W = _build(cfg, 64, seed=13)
+    model.train()
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, 2, 96, 24, seed=13)
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    model.backward(out, model.last_coef)
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    ref, grads = _oracle_grads(batch, W, cfg, 16 / 64)
+    lp_ref = ref["log_prob"].detach()
+    rel = ((out.seq_logp.cpu() - lp_ref).abs() / lp_ref.abs()).max().item()
+    loss_rel = abs(float(loss) - float(ref["loss"].detach())) / abs(float(ref["loss"].detach()))
+    print(f"LoRA full width: seq log-prob max rel err {rel:.2e}, loss rel err {loss_rel:.2e}")
+    assert rel <= 1e-3 and loss_rel <= 1e-3
+    got = model.grads_state_dict()
+    assert set(got) == set(grads)
+    worst_cos, worst_rel = 1.0, 0.0
+    for k, gref in grads.items():
+        n = float(gref.double().norm())
+        if n < 1e-9:
+            continue
+        worst_cos = min(worst_cos, _cos(got[k], gref))
+        worst_rel = max(worst_rel, abs(float(got[k].double().norm()) - n) / n)
+    print(f"  adapter / projector gradients: worst cosine {worst_cos:.5f}, worst norm rel err {worst_rel:.2e}")
+    assert worst_cos >= 0.99 and worst_rel <= 3e-2
