@@ -252,22 +252,15 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   epi.narrow = epi_narrow();
   static bool attr_done = false;
   static int use_a64 = 1;          // RV_GEMM_NN_A64=0: 32-deep A tiles (gemm_nn_256_kernel) also when K % 64 == 0
-  static int use_w4 = 0;           // RV_GEMM_NN_W4=1: the four-wave 128x128-per-wave kernel (A/B knob)
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_nn_256_kernel<EpiStore>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
     hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
-    hipFuncSetAttribute((const void*)gemm_nn_w4_kernel<EpiStore>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
     const char* e = getenv("RV_GEMM_NN_A64");
     if (e) use_a64 = atoi(e);
-    e = getenv("RV_GEMM_NN_W4");
-    if (e) use_w4 = atoi(e);
     attr_done = true;
   }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
-  if (use_w4 && K % 64 == 0 && K >= 512)
-    hipLaunchKernelGGL((gemm_nn_w4_kernel<EpiStore>), dim3(tiles_m * tiles_n), dim3(G5_THREADS), G4_LDS_BYTES,
-                       (hipStream_t)stream, g, epi);
-  else if (use_a64 && K % 64 == 0 && K >= 512)
+  if (use_a64 && K % 64 == 0 && K >= 512)
     hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
                        (hipStream_t)stream, g, epi);
   else

@@ -1126,213 +1126,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
 }
 
-// =============================================================================================
-// NN GEMM "W4": the same 256x256 tile, LDS image, rings and LDS-DMA schedule as gemm_nn_a64_kernel, consumed by FOUR waves -
-// one per SIMD with the whole 512-register file - instead of eight: per-wave output 128x128 = 4x4 MFMA tiles, accumulated in
-// a[0:255] (hard registers, gemm_agpr.inc).  Why: under the 1.4 kW cap the chip runs these GEMMs at 1.5-1.6 GHz
-// (profiles/r02_gemm_power_clock_probe.log) with the matrix pipe 79 % busy (profiles/r02_pmc_hot_kernels_before.txt) -
-// throughput is set by energy per flop, not by idle cycles.  A 128x128 wave tile takes 16 MFMAs per 8 fragment reads instead of
-// 8 per 6 (-33 % LDS read traffic per flop), needs ONE barrier per 32 MFMAs instead of two per 16, and no ping-pong
-// bookkeeping; the fillers of a half phase (12 LDS reads + 4 LDS-DMA issues per 16 MFMAs) are hand-placed in the MFMA
-// shadows (<= 2 per gap).  hipBLASLt's best kernel on these shapes is the same decomposition (MT256x256x64, 256 threads).
-//
-// Phase p (32 of K) = two half phases (k16 steps):
-//     half 0:  16 MFMAs on fragment set 0  ||  reads of (p, step 1) -> set 1  ||  4 DMA pieces
-//     vmcnt(12)  lgkmcnt(0)  s_barrier                   [B(p+1)]
-//     half 1:  16 MFMAs on fragment set 1  ||  reads of (p+1, step 0) -> set 0  ||  4 DMA pieces
-//     lgkmcnt(0)
-// DMA of phase p: A pieces 4(p&1)..+3 (of this wave's 8) of A tile (p>>1)+2, B pieces 0..3 of B tile p+3.
-// Hazards.  RAW: B(p+1) sits behind every wave's vmcnt(12) = "all but the 8 pieces of phase p-1 and the 4 of this half have
-//   landed", i.e. everything issued up to phase p-2: B tile p+1 (phase p-2) and A tile (p+1)>>1 (phases <= p-2); the reads of
-//   (p+1, step 0) come after it.  WAR: B stage (p+3)%4 held tile p-1, last read in half 0 of phase p-1 and retired
-//   (lgkmcnt(0)) before B(p); A stage ((p>>1)+2)%3 held tile (p>>1)-1, last read in half 0 of phase 2(p>>1)-1, before
-//   B(2(p>>1)); both barriers precede phase p.  Prologue A0 B0 | A1 B1 B2: vmcnt(16) + barrier, phase 0 waits vmcnt(8).
-// Requires K % 64 == 0, K >= 512.
-// =============================================================================================
-#include "gemm_agpr.inc"
-#define G5_THREADS 256
-
-template <class Epi>
-__global__ __launch_bounds__(G5_THREADS, 1) void gemm_nn_w4_kernel(GemmShape g, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* const smA = smem;
-  uint8_t* const smB = smem + 3 * G4_A_STAGE;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
-  const int nwg = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  const int GROUP = g.group > 0 ? g.group : 4;
-  const int group_size = GROUP * tiles_n;
-  const int first_m = (id / group_size) * GROUP;
-  const int gsz = min(tiles_m - first_m, GROUP);
-  const int tile_m = first_m + (id % group_size) % gsz;
-  const int tile_n = (id % group_size) / gsz;
-  const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
-  const long ldb = g.ldb;
-
-  // ---- LDS-DMA sources (per lane).  A tile (64 deep): 32 pieces of 8 rows x 128 B, this wave owns pieces 8w..8w+7;
-  //      B tile (32 deep): 16 pieces of 2 k-rows x 512 B, this wave owns pieces 4w..4w+3.  Images as in gemm_nn_a64_kernel.
-  const bf16_t* a_run[8];
-  const bf16_t* b_run[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = (wave * 8 + i) * 8 + (lane >> 3);
-    const int kc = (lane & 7) ^ ((row >> 1) & 7);
-    a_run[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 2 + (lane >> 5);
-    const int c = lane & 31;
-    const int col = (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3);
-    b_run[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
-  }
-  const uint32_t a_piece0 = (uint32_t)(wave * 8) * 1024u, b_piece0 = (uint32_t)(wave * 4) * 1024u;
-  auto issue_a = [&](int T, int i, const bf16_t* src) {      // piece i (0..7) of A tile T
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(smA + (T % 3) * G4_A_STAGE + a_piece0 + i * 1024),
-                                     16, 0, 0);
-  };
-  auto issue_b = [&](int t, int i, const bf16_t* src) {      // piece i (0..3) of B tile t
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(smB + (t % 4) * G4_B_STAGE + b_piece0 + i * 1024),
-                                     16, 0, 0);
-  };
-
-  // ---- fragment read bases
-  const int fr = lane & 31, half = lane >> 5;
-  const uint32_t lds0 = lds_addr_of(smem);
-  const uint32_t a_row_off = (uint32_t)((wm * 128 + fr) * 128);
-  const int a_sw = (fr >> 1) & 7;
-  uint32_t a_pre[2];                       // k16 step ks of the FIRST 32-deep half of an A tile; the second half = ^ 64
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) a_pre[ks] = lds0 + a_row_off + (uint32_t)((((ks * 2 + half) ^ a_sw)) << 4);
-  const int g4 = lane >> 4, s16 = lane & 15;
-  const uint32_t lane_part = (uint32_t)((8 * (g4 >> 1) + (s16 >> 2)) * 512 + 32 * (g4 & 1) + 8 * (s16 & 3));
-  uint32_t q_blk[4];                       // 64-byte column block wn*4 + t of the B tile, swizzled
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    q_blk[t] = lds0 + 3u * G4_A_STAGE + lane_part + (uint32_t)((((wn * 4 + t) ^ (s16 >> 2))) << 6);
-
-  static_for<16>([&](auto ic) { gacc_zero<decltype(ic)::value>(); });
-
-  const int nt1 = g.K / G2_BK;             // 32-deep phases (even)
-  // prologue: A0 B0 | A1 B1 B2
-#pragma unroll
-  for (int i = 0; i < 8; ++i) issue_a(0, i, a_run[i]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) issue_b(0, i, b_run[i]);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) issue_a(1, i, a_run[i] + 64);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) issue_b(1, i, b_run[i] + (long)G2_BK * ldb);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) issue_b(2, i, b_run[i] + 2L * G2_BK * ldb);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a_run[i] += 2 * 64;                  // -> A tile 2
-#pragma unroll
-  for (int i = 0; i < 4; ++i) b_run[i] += 3L * G2_BK * ldb;        // -> B tile 3
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  bf16x8_t fa[2][4], fb[2][4];             // fragment sets: [k16 step parity][tile]
-  // reads of (phase p, step ks) into set ks: A fragment tm at +tm*4096 (32 rows), B fragment tn = two transposing reads
-  auto a_addr = [&](int p, int ks) -> uint32_t {
-    return (a_pre[ks] ^ ((uint32_t)(p & 1) << 6)) + (uint32_t)(((p >> 1) % 3) * G4_A_STAGE);
-  };
-  {
-    const uint32_t va = a_addr(0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) fa[0][t] = ds_read_b128_asm(va, t * 4096);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) fb[0][t] = ds_tr16_pair_asm(q_blk[t], 0, 2048);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  // One half phase: 16 MFMAs on set CUR while set CUR^1 is loaded for (pn, ksn) and 4 DMA pieces are issued.
-  // DMA: d = 0..3 -> A piece / B piece alternately (aidx / bidx = first piece of this half), MODE 1 = steady (running
-  // pointers, unconditional), MODE 0 = tail (B tile p+3 only while it exists).
-  auto half_phase = [&](auto cur_c, const int pn, const int ksn, const int p, auto half_c, auto h_c, auto mode_c) {
-    constexpr int CUR = decltype(cur_c)::value, NXT = CUR ^ 1;
-    constexpr int HALF = decltype(half_c)::value;          // 0 / 1: which half of phase p (selects the DMA pieces)
-    constexpr int H = decltype(h_c)::value;                // p & 1 in steady phases (A piece group)
-    constexpr int MODE = decltype(mode_c)::value;
-    const uint32_t va = a_addr(pn, ksn);
-    const uint32_t vb = (uint32_t)((pn % 4) * G4_B_STAGE + ksn * 8192);
-    static_for<16>([&](auto ic) {
-      constexpr int idx = decltype(ic)::value, tm = idx >> 2, tn = idx & 3;
-      gacc_mfma<idx>(fb[CUR][tn], fa[CUR][tm]);
-      if constexpr (idx < 4) fa[NXT][idx] = ds_read_b128_asm(va, idx * 4096);
-      else if constexpr (idx < 8) fb[NXT][idx - 4] = ds_tr16_pair_asm(q_blk[idx - 4] + vb, 0, 2048);
-      if constexpr ((idx & 3) == 3) {
-        constexpr int d = idx >> 2;                        // 0: A, 1: B, 2: A, 3: B
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MODE == 1) {
-          if constexpr ((d & 1) == 0) issue_a((p >> 1) + 2, 4 * H + 2 * HALF + (d >> 1), a_run[4 * H + 2 * HALF + (d >> 1)]);
-          else issue_b(p + 3, 2 * HALF + (d >> 1), b_run[2 * HALF + (d >> 1)]);
-        } else {
-          if constexpr ((d & 1) == 1) {
-            if (p + 3 < nt1) issue_b(p + 3, 2 * HALF + (d >> 1), b_run[2 * HALF + (d >> 1)]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    });
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  auto phase = [&](const int p, auto h_c, auto mode_c) {
-    constexpr int MODE = decltype(mode_c)::value;
-    half_phase(I0{}, p, 1, p, I0{}, h_c, mode_c);
-    if (MODE == 1) {
-      if (p == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    half_phase(I1{}, p + 1, 0, p, I1{}, h_c, mode_c);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  int p = 0;
-  for (; p + 4 < nt1; p += 2) {            // steady pairs: A tile (p>>1)+2 and B tiles p+3, p+4 exist
-    phase(p, I0{}, I1{});
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b_run[i] += (long)G2_BK * ldb;
-    phase(p + 1, I1{}, I1{});
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b_run[i] += (long)G2_BK * ldb;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a_run[i] += 64;
-  }
-  for (; p < nt1; ++p) {                   // tail: only the last B tile is still to be fetched
-    phase(p, I0{}, I0{});
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b_run[i] += (long)G2_BK * ldb;
-  }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // last asm MFMA -> v_accvgpr_read
-
-  // ---- epilogue: 64x64 blocks of the wave's 128x128 through the shared epilogue objects
-  static_for<4>([&](auto bc) {
-    constexpr int bi = decltype(bc)::value >> 1, bj = decltype(bc)::value & 1;
-    f32x16_t blk[2][2];
-    gacc_read<(2 * bi) * 4 + 2 * bj>(blk[0][0]);
-    gacc_read<(2 * bi) * 4 + 2 * bj + 1>(blk[0][1]);
-    gacc_read<(2 * bi + 1) * 4 + 2 * bj>(blk[1][0]);
-    gacc_read<(2 * bi + 1) * 4 + 2 * bj + 1>(blk[1][1]);
-    epi.apply(blk, m0 + wm * 128 + bi * 64, n0 + wn * 128 + bj * 64, lane, g.M, g.N);
-  });
-}
-
 // ---------------------------------------------------------------------------------------------
 // Epilogues.  apply() receives the wave's 64x64 accumulators and its tile origin.
 // ---------------------------------------------------------------------------------------------
