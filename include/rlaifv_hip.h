@@ -45,6 +45,16 @@ int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
 int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* residual, long ldr, float alpha, void* stream);
 
+/* gate|up projection with SwiGLU in the epilogue (HF LlamaMLP.forward: down_proj(act_fn(gate_proj(x)) * up_proj(x)),
+ * reached through llava_llama.py:91-102).  B = the W^T copy [K][N] of the fused weight whose rows are INTERLEAVED
+ * (row 2j = gate_j, row 2j+1 = up_j), N = 2 x ffn.  Writes GU [M][N] (kept for backward) and ACT [M][N/2] = silu(g) * u. */
+int rv_gemm_nn_swiglu_bf16(const void* A, long lda, const void* B, long ldb, void* GU, long ldgu, void* ACT, long ldact,
+                           int M, int N, int K, void* stream);
+/* Input gradient of down_proj with the SwiGLU backward in the epilogue: d act = A [M][K] x B [K][N] (B = W_down, N = ffn)
+ * never reaches memory; DGU [M][2N] = d(gate|up) interleaved like GU [M][2N]. */
+int rv_gemm_nn_swiglu_bwd_bf16(const void* A, long lda, const void* B, long ldb, const void* GU, long ldgu, void* DGU,
+                               long lddgu, int M, int N, int K, void* stream);
+
 /* Fused LoRA GEMM (peft LoraLayer.forward as used by muffin/train/train_llava15_lora.py:304-318):
  *   C[m][n] = sum_{k<K} A[m][k] B[n][k] + sum_{q<K2} A2[m][c0(n)+q] B2[n][q] (+ residual[m][n]),
  *   c0(n) = group_cols ? (n / group_cols) * K2 : 0.
@@ -146,9 +156,12 @@ int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void
  * backward = inverse rotation. */
 int rv_rope_inplace(void* x, long ld, const float* cos_tab, const float* sin_tab, const int* pos, long n_tok, int L,
                     int n_heads_total, int hd, int backward, void* stream);
-int rv_swiglu_fwd(const void* gu, long ldgu, void* act, long lda, long rows, int f, void* stream);
+/* SwiGLU on a stored gate|up tensor [rows][2f] and its backward.  interleaved = 0: columns [gate | up];  1: column 2j = gate_j,
+ * 2j+1 = up_j (the layout of the fused weight whose GEMM epilogues do this work - rv_gemm_nn_swiglu_bf16 - so the standalone
+ * kernels then only serve the recompute paths). */
+int rv_swiglu_fwd(const void* gu, long ldgu, void* act, long lda, long rows, int f, int interleaved, void* stream);
 int rv_swiglu_bwd(const void* dact, long ldd, const void* gu, long ldgu, void* dgu, long lddgu, long rows, int f,
-                  void* stream);
+                  int interleaved, void* stream);
 int rv_gelu_fwd(const void* x, void* y, long n, void* stream);
 int rv_gelu_bwd(const void* dy, const void* x, void* dx, long n, void* stream);
 /* Dropout of the LoRA branch input (peft lora_dropout, muffin/train/train_llava15_lora.py:114,309): element e is kept

@@ -210,6 +210,10 @@ __global__ void rope_kernel(bf16_t* __restrict__ x, long ld, const float* __rest
 }
 
 // ------------------------------------------------------------------ SwiGLU
+// IL = 0: gu = [gate (f columns) | up (f columns)] per row;  IL = 1: interleaved (column 2j = gate_j, 2j+1 = up_j) - the
+// layout of the fused gate|up weight whose GEMM epilogue computes SwiGLU itself (EpiSwiGLU); this kernel then only serves the
+// recompute paths (activation checkpointing, RV_KEEP_RECOMPUTABLE=0).
+template <int IL>
 __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, long ldgu, bf16_t* __restrict__ act, long lda,
                                   long rows, int f) {
   const int cpr = f >> 3;
@@ -218,14 +222,23 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, long ldgu, bf16
     const long r = i / cpr;
     const int c = (int)(i % cpr) * 8;
     float g[8], u[8], o[8];
-    unpack8(*(const uint4*)(gu + r * ldgu + c), g);
-    unpack8(*(const uint4*)(gu + r * ldgu + f + c), u);
+    if (IL) {
+      float a[8], b[8];
+      unpack8(*(const uint4*)(gu + r * ldgu + 2 * c), a);
+      unpack8(*(const uint4*)(gu + r * ldgu + 2 * c + 8), b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { g[j] = a[2 * j]; u[j] = a[2 * j + 1]; g[4 + j] = b[2 * j]; u[4 + j] = b[2 * j + 1]; }
+    } else {
+      unpack8(*(const uint4*)(gu + r * ldgu + c), g);
+      unpack8(*(const uint4*)(gu + r * ldgu + f + c), u);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
     *(uint4*)(act + r * lda + c) = pack8(o);
   }
 }
 
+template <int IL>
 __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, long ldd, const bf16_t* __restrict__ gu,
                                   long ldgu, bf16_t* __restrict__ dgu, long lddgu, long rows, int f) {
   const int cpr = f >> 3;
@@ -234,8 +247,16 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, long ldd, con
     const long r = i / cpr;
     const int c = (int)(i % cpr) * 8;
     float g[8], u[8], da[8], dg[8], du[8];
-    unpack8(*(const uint4*)(gu + r * ldgu + c), g);
-    unpack8(*(const uint4*)(gu + r * ldgu + f + c), u);
+    if (IL) {
+      float a[8], b[8];
+      unpack8(*(const uint4*)(gu + r * ldgu + 2 * c), a);
+      unpack8(*(const uint4*)(gu + r * ldgu + 2 * c + 8), b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { g[j] = a[2 * j]; u[j] = a[2 * j + 1]; g[4 + j] = b[2 * j]; u[4 + j] = b[2 * j + 1]; }
+    } else {
+      unpack8(*(const uint4*)(gu + r * ldgu + c), g);
+      unpack8(*(const uint4*)(gu + r * ldgu + f + c), u);
+    }
     unpack8(*(const uint4*)(dact + r * ldd + c), da);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -244,8 +265,16 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, long ldd, con
       dg[j] = da[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
       du[j] = da[j] * silu;
     }
-    *(uint4*)(dgu + r * lddgu + c) = pack8(dg);
-    *(uint4*)(dgu + r * lddgu + f + c) = pack8(du);
+    if (IL) {
+      float a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[2 * j] = dg[j]; a[2 * j + 1] = du[j]; b[2 * j] = dg[4 + j]; b[2 * j + 1] = du[4 + j]; }
+      *(uint4*)(dgu + r * lddgu + 2 * c) = pack8(a);
+      *(uint4*)(dgu + r * lddgu + 2 * c + 8) = pack8(b);
+    } else {
+      *(uint4*)(dgu + r * lddgu + c) = pack8(dg);
+      *(uint4*)(dgu + r * lddgu + f + c) = pack8(du);
+    }
   }
 }
 
@@ -781,21 +810,29 @@ int rv_rope_inplace(void* x, long ld, const float* cos_tab, const float* sin_tab
   return 0;
 }
 
-int rv_swiglu_fwd(const void* gu, long ldgu, void* act, long lda, long rows, int f, void* stream) {
+int rv_swiglu_fwd(const void* gu, long ldgu, void* act, long lda, long rows, int f, int interleaved, void* stream) {
   RV_REQUIRE(f % 8 == 0 && ldgu % 8 == 0 && lda % 8 == 0, "rv_swiglu_fwd: alignment");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
-                     (const bf16_t*)gu, ldgu, (bf16_t*)act, lda, rows, f);
+  if (interleaved)
+    hipLaunchKernelGGL(swiglu_fwd_kernel<1>, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
+                       (const bf16_t*)gu, ldgu, (bf16_t*)act, lda, rows, f);
+  else
+    hipLaunchKernelGGL(swiglu_fwd_kernel<0>, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
+                       (const bf16_t*)gu, ldgu, (bf16_t*)act, lda, rows, f);
   RV_CHECK_LAUNCH();
   return 0;
 }
 
 int rv_swiglu_bwd(const void* dact, long ldd, const void* gu, long ldgu, void* dgu, long lddgu, long rows, int f,
-                  void* stream) {
+                  int interleaved, void* stream) {
   RV_REQUIRE(f % 8 == 0 && ldgu % 8 == 0 && ldd % 8 == 0 && lddgu % 8 == 0, "rv_swiglu_bwd: alignment");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
-                     (const bf16_t*)dact, ldd, (const bf16_t*)gu, ldgu, (bf16_t*)dgu, lddgu, rows, f);
+  if (interleaved)
+    hipLaunchKernelGGL(swiglu_bwd_kernel<1>, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
+                       (const bf16_t*)dact, ldd, (const bf16_t*)gu, ldgu, (bf16_t*)dgu, lddgu, rows, f);
+  else
+    hipLaunchKernelGGL(swiglu_bwd_kernel<0>, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
+                       (const bf16_t*)dact, ldd, (const bf16_t*)gu, ldgu, (bf16_t*)dgu, lddgu, rows, f);
   RV_CHECK_LAUNCH();
   return 0;
 }

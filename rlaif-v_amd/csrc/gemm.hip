@@ -183,6 +183,24 @@ static int check_shape(const GemmShape& g, const char* who) {
   return 0;
 }
 
+// NN GEMM with one of the SwiGLU epilogues: the 64-deep-A kernel when K allows, else the 32-deep one
+template <class Epi>
+static int launch_nn_epi(const GemmShape& g, const Epi& epi, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nn_256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+  if (g.K % 64 == 0 && g.K >= 512)
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES, st, g, epi);
+  else
+    hipLaunchKernelGGL((gemm_nn_256_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st, g, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" {
 
 const char* rv_last_error(void) { return g_err; }
@@ -268,6 +286,34 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
                        (hipStream_t)stream, g, epi);
   RV_CHECK_LAUNCH();
   return 0;
+}
+
+int rv_gemm_nn_swiglu_bf16(const void* A, long lda, const void* B, long ldb, void* GU, long ldgu, void* ACT, long ldact,
+                           int M, int N, int K, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  RV_REQUIRE(K > 0 && K % G2_BK == 0, "rv_gemm_nn_swiglu_bf16: K must be a positive multiple of 32");
+  RV_REQUIRE(N % 16 == 0, "rv_gemm_nn_swiglu_bf16: N (= 2 x ffn, interleaved gate/up columns) must be a multiple of 16");
+  RV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldgu % 8 == 0 && ldact % 4 == 0, "rv_gemm_nn_swiglu_bf16: bad leading dimension");
+  RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)GU) & 15) == 0 && ((uintptr_t)ACT & 7) == 0,
+             "rv_gemm_nn_swiglu_bf16: operands must be 16-byte aligned (activation: 8)");
+  read_group_env();
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
+  EpiSwiGLU epi{(bf16_t*)GU, ldgu, (bf16_t*)ACT, ldact};
+  return launch_nn_epi(g, epi, (hipStream_t)stream);
+}
+
+int rv_gemm_nn_swiglu_bwd_bf16(const void* A, long lda, const void* B, long ldb, const void* GU, long ldgu, void* DGU,
+                               long lddgu, int M, int N, int K, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  RV_REQUIRE(K > 0 && K % G2_BK == 0, "rv_gemm_nn_swiglu_bwd_bf16: K must be a positive multiple of 32");
+  RV_REQUIRE(N % 8 == 0, "rv_gemm_nn_swiglu_bwd_bf16: N (= ffn) must be a multiple of 8");
+  RV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldgu % 8 == 0 && lddgu % 8 == 0, "rv_gemm_nn_swiglu_bwd_bf16: bad leading dimension");
+  RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)GU | (uintptr_t)DGU) & 15) == 0,
+             "rv_gemm_nn_swiglu_bwd_bf16: operands must be 16-byte aligned");
+  read_group_env();
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
+  EpiSwiGLUBwd epi{(const bf16_t*)GU, ldgu, (bf16_t*)DGU, lddgu};
+  return launch_nn_epi(g, epi, (hipStream_t)stream);
 }
 
 int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,

@@ -1273,6 +1273,98 @@ struct EpiStore {
   }
 };
 
+// SwiGLU fused into the gate|up projection (HF LlamaMLP: down(silu(gate(x)) * up(x)), llava_llama.py:91-102 -> modeling_llama
+// LlamaMLP.forward).  The fused weight stores gate and up INTERLEAVED (row 2j = gate_j, row 2j+1 = up_j), so a lane that holds 8
+// consecutive output columns holds 4 complete (gate, up) pairs: it writes the gate|up tile (kept for backward) AND the
+// activation tile act[m][j] = silu(g) * u - the separate swiglu pass (1.2 GB read + 0.6 GB write per layer) disappears.
+// The activation is computed from the bf16-ROUNDED g, u (what the unfused kernel would read back): bit-identical results.
+struct EpiSwiGLU {
+  bf16_t* C; long ldc;        // gate|up, interleaved columns [M][N]
+  bf16_t* ACT; long lda;      // activation [M][N/2]
+  __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = mw + tm * 32 + (lane & 31);
+      if (m >= M) continue;                       // lanes l and l+32 share m: partners skip together
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int rgp = 0; rgp < 2; ++rgp) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = acc[tm][tn][(2 * rgp) * 4 + j], b = acc[tm][tn][(2 * rgp + 1) * 4 + j];
+            const float recv = __shfl_xor(half ? a : b, 32);
+            v[j] = half ? recv : a;
+            v[4 + j] = half ? b : recv;
+          }
+          const int n = nw + tn * 32 + rgp * 16 + 8 * half;
+          if (n >= N) continue;
+          const uint4 pk = epi_pack8(v);
+          *(uint4*)(C + (long)m * ldc + n) = pk;
+          float r[8];
+          epi_unpack8(pk, r);
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = r[2 * j] / (1.f + __expf(-r[2 * j])) * r[2 * j + 1];
+          uint2 w;
+          w.x = pack2bf(o[0], o[1]);
+          w.y = pack2bf(o[2], o[3]);
+          *(uint2*)(ACT + (long)m * lda + (n >> 1)) = w;
+        }
+      }
+    }
+  }
+};
+
+// SwiGLU backward fused into the input-gradient GEMM of the down projection: acc = d act [M][f]; with the kept gate|up tile
+// (interleaved) it emits d(gate|up) [M][2f] directly - d act never reaches HBM.  d act is rounded to bf16 first (what the
+// unfused path stores), then the arithmetic of swiglu_bwd_kernel.
+struct EpiSwiGLUBwd {
+  const bf16_t* GU; long ldgu;
+  bf16_t* DGU; long lddgu;
+  __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = mw + tm * 32 + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int rgp = 0; rgp < 2; ++rgp) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = acc[tm][tn][(2 * rgp) * 4 + j], b = acc[tm][tn][(2 * rgp + 1) * 4 + j];
+            const float recv = __shfl_xor(half ? a : b, 32);
+            v[j] = half ? recv : a;
+            v[4 + j] = half ? b : recv;
+          }
+          const int n = nw + tn * 32 + rgp * 16 + 8 * half;
+          if (n >= N) continue;
+          float da[8], gu0[8], gu1[8], o0[8], o1[8];
+          epi_unpack8(epi_pack8(v), da);
+          const bf16_t* gp = GU + (long)m * ldgu + 2 * n;
+          epi_unpack8(*(const uint4*)gp, gu0);
+          epi_unpack8(*(const uint4*)(gp + 8), gu1);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float gg = (j < 4) ? gu0[2 * j] : gu1[2 * (j - 4)], uu = (j < 4) ? gu0[2 * j + 1] : gu1[2 * (j - 4) + 1];
+            const float sg = 1.f / (1.f + __expf(-gg));
+            const float dg = da[j] * uu * sg * (1.f + gg * (1.f - sg)), du = da[j] * (gg * sg);
+            if (j < 4) { o0[2 * j] = dg; o0[2 * j + 1] = du; } else { o1[2 * (j - 4)] = dg; o1[2 * (j - 4) + 1] = du; }
+          }
+          bf16_t* dp = DGU + (long)m * lddgu + 2 * n;
+          *(uint4*)dp = epi_pack8(o0);
+          *(uint4*)(dp + 8) = epi_pack8(o1);
+        }
+      }
+    }
+  }
+};
+
 // fp32 output (used where a downstream reduction wants full precision).
 struct EpiStoreF32 {
   float* C; long ldc;

@@ -135,6 +135,10 @@ class ParamStore:
             raise NotImplementedError("LoRA with grouped-query attention: the fused q|k|v adapter groups assume equal widths")
         Entry = Tuple[str, Tuple[int, ...], bool]        # (key, shape, needs transposed copy); fused keys map to HF names
         self.lora = lora
+        # Full fine-tune: the fused gate|up weight stores its rows INTERLEAVED (row 2j = gate_j, 2j+1 = up_j) so that the GEMM
+        # epilogues can apply SwiGLU and its backward in registers (ops.linear_swiglu / linear_swiglu_bwd).  LoRA keeps
+        # [gate | up] blocks (its adapter column groups address them).  RV_FUSE_SWIGLU=0: block layout + separate kernels.
+        self.interleave_gu = lora is None and os.environ.get("RV_FUSE_SWIGLU", "1") != "0"
         proj_w: List[Entry] = [("model.mm_projector.2.weight", (d, d), True), ("model.mm_projector.0.weight", (d, cd), False)]
         proj_b: List[Entry] = [("model.mm_projector.2.bias", (d,), False), ("model.mm_projector.0.bias", (d,), False)]
         base_w: List[Entry] = [("lm_head.weight", (V, d), True)]
@@ -243,25 +247,32 @@ class ParamStore:
             self.flat_master.copy_(self.train_p)     # bf16 -> fp32 (device copy, plumbing)
 
     # ---- HF state-dict mapping ------------------------------------------------------------
-    def hf_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int]]:
-        """HF name -> (store key, first row, n rows) for the language model + projector."""
+    def hf_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int, int]]:
+        """HF name -> (store key, first row, n rows, row step) for the language model + projector: the HF tensor is
+        ``rows(view(key), r0, n, step)`` (step 2 = the interleaved gate / up rows of the fused MLP weight)."""
         d, f, kvd = cfg.hidden, cfg.ffn, cfg.kv_dim
-        m: Dict[str, Tuple[str, int, int]] = {}
+        m: Dict[str, Tuple[str, int, int, int]] = {}
+        il = self.interleave_gu
         for i in range(cfg.layers):
             p = f"model.layers.{i}."
-            m[p + "self_attn.q_proj.weight"] = (f"layers.{i}.wqkv", 0, d)
-            m[p + "self_attn.k_proj.weight"] = (f"layers.{i}.wqkv", d, kvd)
-            m[p + "self_attn.v_proj.weight"] = (f"layers.{i}.wqkv", d + kvd, kvd)
-            m[p + "self_attn.o_proj.weight"] = (f"layers.{i}.wo", 0, d)
-            m[p + "mlp.gate_proj.weight"] = (f"layers.{i}.wgu", 0, f)
-            m[p + "mlp.up_proj.weight"] = (f"layers.{i}.wgu", f, f)
-            m[p + "mlp.down_proj.weight"] = (f"layers.{i}.wdown", 0, d)
-            m[p + "input_layernorm.weight"] = (f"layers.{i}.ln1", 0, d)
-            m[p + "post_attention_layernorm.weight"] = (f"layers.{i}.ln2", 0, d)
+            m[p + "self_attn.q_proj.weight"] = (f"layers.{i}.wqkv", 0, d, 1)
+            m[p + "self_attn.k_proj.weight"] = (f"layers.{i}.wqkv", d, kvd, 1)
+            m[p + "self_attn.v_proj.weight"] = (f"layers.{i}.wqkv", d + kvd, kvd, 1)
+            m[p + "self_attn.o_proj.weight"] = (f"layers.{i}.wo", 0, d, 1)
+            m[p + "mlp.gate_proj.weight"] = (f"layers.{i}.wgu", 0, f, 2) if il else (f"layers.{i}.wgu", 0, f, 1)
+            m[p + "mlp.up_proj.weight"] = (f"layers.{i}.wgu", 1, f, 2) if il else (f"layers.{i}.wgu", f, f, 1)
+            m[p + "mlp.down_proj.weight"] = (f"layers.{i}.wdown", 0, d, 1)
+            m[p + "input_layernorm.weight"] = (f"layers.{i}.ln1", 0, d, 1)
+            m[p + "post_attention_layernorm.weight"] = (f"layers.{i}.ln2", 0, d, 1)
         for k in ("lm_head.weight", "model.embed_tokens.weight", "model.norm.weight", "model.mm_projector.0.weight",
                   "model.mm_projector.0.bias", "model.mm_projector.2.weight", "model.mm_projector.2.bias"):
-            m[k] = (k, 0, self.offsets[k][1][0])
+            m[k] = (k, 0, self.offsets[k][1][0], 1)
         return m
+
+    @staticmethod
+    def rows(view: torch.Tensor, r0: int, n: int, step: int = 1) -> torch.Tensor:
+        """Rows r0, r0 + step, ... (n of them) of a store view."""
+        return view[r0:r0 + n * step:step]
 
 
     def lora_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int, int]]:
@@ -329,8 +340,8 @@ class LlavaDPOModel:
         """HF-named fp32/bf16 CPU tensors (the reference's checkpoint layout, 4.35 CLIP key names)."""
         cfg, st = self.cfg, self.store
         self._clip_raw = {k: v.detach().to(BF16).cpu() for k, v in sd.items() if k.startswith(VT)}
-        for name, (key, r0, n) in st.hf_slices(cfg).items():
-            st.p(key)[r0:r0 + n].copy_(sd[name].to(BF16))
+        for name, (key, r0, n, step) in st.hf_slices(cfg).items():
+            st.rows(st.p(key), r0, n, step).copy_(sd[name].to(BF16))
         if self.lora is not None:
             self.load_lora_state_dict(sd, strict=False, _refresh=False)
         st.sync_master_from_params()
@@ -399,8 +410,8 @@ class LlavaDPOModel:
         """HF-named CPU bf16 tensors of the trainable part (safe_save_model_for_hf_trainer layout,
         muffin/train/train_llava15.py:102-112)."""
         out = {}
-        for name, (key, r0, n) in self.store.hf_slices(self.cfg).items():
-            out[name] = self.store.p(key)[r0:r0 + n].detach().cpu().clone()
+        for name, (key, r0, n, step) in self.store.hf_slices(self.cfg).items():
+            out[name] = self.store.rows(self.store.p(key), r0, n, step).detach().cpu().clone()
         return out
 
     # ---- LoRA adapters (peft naming, muffin/train/train_llava15_lora.py:152-197) ----------------
@@ -473,9 +484,9 @@ class LlavaDPOModel:
 
     def grads_state_dict(self) -> Dict[str, torch.Tensor]:
         out = {}
-        for name, (key, r0, n) in self.store.hf_slices(self.cfg).items():
+        for name, (key, r0, n, step) in self.store.hf_slices(self.cfg).items():
             if key in self.store.trainable:
-                out[name] = self.store.g(key)[r0:r0 + n].detach().float().cpu()
+                out[name] = self.store.rows(self.store.g(key), r0, n, step).detach().float().cpu()
         for name, t in self.lora_state_dict(grads=True).items():
             out[name.replace("base_model.model.", "")] = t
         return out
@@ -602,8 +613,12 @@ class LlavaDPOModel:
         attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, d + cfg.kv_dim, seg=plan.seg, kv_group=cfg.kv_group)
         x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
         xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
-        gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2)
-        act = ops.swiglu_fwd(gu)
+        if st.interleave_gu:          # full fine-tune: SwiGLU in the epilogue of the gate|up GEMM (interleaved weight rows)
+            gu, act = ops.linear_swiglu(xn2, st.pT(f"layers.{i}.wgu"))
+            t_gu = xd_gu = None
+        else:
+            gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2)
+            act = ops.swiglu_fwd(gu)
         x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3)
         if not save:
             return x_next, None
@@ -723,12 +738,18 @@ class LlavaDPOModel:
             c = ctx["layers"][i]
             if c.get("recompute"):      # --gradient_checkpointing: only the layer input was kept; run the layer again
                 _, c = self._layer_fwd(i, c["x"], plan, cos, sin, True)
-            act = c["act"] if c["act"] is not None else ops.swiglu_fwd(c["gu"])
+            act = c["act"] if c["act"] is not None else ops.swiglu_fwd(c["gu"], interleaved=st.interleave_gu)
             c["act"] = None
-            dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3, xd=c["xd_down"])
-            del act
-            dgu = ops.swiglu_bwd(dact, c["gu"])
-            del dact
+            if st.interleave_gu:
+                # d(gate|up) straight out of the down projection's input-gradient GEMM (SwiGLU backward in its epilogue)
+                dgu = ops.linear_swiglu_bwd(dx, st.p(f"layers.{i}.wdown"), c["gu"])
+                ops.gemm_tn(dx, act, out=st.g(f"layers.{i}.wdown"))
+                del act
+            else:
+                dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3, xd=c["xd_down"])
+                del act
+                dgu = ops.swiglu_bwd(dact, c["gu"])
+                del dact
             xn2 = c["xn2"] if c["xn2"] is not None else \
                 ops.rmsnorm_fwd(c["x_mid"], st.p(f"layers.{i}.ln2"), cfg.rms_eps, want_rstd=False)[0]
             c["xn2"] = None

@@ -250,22 +250,51 @@ def rope_inplace(x: torch.Tensor, cos, sin, L: int, n_heads_total: int, hd: int,
     return x
 
 
-def swiglu_fwd(gu: torch.Tensor, out=None):
+def swiglu_fwd(gu: torch.Tensor, out=None, interleaved: bool = False):
+    """act = silu(gate) * up from gu = [gate | up] columns, or interleaved (column 2j = gate_j, 2j+1 = up_j)."""
     _chk2d(gu, "gu")
     rows, f2 = gu.shape
     f = f2 // 2
     if out is None:
         out = torch.empty(rows, f, dtype=BF16, device=gu.device)
-    hip.call("rv_swiglu_fwd", gu, gu.stride(0), out, out.stride(0), rows, f)
+    hip.call("rv_swiglu_fwd", gu, gu.stride(0), out, out.stride(0), rows, f, int(interleaved))
     return out
 
 
-def swiglu_bwd(dact, gu, out=None):
+def swiglu_bwd(dact, gu, out=None, interleaved: bool = False):
     rows, f2 = gu.shape
     if out is None:
         out = torch.empty_like(gu)
-    hip.call("rv_swiglu_bwd", dact, dact.stride(0), gu, gu.stride(0), out, out.stride(0), rows, f2 // 2)
+    hip.call("rv_swiglu_bwd", dact, dact.stride(0), gu, gu.stride(0), out, out.stride(0), rows, f2 // 2, int(interleaved))
     return out
+
+
+def linear_swiglu(x: torch.Tensor, wguT: torch.Tensor):
+    """(gu, act): gu = x @ W_gu^T with the INTERLEAVED fused weight (wguT = its [in, 2f] copy), act = silu(gate) * up computed
+    in the GEMM epilogue (rv_gemm_nn_swiglu_bf16) - no separate SwiGLU pass."""
+    _chk2d(x, "x"), _chk2d(wguT, "wguT")
+    M, K = x.shape
+    N = wguT.shape[1]
+    if wguT.shape[0] != K:
+        raise ValueError(f"linear_swiglu: inner dimensions differ: {K} vs {wguT.shape[0]}")
+    gu = torch.empty(M, N, dtype=BF16, device=x.device)
+    act = torch.empty(M, N // 2, dtype=BF16, device=x.device)
+    hip.call("rv_gemm_nn_swiglu_bf16", x, x.stride(0), wguT, wguT.stride(0), gu, gu.stride(0), act, act.stride(0), M, N, K)
+    return gu, act
+
+
+def linear_swiglu_bwd(dy: torch.Tensor, w_down: torch.Tensor, gu: torch.Tensor):
+    """d(gate|up) [M, 2f] (interleaved like gu) = SwiGLU'(gu) applied to d act = dy @ W_down - the input gradient of the down
+    projection with the SwiGLU backward in its epilogue (rv_gemm_nn_swiglu_bwd_bf16); d act never reaches HBM."""
+    _chk2d(dy, "dy"), _chk2d(w_down, "w_down"), _chk2d(gu, "gu")
+    M, K = dy.shape
+    f = w_down.shape[1]
+    if w_down.shape[0] != K or gu.shape != (M, 2 * f):
+        raise ValueError(f"linear_swiglu_bwd: shapes dy{tuple(dy.shape)} w_down{tuple(w_down.shape)} gu{tuple(gu.shape)}")
+    dgu = torch.empty_like(gu)
+    hip.call("rv_gemm_nn_swiglu_bwd_bf16", dy, dy.stride(0), w_down, w_down.stride(0), gu, gu.stride(0), dgu, dgu.stride(0),
+             M, f, K)
+    return dgu
 
 
 def gelu_fwd(x):

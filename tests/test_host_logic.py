@@ -183,10 +183,13 @@ def test_param_store_layout_and_schedules():
     assert all(sch[i][2] == sch[i + 1][1] for i in range(len(sch) - 1))
     names = st.hf_slices(cfg)
     assert set(names) == set(O.trainable_names(O.tiny_cfg()))
-    for hf, (key, r0, n) in names.items():
+    for hf, (key, r0, n, step) in names.items():
         off, shp = st.offsets[key]
         assert (off >= st.n_decay) == (not O.is_decay_param(hf)), hf     # decay / no-decay split == HF's
-        assert tuple(st.p(key)[r0:r0 + n].shape) == tuple(O.weight_shapes(O.tiny_cfg())[hf]), hf
+        assert tuple(st.rows(st.p(key), r0, n, step).shape) == tuple(O.weight_shapes(O.tiny_cfg())[hf]), hf
+    # the fused MLP weight interleaves gate / up rows (SwiGLU in the GEMM epilogue); together they tile it exactly
+    g_, u_ = names["model.layers.0.mlp.gate_proj.weight"], names["model.layers.0.mlp.up_proj.weight"]
+    assert g_[0] == u_[0] and (g_[1], g_[3], u_[1], u_[3]) == (0, 2, 1, 2) and g_[2] == u_[2] == cfg.ffn
     for s in range(0, 40):
         assert abs(cosine_lr(s, 40, 5e-7, 0.05) - O.cosine_lr(s, 40, 5e-7, 0.05)) < 1e-18
     # the 7B layout: 6.76 B trainable parameters

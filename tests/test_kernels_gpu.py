@@ -600,3 +600,33 @@ def test_adamw_and_gradnorm(ops):
         opt.step()
         torch.testing.assert_close(master, ref.detach(), rtol=2e-5, atol=2e-6)
         assert torch.equal(p, master.to(BF))
+
+
+@pytest.mark.parametrize("M,d,f", [(300, 256, 512), (1000, 512, 776), (27000, 1024, 1024)])
+def test_swiglu_fused_gemm_epilogues(ops, M, d, f):
+    """SwiGLU in the gate|up GEMM epilogue and its backward in the down-projection input-gradient epilogue (interleaved gate /
+    up columns): bit-identical to the unfused composition GEMM -> bf16 -> swiglu kernel, which is pinned against torch fp32."""
+    dev = _dev()
+    x = rnd(M, d, seed=71, dev=dev, scale=1.0)
+    wguT = rnd(d, 2 * f, seed=72, dev=dev, scale=0.08)          # [in, 2f], column 2j = gate_j, 2j+1 = up_j
+    gu, act = ops.linear_swiglu(x, wguT)
+    gu_ref = ops.gemm_nn(x, wguT)
+    assert torch.equal(gu, gu_ref)
+    assert torch.equal(act, ops.swiglu_fwd(gu_ref, interleaved=True))
+    g32, u32 = gu_ref.float()[:, 0::2], gu_ref.float()[:, 1::2]
+    close(act, torch.nn.functional.silu(g32) * u32, what="fused swiglu act")
+    # the interleaved kernels agree with the block-layout ones on the de-interleaved tensor
+    blocks = torch.cat([gu_ref[:, 0::2], gu_ref[:, 1::2]], 1).contiguous()
+    assert torch.equal(ops.swiglu_fwd(blocks), act)
+    # backward: dgu = SwiGLU'(gu) o (dy @ W_down)
+    dy = rnd(M, d, seed=73, dev=dev, scale=0.5)
+    w_down = rnd(d, f, seed=74, dev=dev, scale=0.08)            # [out = d, in = f]: dy @ w_down = d act
+    dgu = ops.linear_swiglu_bwd(dy, w_down, gu)
+    dact = ops.gemm_nn(dy, w_down)
+    dgu_ref = ops.swiglu_bwd(dact, gu, interleaved=True)
+    assert torch.equal(dgu, dgu_ref)
+    da, sg = dact.float(), torch.sigmoid(g32)
+    close(dgu[:, 0::2], da * u32 * sg * (1 + g32 * (1 - sg)), what="fused swiglu d gate")
+    close(dgu[:, 1::2], da * g32 * sg, what="fused swiglu d up")
+    dblocks = ops.swiglu_bwd(dact, blocks)
+    assert torch.equal(torch.cat([dgu_ref[:, 0::2], dgu_ref[:, 1::2]], 1), dblocks)

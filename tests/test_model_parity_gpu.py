@@ -135,9 +135,9 @@ def test_training_step_matches_oracle():
         for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "lm_head.weight",
                   "model.mm_projector.2.weight", "model.norm.weight"):
             ref_delta = Wo[k] - W[k]
-            key, r0, n = model.store.hf_slices(model.cfg)[k]
+            key, r0, n, step = model.store.hf_slices(model.cfg)[k]
             off, shp = model.store.offsets[key]
-            master = model.store.flat_master[off:off + torch.Size(shp).numel()].view(*shp)[r0:r0 + n].cpu()
+            master = model.store.flat_master[off:off + torch.Size(shp).numel()].view(*shp)[r0:r0 + n * step:step].cpu()
             got_delta = master - W[k]
             c = _cos(got_delta, ref_delta)
             assert c >= 0.97, (step, k, c)
