@@ -132,7 +132,9 @@ struct TileDma {
   }
 };
 
-template <int HD, bool CAUSAL>
+// ABL (experiment builds, -DRV_ATTN_EXPERIMENTS; results WRONG by construction): 1 = no softmax arithmetic, 2 = no PV MFMAs,
+// 3 = no QK^T MFMAs, 6 = no LDS-DMA of the following tiles.
+template <int HD, bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                            int k_col0, int v_col0, bf16_t* __restrict__ out, long ldo,
                                                            float* __restrict__ lse, int L, int H, int nx, float scale,
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
       const int k0 = t * 64;
       const uint8_t* Ks = smem + (i & 1) * STAGE;
       const uint8_t* Vs = Ks + TILE;
-      if (i + 1 < nte) {
+      if (i + 1 < nte && ABL != 6) {
         const int kn = ((i + 1 < skip_lo) ? i + 1 : i + 1 + skip_n) * 64;
         dma.issue(kbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE, wave);
         dma.issue(vbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE + TILE, wave);
@@ -231,8 +233,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)     // the two halves alternate: consecutive MFMAs never share an accumulator
+          for (int j = 0; j < 4; ++j) {   // the two halves alternate: consecutive MFMAs never share an accumulator
+            if (ABL == 3) { asm volatile("" ::"v"(kcur[j])); continue; }
             sacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[j], qf[2 * g + (j >> 1)], sacc[j & 1], 0, 0, 0);
+          }
         }
         // The tile needs element masks only when it touches the sequence end, the causal diagonal of this wave
         // or the chosen-branch window of a packed pair; interior tiles (the vast majority) skip ~200 VALU ops.
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
         for (int e = 0; e < ET; ++e) vA[e] = tro.read(vs_addr, 0, e);
         float tmax = -INFINITY;                      // raw-score maximum (c > 0 keeps the order)
+        if (ABL != 1)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -267,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
+            if (ABL == 1) continue;
             const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c, neg_m));   // one v_fma + one v_exp
             sacc[kt][r] = p;
             psum += p;
@@ -294,7 +300,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int e = 0; e < ET; ++e) o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[e], pf, o[e], 0, 0, 0);
+          for (int e = 0; e < ET; ++e) {
+            if (ABL == 2) { asm volatile("" ::"v"(vcur[e]), "v"(pf)); continue; }
+            o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[e], pf, o[e], 0, 0, 0);
+          }
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1077,6 +1086,20 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
 #define LAUNCH_FWD(HD_, C_)                                                                                      \
   hipLaunchKernelGGL((attn_fwd2_kernel<HD_, C_>), grid, block, 4 * 64 * HD_ * 2, st, (const bf16_t*)qkv, ld, q_col0, \
                      k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group)
+#ifdef RV_ATTN_EXPERIMENTS
+  static int fwd_ablate = -1;
+  if (fwd_ablate < 0) { const char* a = getenv("RV_FWD_ABLATE"); fwd_ablate = a ? atoi(a) : 0; }
+#define LAUNCH_FWD_ABL(N)                                                                                                  \
+  if (fwd_ablate == N && hd == 128 && causal) {                                                                            \
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);     \
+    hipLaunchKernelGGL((attn_fwd2_kernel<128, true, N>), grid, block, 4 * 64 * 128 * 2, st, (const bf16_t*)qkv, ld, q_col0, \
+                       k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group);                   \
+    RV_CHECK_LAUNCH();                                                                                                     \
+    return 0;                                                                                                              \
+  }
+  LAUNCH_FWD_ABL(1) LAUNCH_FWD_ABL(2) LAUNCH_FWD_ABL(3) LAUNCH_FWD_ABL(6)
+#undef LAUNCH_FWD_ABL
+#endif
   if (hd == 128) { if (causal) LAUNCH_FWD(128, true); else LAUNCH_FWD(128, false); }
   else { if (causal) LAUNCH_FWD(64, true); else LAUNCH_FWD(64, false); }
 #undef LAUNCH_FWD
