@@ -32,6 +32,14 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (the host driver has no legacy IPC)
+        # RCCL next to 256-CU GEMMs: every RCCL channel is a persistent workgroup that takes a CU away
+        # from the one-workgroup-per-CU GEMMs for as long as a collective runs.  The step needs 2 x 7/8 x 13.5 GB = 23.6 GB
+        # per GPU inside ~0.7 s of backward (34 GB/s) - a fraction of xGMI - so the channel count is capped low instead of
+        # letting RCCL take its default 32+ CUs.  RV_RCCL_CHANNELS overrides (0 = leave RCCL's defaults alone).
+        ch = int(os.environ.get("RV_RCCL_CHANNELS", "8"))
+        if ch > 0:
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(ch))
+            os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(ch, 4)))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" IS RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
