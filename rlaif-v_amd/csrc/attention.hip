@@ -86,6 +86,52 @@ __device__ __forceinline__ uint32_t kvtile_off(int row, int c) {
   return (uint32_t)(row * 128 + ((c ^ (((x & 1) << 2) | (x >> 1))) << 4));
 }
 
+// Element masks of a 32 x 32 score block (accumulator register r of a lane <-> index (r&3) + 8*(r>>2) + 4*half along the
+// MFMA's row axis).  The predicate of the whole path is
+//     hidden(q, key)  <=>  key >= L  ||  (CAUSAL && key > q)  ||  (q >= e1 && sh <= key < e1)
+// (causal + the packed pair's "rejected branch does not see the chosen branch" window).  Written out per element it compiles
+// to 5 compares and 6 scalar mask operations (17 instructions per element, 544 per forward tile - longer than the rest of
+// the tile); with the lane-constant part folded into interval bounds it is one or two unsigned compares per element.
+template <bool CAUSAL>
+struct QueryLaneMask {            // this lane owns ONE query, the 16 registers run over keys (forward, dQ)
+  int hi, xs;                     // last visible key; start of the hidden window
+  unsigned xw;                    // width of the hidden window (0: none)
+  __device__ __forceinline__ void init(int q, int L, int sh, int e1) {
+    hi = CAUSAL ? min(q, L - 1) : L - 1;
+    xs = sh;
+    xw = (q >= e1 && e1 > sh) ? (unsigned)(e1 - sh) : 0u;
+  }
+  // kb = key of register 0 of this lane (block start + 4 * half)
+  __device__ __forceinline__ void apply(f32x16_t& sacc, int kb) const {
+    const int a = hi - kb, b = xs - kb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cr = (r & 3) + 8 * (r >> 2);
+      if (cr > a || (unsigned)(cr - b) < xw) sacc[r] = -INFINITY;
+    }
+  }
+};
+template <bool CAUSAL>
+struct KeyLaneMask {              // this lane owns ONE key, the 16 registers run over queries (dK / dV)
+  int lo;                         // first query that sees the key
+  unsigned wd;                    // number of queries that see it: [lo, lo + wd)
+  __device__ __forceinline__ void init(int key, int L, int sh, int e1) {
+    const bool in_window = key >= sh && key < e1;
+    lo = CAUSAL ? key : 0;
+    const int up = in_window ? e1 : L;        // e1 <= L
+    wd = (key < L && up > lo) ? (unsigned)(up - lo) : 0u;
+  }
+  // qb = query of register 0 of this lane (sub-tile start + 4 * half)
+  __device__ __forceinline__ void apply(f32x16_t& sacc, int qb) const {
+    const int a = lo - qb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cr = (r & 3) + 8 * (r >> 2);
+      if ((unsigned)(cr - a) >= wd) sacc[r] = -INFINITY;
+    }
+  }
+};
+
 // lane constants of the transposing reads over a [64 rows][HD] tile (rows = contraction index)
 template <int HD>
 struct TrOffsets {
@@ -107,28 +153,51 @@ struct TrOffsets {
   }
 };
 
-// LDS-DMA of a [64 rows][HD] tile: 64*HD*2/1024 pieces of 1 KiB, split over the 4 waves
-template <int HD>
+// LDS-DMA of a [64 rows][HD] tile: 64*HD*2/1024 pieces of 1 KiB, split over the 4 waves.
+// Addressing: a lane's source = (sequence base + tile row offset) [wave-uniform, SGPR pair] + voff[i] [32-bit VGPR, constant
+// for the whole kernel] - the `saddr` form of global_load_lds, no per-piece VALU.  (The first version rebuilt a 64-bit address
+// per piece - ~50 VALU per tile per wave; the forward ablation run prices the DMA issue at 20 % of the kernel,
+// profiles/r02_attn_fwd_ablation.log.)  Only a tile that crosses the sequence end takes the per-lane clamped path.
+template <int HD, int NW = 4>
 struct TileDma {
-  static constexpr int NP = 64 * HD * 2 / 1024 / 4;       // pieces per wave (4 for HD 128, 2 for HD 64)
+  static constexpr int NP = 64 * HD * 2 / 1024 / NW;      // pieces per wave (4 waves: 4 for HD 128, 2 for HD 64; 8 waves: 2)
   static constexpr int RPP = 1024 / (HD * 2);             // rows per piece (4 / 8)
   static constexpr int CPR = HD / 8;                      // 16-byte chunks per row
-  int row[NP], col[NP];
-  __device__ __forceinline__ void init(int wave, int lane) {
+  uint32_t voff[NP];                                      // row * (row stride in bytes) + source chunk * 16
+  uint32_t ldb;
+  __device__ __forceinline__ static int piece_row(int wave, int lane, int i) { return (wave * NP + i) * RPP + lane / CPR; }
+  __device__ __forceinline__ static int piece_col(int row, int lane) {
+    const int cp = lane % CPR;                             // chunk position in the LDS row
+    // inverse of the read swizzle (an involution): source chunk = cp ^ f(row)
+    return (int)((kvtile_off<HD>(row, cp) - (uint32_t)(row * HD * 2)) >> 4) * 8;
+  }
+  __device__ __forceinline__ void init(int wave, int lane, long ld) {
+    ldb = (uint32_t)(ld * 2);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      row[i] = (wave * NP + i) * RPP + lane / CPR;
-      const int cp = lane % CPR;                           // chunk position in the LDS row
-      // inverse of the read swizzle (an involution): source chunk = cp ^ f(row)
-      col[i] = (int)((kvtile_off<HD>(row[i], cp) - (uint32_t)(row[i] * HD * 2)) >> 4) * 8;
+      const int row = piece_row(wave, lane, i);
+      voff[i] = (uint32_t)row * ldb + (uint32_t)piece_col(row, lane) * 2u;
     }
   }
   __device__ __forceinline__ void issue(const bf16_t* base, long ld, long tok0, int r0, int L, uint8_t* dst, int wave) const {
+    const char* seq = (const char*)(base + tok0 * ld);     // wave-uniform
+    if (r0 + 64 <= L) {
+      const char* b = seq + (size_t)(uint32_t)r0 * ldb;
 #pragma unroll
-    for (int i = 0; i < NP; ++i)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(base + (tok0 + min(r0 + row[i], L - 1)) * ld + col[i]),
-          (__attribute__((address_space(3))) void*)(dst + (wave * NP + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < NP; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + voff[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + (wave * NP + i) * 1024), 16, 0, 0);
+    } else {
+      const int lane = threadIdx.x & 63;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int row = piece_row(wave, lane, i);
+        const uint32_t r = (uint32_t)min(r0 + row, L - 1);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(seq + (r * ldb + (uint32_t)piece_col(row, lane) * 2u)),
+            (__attribute__((address_space(3))) void*)(dst + (wave * NP + i) * 1024), 16, 0, 0);
+      }
+    }
   }
 };
 
@@ -154,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   const float c = scale * LOG2E;
 
   TileDma<HD> dma;
-  dma.init(wave, lane);
+  dma.init(wave, lane, ld);
   TrOffsets<HD> tro;
   tro.init(lane);
   uint32_t boff[KS];
@@ -169,6 +238,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     if (pass == 1 && qb <= bx) break;
     const int q0 = qb * 128, q0w = q0 + wave * 32;
     const int q = q0w + fr;
+    QueryLaneMask<CAUSAL> qmask;
+    qmask.init(q, L, sh, e1);
 
     bf16x8_t qf[KS];
     {
@@ -243,13 +314,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         const bool need_mask = (k0 + 63 >= L) || (CAUSAL && k0 + 63 > q0w) ||
                                (q0w + 31 >= e1 && k0 + 63 >= sh && k0 < e1);
         if (need_mask) {
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) sacc[kt][r] = -INFINITY;
-            }
+          qmask.apply(sacc[0], k0 + 4 * half);
+          qmask.apply(sacc[1], k0 + 32 + 4 * half);
         }
         // V^T fragments of the first 16 keys are requested NOW: they do not depend on P, so their LDS latency hides under
         // the softmax VALU work; afterwards the fragments of 16-key group kk+1 are in flight while group kk multiplies.
@@ -350,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
   const float c = scale * LOG2E;
 
   TileDma<HD> dma;
-  dma.init(wave, lane);
+  dma.init(wave, lane, ld);
   TrOffsets<HD> tro;
   tro.init(lane);
   uint32_t boff[KS];
@@ -365,6 +431,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
     if (pass == 1 && qb <= bx) break;
     const int q0 = qb * 128, q0w = q0 + wave * 32;
     const int q = q0w + fr, qc = min(q, L - 1);
+    QueryLaneMask<CAUSAL> qmask;
+    qmask.init(q, L, sh, e1);
 
     bf16x8_t qf[KS], dof[KS];
     {
@@ -457,13 +525,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
           for (int e = 0; e < ET; ++e) kfr0[e] = tro.read(ks_addr, kt * 32, e);
           const bool need_mask = (k0 + 63 >= L) || (CAUSAL && k0 + 63 > q0w) ||
                                  (q0w + 31 >= e1 && k0 + 63 >= sh && k0 < e1);
-          if (need_mask) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (key >= L || (CAUSAL && key > q) || (q >= e1 && key >= sh && key < e1)) sacc[r] = -INFINITY;
-            }
-          }
+          if (need_mask) qmask.apply(sacc, k0 + kt * 32 + 4 * half);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse_q));   // masked: exp2(-inf) = 0
@@ -604,6 +666,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     if (pass == 1 && kvb <= bx) break;
     const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
     const int key = kv0w + fr, keyc = min(key, L - 1);
+    KeyLaneMask<CAUSAL> kmask;
+    kmask.init(key, L, sh, e1);
 
     bf16x8_t kf[KS], vf[KS];
     {
@@ -662,13 +726,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
           const int qsub = qs0 + qt * 32;                      // first query of this 32-row sub-tile
           const bool need_mask = (qsub + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qsub) ||
                                  (qsub + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
-          if (need_mask) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int qg = qsub + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (qg >= L || key >= L || (CAUSAL && key > qg) || (qg >= e1 && key >= sh && key < e1)) sacc[r] = -INFINITY;
-            }
-          }
+          if (need_mask) kmask.apply(sacc, qsub + 4 * half);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -835,6 +893,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
     if (pass == 1 && kvb <= bx) break;
     const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
     const int key = kv0w + fr, keyc = min(key, L - 1);
+    KeyLaneMask<CAUSAL> kmask;
+    kmask.init(key, L, sh, e1);
 
     // B operands of S^T / dP^T: K / V fragments of this wave's 32 keys, loaded STRAIGHT INTO fixed AGPRs (gfx90a+ vector
     // memory can target the accumulator file); dK / dV accumulate in fixed AGPRs as well (map in attn_agpr.inc).  With
@@ -928,13 +988,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
           const int qsub = qs0 + qt * 32;                      // first query of this 32-row sub-tile
           const bool need_mask = (qsub + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qsub) ||
                                  (qsub + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
-          if (need_mask) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int qg = qsub + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (qg >= L || key >= L || (CAUSAL && key > qg) || (qg >= e1 && key >= sh && key < e1)) sacc[r] = -INFINITY;
-            }
-          }
+          if (need_mask) kmask.apply(sacc, qsub + 4 * half);
           asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");   // first lse / delta half landed (the 16 transposing reads stay in flight)
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1069,14 +1123,15 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   RV_REQUIRE(kv_group >= 1 && H % kv_group == 0, "rv_attn_fwd: kv_group must divide the number of query heads");
   RV_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0 && v_col0 % 8 == 0,
              "rv_attn_fwd: alignment");
+  RV_REQUIRE((double)L * (double)ld * 2.0 < 4.0e9, "rv_attn_fwd: one sequence must span < 4 GB of the qkv buffer (32-bit DMA offsets)");
   if (S == 0 || L == 0) return 0;
-  const int nb = (L + 127) / 128;
   static int map_mode = -1;
   if (map_mode < 0) { const char* e = getenv("RV_ATTN_MAP"); map_mode = e ? atoi(e) : 1; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (L + 127) / 128;
   const int nxr = causal ? (nb + 1) / 2 : nb;
   const int nx = nxr | (map_mode << 16);
   dim3 grid(nxr * H * S), block(256);
-  hipStream_t st = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
