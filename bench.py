@@ -317,17 +317,20 @@ def main():
         }
         if not args.no_gemm_timer:
             g = timer.summary()
-            traffic = None
-            try:       # HBM bytes per GEMM launch from the committed PMC passes (profiles/, separate rocprofv3 runs)
-                with open(os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
-                    traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
-            except Exception:
-                pass
+            traffic, traffic_file = None, None
+            for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # newest committed PMC passes first
+                try:   # HBM bytes per GEMM launch (profiles/, separate rocprofv3 --pmc runs of this same command)
+                    with open(os.path.join(REPO, "profiles", name)) as fh:
+                        traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
+                    traffic_file = name
+                    break
+                except Exception:
+                    pass
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nn_a64_kernel / gemm_tn_256_kernel (+ gemm_nn_256 / gemm_nt_256 for the shapes they serve): 256x256 ping-pong tiles; all rv_gemm_nn_bf16 + rv_gemm_tn_bf16 + rv_gemm_nt_bf16 launches",
                                 "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                 "traffic_note": "HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
-                                                "WRITE_SIZE, separate passes (profiles/r01_pmc_hbm_traffic.json); algorithmic "
+                                                f"WRITE_SIZE, separate passes (profiles/{traffic_file}); algorithmic "
                                                 "operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
                                 "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
                                 "gemm_ms_per_step": g["total_ms"] / args.steps}
