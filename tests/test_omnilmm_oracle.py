@@ -1,0 +1,86 @@
+"""The OmniLMM oracle (oracle/omnilmm_oracle.py) against the fixture the REFERENCE'S OWN OmniLMMForCausalLM / Resampler /
+forward_DPO produced (tests/golden/make_omnilmm_golden.py): resampler forward + all gradients (both position-table
+branches), the <im_start>/<im_end> replacement splice, logits, per-sequence log-probs, DPO loss and parameter gradients."""
+import os
+
+import pytest
+import torch
+
+from oracle import dpo_oracle as O
+from oracle import omnilmm_oracle as OO
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "omnilmm_tiny.pt")
+
+
+def _cfg():
+    return O.LlavaCfg(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=320, model_max_length=256)
+
+
+def _weights(cfg, meta):
+    W = {k: v for k, v in O.make_weights(cfg, seed=3).items() if "vision_tower" not in k and "mm_projector" not in k}
+    W.update(OO.make_resampler_weights(cfg.hidden, meta["kv_dim"], meta["num_query"]))
+    return W
+
+
+def check_grads(gold, mine, rtol=2e-4):
+    assert set(gold) <= set(mine), set(gold) - set(mine)
+    for k, g in gold.items():
+        m = mine[k].detach().float()
+        if "full" in g:
+            scale = float(g["full"].abs().max()) + 1e-12
+            assert float((m - g["full"]).abs().max()) <= rtol * scale + 1e-9, k
+        else:
+            r = torch.randn(m.shape, generator=torch.Generator().manual_seed(99))
+            assert abs(float(m.double().norm()) - g["norm"]) <= rtol * g["norm"] + 1e-9, k
+            assert abs(float((m.double() * r.double()).sum()) - g["proj"]) <= 5 * rtol * g["norm"] * (m.numel() ** 0.5) * 0.05 + 1e-7, k
+            blk = m.reshape(m.shape[0], -1)[:8, :64]
+            scale = float(g["block"].abs().max()) + 1e-12
+            assert float((blk - g["block"]).abs().max()) <= rtol * scale + 1e-9, k
+
+
+@pytest.mark.parametrize("n_tok", [36, 16])
+def test_resampler_matches_reference(n_tok):
+    G = torch.load(GOLD)
+    meta, case = G["meta"], G[f"resampler_{n_tok}"]
+    cfg = _cfg()
+    W = {k: v.clone().requires_grad_(True) for k, v in _weights(cfg, meta).items() if k.startswith(OO.RS)}
+    pos = torch.from_numpy(OO.get_2d_sincos_pos_embed(cfg.hidden, int(meta["num_query"] ** 0.5))).float()
+    assert torch.equal(pos, meta["pos_embed"])                      # the frozen 2-D sincos table, bit for bit
+    x = case["x"].clone().requires_grad_(True)
+    y = OO.resampler_forward(x, W, meta["resampler_heads"])
+    assert float((y - case["y"]).abs().max()) <= 2e-5 * float(case["y"].abs().max())
+    (y * case["gy"]).sum().backward()
+    assert float((x.grad - case["dx"]).abs().max()) <= 2e-4 * float(case["dx"].abs().max())
+    check_grads(case["grads"], {k[len(OO.RS):]: v.grad for k, v in W.items()})
+
+
+def test_dpo_forward_backward_matches_reference():
+    G = torch.load(GOLD)
+    meta, case = G["meta"], G["dpo"]
+    cfg = _cfg()
+    W = {k: v.clone().requires_grad_(True) for k, v in _weights(cfg, meta).items()}
+    out = OO.omnilmm_step_forward(case["batch"], case["tower_features"], W, cfg, meta["resampler_heads"], tuple(meta["tokens"]))
+    assert float((out["logits"] - case["logits"]).abs().max()) <= 1e-4
+    assert torch.allclose(out["log_prob"], case["logp"], rtol=1e-5, atol=1e-3)
+    assert abs(float(out["loss"]) - float(case["loss"])) <= 1e-5
+    assert torch.allclose(out["chosen_rewards"], case["chosen_rewards"], atol=1e-4)
+    out["loss"].backward()
+    mine = {k: v.grad for k, v in W.items() if v.grad is not None}
+    check_grads(case["grads"], mine, rtol=5e-4)
+
+
+def test_splice_keeps_length_and_raises_like_reference():
+    cfg = _cfg()
+    tokens = (317, 318, 319)
+    b = OO.make_omnilmm_batch(cfg, 2, 48, 16, tokens, seed=1)
+    ids = b["concatenated_input_ids"]
+    emb = torch.randn(cfg.vocab, 8)
+    feats = torch.randn(4, 16, 8)
+    e = OO.omnilmm_splice(ids, emb, feats, *tokens)
+    assert e.shape == (4, ids.shape[1], 8)
+    p = int(torch.where(ids[3] == tokens[1])[0][0])
+    assert torch.equal(e[3, p + 1:p + 17], feats[3]) and torch.equal(e[3, p], emb[tokens[1]]) and torch.equal(e[3, p + 17], emb[tokens[2]])
+    bad = ids.clone()
+    bad[0, p + 17] = 5                   # <im_end> missing behind the patches
+    with pytest.raises(ValueError):
+        OO.omnilmm_splice(bad, emb, feats, *tokens)
