@@ -151,6 +151,17 @@ int rv_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const int
                    void* dw, int dw_accumulate, int rows, int d, void* stream);
 int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int d,
                      float eps, void* stream);
+/* LayerNorm backward for the OmniLMM Resampler's trainable ln_q / ln_kv / ln_post (omnilmm/model/resampler.py:127-129,
+ * autograd of F.layer_norm): dx (NULL = not wanted), dw / db written or accumulated.  x_period > 0: rows r and r + x_period
+ * share the x row r % x_period (the learned queries, identical for every image).  partial: fp32 scratch
+ * [rv_rmsnorm_bwd_nblocks(rows)][2 d]. */
+int rv_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, int x_period, const void* w, void* dx, long lddx,
+                     float* partial, void* dw, void* db, int accumulate, int rows, int d, float eps, void* stream);
+/* y[r] = x[r] + p[r % period]: the Resampler's position tables added per image (resampler.py:150-155) */
+int rv_add_rows(const void* x, long ldx, const void* p, long ldp, int period, void* y, long ldy, long rows, int d,
+                void* stream);
+/* y[q] = sum_b x[b * period + q]: gradient of a row block that was broadcast over the batch (resampler.py:166-167 _repeat) */
+int rv_sum_rows_periodic(const void* x, long ldx, int period, int reps, void* y, long ldy, int d, void* stream);
 /* in-place half-split RoPE over n_heads_total adjacent heads (q then k); position = pos[token] when pos != NULL
  * (packed pairs), else token % L (position_ids are dropped: llava/model/language_model/llava_llama.py:94);
  * backward = inverse rotation. */

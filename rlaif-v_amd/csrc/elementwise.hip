@@ -178,6 +178,138 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   }
 }
 
+
+// LayerNorm backward (the OmniLMM Resampler's ln_q / ln_kv / ln_post are trainable: omnilmm/model/resampler.py:127-129).
+// mean / rstd are recomputed from x (one extra pass over a row that is in cache anyway) instead of being stored by the
+// forward; dgamma / dbeta go through the same fixed-order two-stage reduction as the RMSNorm gain gradient.
+// x rows may repeat with period `period` (rows r and r + period share one x row: the learned queries, identical for every image).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, long lddy,
+                                                            const bf16_t* __restrict__ x, long ldx, int period,
+                                                            const bf16_t* __restrict__ w, bf16_t* __restrict__ dx, long lddx,
+                                                            float* __restrict__ partial, int rows, int d, float eps) {
+  __shared__ float red[16];
+  float gacc[RMS_MAX_ITERS][8], bacc[RMS_MAX_ITERS][8];
+#pragma unroll
+  for (int i = 0; i < RMS_MAX_ITERS; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gacc[i][j] = bacc[i][j] = 0.f;
+  const int rows_per = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = min(rows, r0 + rows_per);
+  for (int r = r0; r < r1; ++r) {
+    const bf16_t* xr = x + (long)(period > 0 ? r % period : r) * ldx;
+    const bf16_t* dyr = dy + (long)r * lddy;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+      const int c = threadIdx.x * 8 + i * 2048;
+      if (c < d) {
+        float f[8];
+        unpack8(*(const uint4*)(xr + c), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f[j];
+      }
+    }
+    const float mean = block_sum(s, red) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+      const int c = threadIdx.x * 8 + i * 2048;
+      if (c < d) {
+        float f[8];
+        unpack8(*(const uint4*)(xr + c), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += (f[j] - mean) * (f[j] - mean);
+      }
+    }
+    const float rs = rsqrtf(block_sum(v, red) / (float)d + eps);
+    float s1 = 0.f, s2 = 0.f;        // sum(dy*w), sum(dy*w*xhat)
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+      const int c = threadIdx.x * 8 + i * 2048;
+      if (c < d) {
+        float fx[8], fy[8], fw[8];
+        unpack8(*(const uint4*)(xr + c), fx);
+        unpack8(*(const uint4*)(dyr + c), fy);
+        unpack8(*(const uint4*)(w + c), fw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (fx[j] - mean) * rs, g = fy[j] * fw[j];
+          s1 += g;
+          s2 += g * xh;
+          gacc[i][j] += fy[j] * xh;
+          bacc[i][j] += fy[j];
+        }
+      }
+    }
+    s1 = block_sum(s1, red) / (float)d;
+    s2 = block_sum(s2, red) / (float)d;
+    if (dx) {
+      bf16_t* dxr = dx + (long)r * lddx;
+#pragma unroll
+      for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+        const int c = threadIdx.x * 8 + i * 2048;
+        if (c < d) {
+          float fx[8], fy[8], fw[8], o[8];
+          unpack8(*(const uint4*)(xr + c), fx);
+          unpack8(*(const uint4*)(dyr + c), fy);
+          unpack8(*(const uint4*)(w + c), fw);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = rs * (fy[j] * fw[j] - s1 - (fx[j] - mean) * rs * s2);
+          *(uint4*)(dxr + c) = pack8(o);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+    const int c = threadIdx.x * 8 + i * 2048;
+    if (c < d) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        partial[(long)blockIdx.x * 2 * d + c + j] = gacc[i][j];
+        partial[(long)blockIdx.x * 2 * d + d + c + j] = bacc[i][j];
+      }
+    }
+  }
+}
+
+// y[r][:] = x[r][:] + p[r % period][:]   (position tables broadcast over the images of a batch)
+__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ p,
+                                                       long ldp, int period, bf16_t* __restrict__ y, long ldy, long rows,
+                                                       int d) {
+  const int cpr = d >> 3;
+  const long total = rows * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cpr;
+    const int c = (int)(i % cpr) * 8;
+    float a[8], b[8];
+    unpack8(*(const uint4*)(x + r * ldx + c), a);
+    unpack8(*(const uint4*)(p + (r % period) * ldp + c), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+    *(uint4*)(y + r * ldy + c) = pack8(a);
+  }
+}
+
+// y[q][:] = sum_b x[b * period + q][:]  (fp32 accumulation in fixed order b = 0, 1, ...: deterministic)
+__global__ __launch_bounds__(256) void sum_rows_periodic_kernel(const bf16_t* __restrict__ x, long ldx, int period, int reps,
+                                                                bf16_t* __restrict__ y, long ldy, int d) {
+  const int cpr = d >> 3;
+  const long total = (long)period * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long q = i / cpr;
+    const int c = (int)(i % cpr) * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < reps; ++b) {
+      float a[8];
+      unpack8(*(const uint4*)(x + ((long)b * period + q) * ldx + c), a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += a[j];
+    }
+    *(uint4*)(y + q * ldy + c) = pack8(acc);
+  }
+}
+
 // ------------------------------------------------------------------ RoPE (half-split layout), in place
 // x: [n_tok][ld]; rotates `n_heads_total` heads of width hd starting at column 0 (q then k are adjacent).
 __global__ void rope_kernel(bf16_t* __restrict__ x, long ld, const float* __restrict__ cs_cos,
@@ -795,6 +927,45 @@ int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void
   if (rows == 0) return 0;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx,
                      (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, rows, d, eps);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, int x_period, const void* w, void* dx, long lddx,
+                     float* partial, void* dw, void* db, int accumulate, int rows, int d, float eps, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && d <= 2048 * RMS_MAX_ITERS, "rv_layernorm_bwd: d must be a multiple of 8 and <= 8192");
+  RV_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0, "rv_layernorm_bwd: ld alignment");
+  if (rows == 0) return 0;
+  const int nb = rv_rmsnorm_bwd_nblocks(rows);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, lddy, (const bf16_t*)x,
+                     ldx, x_period, (const bf16_t*)w, (bf16_t*)dx, lddx, partial, rows, d, eps);
+  RV_CHECK_LAUNCH();
+  // partial = [nb][2d] (gain | bias halves): one reduction over 2d columns, then the halves go to dw / db
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, STREAM(stream), partial, nb, 2 * d,
+                     (bf16_t*)dw, accumulate);
+  RV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, STREAM(stream), partial + d, nb, 2 * d,
+                     (bf16_t*)db, accumulate);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_add_rows(const void* x, long ldx, const void* p, long ldp, int period, void* y, long ldy, long rows, int d,
+                void* stream) {
+  RV_REQUIRE(d % 8 == 0 && ldx % 8 == 0 && ldp % 8 == 0 && ldy % 8 == 0 && period > 0, "rv_add_rows: alignment / period");
+  if (rows == 0) return 0;
+  const long total = rows * (d / 8);
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)min((total + 255) / 256, (long)8192)), dim3(256), 0, STREAM(stream),
+                     (const bf16_t*)x, ldx, (const bf16_t*)p, ldp, period, (bf16_t*)y, ldy, rows, d);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_sum_rows_periodic(const void* x, long ldx, int period, int reps, void* y, long ldy, int d, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && period > 0 && reps > 0, "rv_sum_rows_periodic: alignment");
+  const long total = (long)period * (d / 8);
+  hipLaunchKernelGGL(sum_rows_periodic_kernel, dim3((unsigned)min((total + 255) / 256, (long)8192)), dim3(256), 0,
+                     STREAM(stream), (const bf16_t*)x, ldx, period, reps, (bf16_t*)y, ldy, d);
   RV_CHECK_LAUNCH();
   return 0;
 }

@@ -56,6 +56,20 @@ class LlavaConfig:
     pad_token_id: int = 0
     kv_heads: Optional[int] = None      # num_key_value_heads (Mistral / Llama-3 style GQA); None = heads (LLaVA-1.5: MHA)
 
+    arch = "llava"                      # class attribute: "llava" (CLIP + mlp2x_gelu projector) | "omnilmm" (omnilmm.py)
+
+    @property
+    def n_image_tokens(self) -> int:
+        """Sequence positions one image occupies after the splice."""
+        return self.n_patches
+
+    def vision_param_entries(self):
+        """(decay weights, no-decay tensors) of the trainable vision-to-language adapter, each (key, shape, transposed copy),
+        in backward-completion order.  LLaVA-1.5: the mlp2x_gelu projector (llava/model/multimodal_projector/builder.py)."""
+        d, cd = self.hidden, self.clip_hidden
+        return ([("model.mm_projector.2.weight", (d, d), True), ("model.mm_projector.0.weight", (d, cd), False)],
+                [("model.mm_projector.2.bias", (d,), False), ("model.mm_projector.0.bias", (d,), False)])
+
     @property
     def head_dim(self) -> int:
         return self.hidden // self.heads
@@ -139,8 +153,8 @@ class ParamStore:
         # epilogues can apply SwiGLU and its backward in registers (ops.linear_swiglu / linear_swiglu_bwd).  LoRA keeps
         # [gate | up] blocks (its adapter column groups address them).  RV_FUSE_SWIGLU=0: block layout + separate kernels.
         self.interleave_gu = lora is None and os.environ.get("RV_FUSE_SWIGLU", "1") != "0"
-        proj_w: List[Entry] = [("model.mm_projector.2.weight", (d, d), True), ("model.mm_projector.0.weight", (d, cd), False)]
-        proj_b: List[Entry] = [("model.mm_projector.2.bias", (d,), False), ("model.mm_projector.0.bias", (d,), False)]
+        proj_w, proj_b = cfg.vision_param_entries()
+        self.vision_keys = [k for k, _, _ in proj_w + proj_b]
         base_w: List[Entry] = [("lm_head.weight", (V, d), True)]
         for i in reversed(range(cfg.layers)):
             base_w += [(f"layers.{i}.wdown", (d, f), True), (f"layers.{i}.wgu", (2 * f, d), True),
@@ -204,11 +218,11 @@ class ParamStore:
             self.buckets["lm_head"] = self.grad_range("lm_head.weight", "lm_head.weight")
             for i in reversed(range(cfg.layers)):
                 self.buckets[f"layer{i}"] = self.grad_range(f"layers.{i}.wdown", f"layers.{i}.wqkv")
-            self.buckets["embed_proj"] = self.grad_range("model.embed_tokens.weight", "model.mm_projector.0.weight")
+            self.buckets["embed_proj"] = self.grad_range("model.embed_tokens.weight", proj_w[-1][0])
         else:
             for i in reversed(range(cfg.layers)):
                 self.buckets[f"layer{i}"] = self.grad_range(f"layers.{i}.lora_down.B", f"layers.{i}.lora_qkv.A")
-            self.buckets["embed_proj"] = self.grad_range("model.mm_projector.2.weight", "model.mm_projector.0.weight")
+            self.buckets["embed_proj"] = self.grad_range(proj_w[0][0], proj_w[-1][0])
         self.buckets["nodecay"] = (self.n_decay, self.n_train)
 
     def bucket_schedule(self) -> List[Tuple[str, int, int]]:
@@ -264,8 +278,7 @@ class ParamStore:
             m[p + "mlp.down_proj.weight"] = (f"layers.{i}.wdown", 0, d, 1)
             m[p + "input_layernorm.weight"] = (f"layers.{i}.ln1", 0, d, 1)
             m[p + "post_attention_layernorm.weight"] = (f"layers.{i}.ln2", 0, d, 1)
-        for k in ("lm_head.weight", "model.embed_tokens.weight", "model.norm.weight", "model.mm_projector.0.weight",
-                  "model.mm_projector.0.bias", "model.mm_projector.2.weight", "model.mm_projector.2.bias"):
+        for k in ["lm_head.weight", "model.embed_tokens.weight", "model.norm.weight"] + self.vision_keys:
             m[k] = (k, 0, self.offsets[k][1][0], 1)
         return m
 
@@ -339,13 +352,18 @@ class LlavaDPOModel:
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         """HF-named fp32/bf16 CPU tensors (the reference's checkpoint layout, 4.35 CLIP key names)."""
         cfg, st = self.cfg, self.store
-        self._clip_raw = {k: v.detach().to(BF16).cpu() for k, v in sd.items() if k.startswith(VT)}
         for name, (key, r0, n, step) in st.hf_slices(cfg).items():
             st.rows(st.p(key), r0, n, step).copy_(sd[name].to(BF16))
         if self.lora is not None:
             self.load_lora_state_dict(sd, strict=False, _refresh=False)
         st.sync_master_from_params()
         st.refresh_transposes()
+        self._load_tower(sd)
+
+    def _load_tower(self, sd: Dict[str, torch.Tensor]):
+        """The frozen CLIP-ViT-L/14 tower (llava/model/multimodal_encoder/clip_encoder.py) into device tensors."""
+        cfg = self.cfg
+        self._clip_raw = {k: v.detach().to(BF16).cpu() for k, v in sd.items() if k.startswith(VT)}
         cd, Kp = cfg.clip_hidden, cfg.patch_k
 
         def dev(t):
@@ -387,6 +405,10 @@ class LlavaDPOModel:
             self.reset_lora_parameters(seed + 1, lora_b_std)
         st.sync_master_from_params()
         st.refresh_transposes()
+        self._init_tower(g, std)
+
+    def _init_tower(self, g: torch.Generator, std: float):
+        cfg = self.cfg
         cd, Kp = cfg.clip_hidden, cfg.patch_k
 
         def rn(*shape, s=std):
@@ -544,6 +566,20 @@ class LlavaDPOModel:
             ctx.update(f_clip=f_clip, z1=z1, h1=h1)
         return feats
 
+    def _vision_backward(self, dfeat: torch.Tensor, ctx: dict):
+        """Autograd of the mlp2x_gelu projector (the CLIP tower is frozen: llava_arch.py:141-148, train_llava15.py:268)."""
+        st = self.store
+        ops.colsum(dfeat, out=st.g("model.mm_projector.2.bias"))
+        ops.gemm_tn(dfeat, ctx["h1"], out=st.g("model.mm_projector.2.weight"))
+        dh1 = ops.gemm_nt(dfeat, st.pT("model.mm_projector.2.weight"))
+        dz1 = ops.gelu_bwd(dh1, ctx["z1"])
+        ops.colsum(dz1, out=st.g("model.mm_projector.0.bias"))
+        ops.gemm_tn(dz1, ctx["f_clip"], out=st.g("model.mm_projector.0.weight"))
+
+    def _row_splicer(self):
+        """Row-level splice rule handed to the planners (None = LLaVA's expanding <image> splice, splice._splice_rows)."""
+        return None
+
     # ------------------------------------------------------------------ decoder projections (+ LoRA)
     _GROUP_COLS = {"qkv": "hidden", "o": None, "gu": "ffn", "down": None}
 
@@ -648,7 +684,7 @@ class LlavaDPOModel:
         if all_rows:
             if save_for_backward:
                 raise ValueError("all_rows is a forward-only mode")
-            plan = build_splice_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length)
+            plan = build_splice_plan(input_ids, labels, cfg.n_image_tokens, B, cfg.model_max_length, splicer=self._row_splicer())
             nxt = plan.labels[:, 1:]
             S_, Lm1 = nxt.shape
             plan.sel_idx = (torch.arange(S_)[:, None] * plan.L + torch.arange(Lm1)[None]).reshape(-1).to(torch.int32)
@@ -659,11 +695,13 @@ class LlavaDPOModel:
             w_rows = (nxt != -100).reshape(-1).to(torch.float32).to(self.device)     # loss_mask of get_batch_logps
         elif label_shift != 1:
             # get_batch_logps_minicpm convention (labels pre-shifted, muffin_inference_logp.py:21-52): reference layout only
-            plan = build_splice_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length, label_shift=label_shift)
+            plan = build_splice_plan(input_ids, labels, cfg.n_image_tokens, B, cfg.model_max_length, label_shift=label_shift,
+                                     splicer=self._row_splicer())
         elif self.share_prefix and input_ids.shape[0] == 2 * B:
-            plan = build_packed_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length, cfg.pad_token_id)
+            plan = build_packed_plan(input_ids, labels, cfg.n_image_tokens, B, cfg.model_max_length, cfg.pad_token_id,
+                                     splicer=self._row_splicer())
         else:
-            plan = build_splice_plan(input_ids, labels, cfg.n_patches, B, cfg.model_max_length)
+            plan = build_splice_plan(input_ids, labels, cfg.n_image_tokens, B, cfg.model_max_length, splicer=self._row_splicer())
         plan = plan.to(self.device)
         S, L = plan.S, plan.L
         N = S * L
@@ -781,12 +819,7 @@ class LlavaDPOModel:
             ge.zero_()
             ops.embed_bwd(plan.uniq_ids, plan.seg_off, plan.pos_sorted, dx, ge)
         dfeat = ops.feat_grad(plan.feat_src_a, plan.feat_src_b, dx, d)
-        ops.colsum(dfeat, out=st.g("model.mm_projector.2.bias"))
-        wgrad(dfeat, ctx["h1"], "model.mm_projector.2.weight")
-        dh1 = ops.gemm_nt(dfeat, st.pT("model.mm_projector.2.weight"))
-        dz1 = ops.gelu_bwd(dh1, ctx["z1"])
-        ops.colsum(dz1, out=st.g("model.mm_projector.0.bias"))
-        wgrad(dz1, ctx["f_clip"], "model.mm_projector.0.weight")
+        self._vision_backward(dfeat, ctx)
         if hook:
             hook("embed_proj", *st.buckets["embed_proj"])
             hook("nodecay", *st.buckets["nodecay"])

@@ -236,6 +236,38 @@ def layernorm_fwd(x, w, b, eps: float, out=None):
     return out
 
 
+def layernorm_bwd(dy, x, w, eps: float, dw: torch.Tensor, db: torch.Tensor, want_dx: bool = True, x_period: int = 0,
+                  accumulate: bool = False) -> Optional[torch.Tensor]:
+    """F.layer_norm backward: returns dx [rows, d] (None if not wanted); dw / db (bf16 [d]) written or accumulated.
+    ``x_period``: x has only that many rows and row r of dy belongs to x row r % x_period."""
+    _chk2d(dy, "dy"), _chk2d(x, "x")
+    rows, d = dy.shape
+    dx = torch.empty(rows, d, dtype=dy.dtype, device=dy.device) if want_dx else None
+    nb = hip.lib().lib.rv_rmsnorm_bwd_nblocks(rows)
+    partial = torch.empty(nb, 2 * d, dtype=torch.float32, device=dy.device)
+    hip.call("rv_layernorm_bwd", dy, dy.stride(0), x, x.stride(0), int(x_period), w, dx, dx.stride(0) if want_dx else 0,
+             partial, dw, db, int(accumulate), rows, d, float(eps))
+    return dx
+
+
+def add_rows(x: torch.Tensor, p: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r] = x[r] + p[r % len(p)]"""
+    _chk2d(x, "x"), _chk2d(p, "p")
+    if out is None:
+        out = torch.empty_like(x)
+    hip.call("rv_add_rows", x, x.stride(0), p, p.stride(0), p.shape[0], out, out.stride(0), x.shape[0], x.shape[1])
+    return out
+
+
+def sum_rows_periodic(x: torch.Tensor, period: int) -> torch.Tensor:
+    """out[q] = sum_b x[b * period + q]"""
+    _chk2d(x, "x")
+    assert x.shape[0] % period == 0
+    out = torch.empty(period, x.shape[1], dtype=x.dtype, device=x.device)
+    hip.call("rv_sum_rows_periodic", x, x.stride(0), period, x.shape[0] // period, out, out.stride(0), x.shape[1])
+    return out
+
+
 def rope_tables(L: int, hd: int, theta: float, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """fp32 cos/sin [L, hd/2] exactly as HF LlamaRotaryEmbedding computes them (fp32, before any cast)."""
     inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))

@@ -94,6 +94,37 @@ def _splice_rows(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: in
     return rows_src, rows_lab
 
 
+def make_omnilmm_splicer(im_patch: int, im_start: int, im_end: int):
+    """Row splicer for the OmniLMM convention (omnilmm/model/omnilmm.py:221-257, use_im_start_end): the ``num_query``
+    <im_patch> embeddings behind an <im_start> are REPLACED by the image's resampler features - no length change, labels
+    untouched (the data pipeline already masks them).  ``cur_image_idx`` advances once per <im_start> and not at all for
+    a row without <im_patch> tokens; the reference's batch carries cat([images, images]) (trainers.py:190), so global
+    image k is distinct image k % n_images.  The reference restarts every replacement from the ORIGINAL row, so a row
+    with several images keeps only the last one - reproduced here (one image per sample is the DPO data format)."""
+    def splicer(input_ids, labels, n_img_tokens, n_images, max_len):
+        rows_src, rows_lab = [], []
+        cur = 0
+        P = n_img_tokens
+        for ids, lab in zip(input_ids, labels):
+            src = ids.clone()
+            if int((ids == im_patch).sum()) > 0:
+                starts = torch.nonzero(ids == im_start, as_tuple=True)[0]
+                if starts.numel() != int((ids == im_end).sum()):
+                    raise ValueError("The number of image start tokens and image end tokens should be the same.")
+                for p in starts.tolist():
+                    if p + P + 1 >= ids.numel() or int(ids[p + P + 1]) != im_end:
+                        raise ValueError("The image end token should follow the image start token.")
+                    src = ids.clone()
+                    src[p + 1:p + 1 + P] = -2 - ((cur % max(n_images, 1)) * P + torch.arange(P))
+                    cur += 1
+            if max_len is not None:
+                src, lab = src[:max_len], lab[:max_len]
+            rows_src.append(src)
+            rows_lab.append(lab.clone())
+        return rows_src, rows_lab
+    return splicer
+
+
 def _tables(flat: torch.Tensor, n_feat_rows: int):
     """Embedding-backward segments and feature-gradient sources from the flat source table."""
     text_rows = torch.nonzero(flat >= 0, as_tuple=True)[0]
@@ -127,7 +158,7 @@ def _tables(flat: torch.Tensor, n_feat_rows: int):
 
 
 def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
-                      max_len: Optional[int], label_shift: int = 1) -> SplicePlan:
+                      max_len: Optional[int], label_shift: int = 1, splicer=None) -> SplicePlan:
     """Reference layout.  input_ids/labels: int64 [S, T] (the collator's ``concatenated_*`` tensors);
     ``n_images`` distinct images were encoded (one per pair).  label_shift = 1: get_batch_logps
     (labels[:, 1:] vs logits[:, :-1], muffin_inference_logp.py:93-94); 0: get_batch_logps_minicpm (labels already
@@ -137,7 +168,7 @@ def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
     input_ids = input_ids.cpu().long()
     labels = labels.cpu().long()
     S = input_ids.shape[0]
-    rows_src, rows_lab = _splice_rows(input_ids, labels, n_img_tokens, n_images, max_len)
+    rows_src, rows_lab = (splicer or _splice_rows)(input_ids, labels, n_img_tokens, n_images, max_len)
     L = max(int(x.numel()) for x in rows_src)                              # :286
     src_full = torch.full((S, L), -1, dtype=torch.int64)                   # zero-embedding right pad (:305-313)
     lab_full = torch.full((S, L), IGNORE_INDEX, dtype=torch.int64)
@@ -164,7 +195,7 @@ def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
 
 
 def build_packed_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
-                      max_len: Optional[int], pad_token_id: int = 0) -> SplicePlan:
+                      max_len: Optional[int], pad_token_id: int = 0, splicer=None) -> SplicePlan:
     """One row per pair: [shared prefix | chosen branch | rejected branch] (module docstring).
     input_ids / labels: [2B, T], wins then rejects."""
     input_ids = input_ids.cpu().long()
@@ -173,7 +204,7 @@ def build_packed_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
     if S2 % 2:
         raise ValueError("packed layout needs wins followed by the same number of rejects")
     B = S2 // 2
-    rows_src, rows_lab = _splice_rows(input_ids, labels, n_img_tokens, n_images, max_len)
+    rows_src, rows_lab = (splicer or _splice_rows)(input_ids, labels, n_img_tokens, n_images, max_len)
     for r in range(S2):        # drop the collator's right padding (pad id with label -100 at the very end)
         pad = (rows_src[r] == pad_token_id) & (rows_lab[r] == IGNORE_INDEX)
         keep = int(torch.nonzero(~pad)[-1]) + 1 if bool((~pad).any()) else 1

@@ -416,3 +416,28 @@ def test_dkv3_isa_has_no_compiler_agpr_traffic():
     out = subprocess.run(["bash", os.path.join(REPO, "tools", "check_agpr_isa.sh")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-500:]
     assert "instructions in dkv3: 0" in out.stdout
+
+
+def test_omnilmm_splice_plan_matches_oracle_bit_exact():
+    """The <im_start>/<im_end> replacement rule of the planner against the oracle's restatement of omnilmm.py:221-257
+    (itself pinned by the reference golden): identical spliced rows, unchanged labels, both layouts' targets."""
+    import importlib
+    from oracle import omnilmm_oracle as OO
+    from oracle import dpo_oracle as O
+    sp = importlib.import_module("rlaif-v_amd.splice")
+    tokens = (317, 318, 319)
+    cfg = O.LlavaCfg(hidden=512, layers=1, heads=4, kv_heads=2, ffn=768, vocab=320, model_max_length=256)
+    b = OO.make_omnilmm_batch(cfg, 3, 60, 16, tokens, seed=2)
+    ids, lab = b["concatenated_input_ids"], b["concatenated_labels"]
+    emb = torch.arange(cfg.vocab, dtype=torch.float32)[:, None].repeat(1, 2)
+    feats = (-2.0 - torch.arange(3 * 16, dtype=torch.float32)).view(3, 16, 1).repeat(1, 1, 2)
+    ref = OO.omnilmm_splice(ids, emb, torch.cat([feats, feats], 0), *tokens)[..., 0]        # [6, T]: id or -2 - feature row
+    plan = sp.build_splice_plan(ids, lab, 16, 3, 256, splicer=sp.make_omnilmm_splicer(*tokens))
+    assert torch.equal(plan.src.view(plan.S, plan.L).float(), ref)
+    assert torch.equal(plan.labels, lab)
+    packed = sp.build_packed_plan(ids, lab, 16, 3, 256, 0, splicer=sp.make_omnilmm_splicer(*tokens))
+    assert torch.equal(packed.tgt, plan.tgt) and packed.S == 3 and min(packed.shared_len) >= 1 + 8 + 18
+    bad = ids.clone()
+    bad[0, int(torch.where(ids[0] == tokens[2])[0][0])] = 7
+    with pytest.raises(ValueError):
+        sp.build_splice_plan(bad, lab, 16, 3, 256, splicer=sp.make_omnilmm_splicer(*tokens))
