@@ -27,13 +27,14 @@ PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICR
 
 
 def flops_per_seq(n_tok: float, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000,
-                  lora_r: int = 0, n_tgt: float = None) -> float:
+                  lora_r: int = 0, n_tgt: float = None, kvd: int = None) -> float:
     """Algorithmic FLOPs of fwd + bwd over one sequence of n_tok tokens (causal attention at half, no recompute).
     Full fine-tune: forward + input gradients + weight gradients = 3 passes over the linear layers.  LoRA: the base
     weights are frozen -> 2 passes, plus the adapters (forward t = xA^T and tB^T; backward dt, dt A, dA, dB = 2x).
     ``n_tgt``: rows that reach the LM head (positions whose next label is a target); None = all n_tok rows, SURVEY's
     reference-layout accounting (the reference computes logits for every position)."""
-    per_tok_linear = layers * (8 * d * d + 6 * d * f)
+    kvd = d if kvd is None else kvd                      # grouped-query attention: k / v projections are [kvd, d]
+    per_tok_linear = layers * (4 * d * d + 4 * d * kvd + 6 * d * f)
     per_tok_attn = layers * 2 * d * n_tok
     per_tok_lora = layers * 2 * lora_r * (4 * 2 * d + 3 * (d + f))
     passes = 2 if lora_r else 3
@@ -42,10 +43,10 @@ def flops_per_seq(n_tok: float, layers: int = 32, d: int = 4096, f: int = 11008,
 
 
 def flops_per_pair(L: int, layers: int = 32, d: int = 4096, f: int = 11008, V: int = 32000, lora_r: int = 0,
-                   n_tgt: float = None) -> float:
+                   n_tgt: float = None, kvd: int = None, vision: float = 0.366e12 + 3 * 0.024e12) -> float:
     """algorithmic FLOPs of one pair (two sequences of L tokens), CLIP once per pair (forward
     only) + projector (fwd+bwd).  Full fine-tune at L = 2048: 169.4 TFLOP (n_tgt None = LM head on every position)."""
-    return 2 * flops_per_seq(L, layers, d, f, V, lora_r, n_tgt) + 0.366e12 + 3 * 0.024e12
+    return 2 * flops_per_seq(L, layers, d, f, V, lora_r, n_tgt, kvd) + vision
 
 
 class GemmTimer:
@@ -191,6 +192,9 @@ def main():
                          "frozen base; use with --seq-len 4096).  Not the headline line.")
     ap.add_argument("--lora-r", type=int, default=64)
     ap.add_argument("--gradient-checkpointing", action="store_true", help="re-run each decoder layer in backward")
+    ap.add_argument("--omnilmm", action="store_true",
+                    help="BASELINE config 4 shape: OmniLMM-12B language side (Mistral-7B, 8 kv heads, f 14336) + Resampler, "
+                         "64 image tokens; the frozen EVA02 tower is NOT run - synthetic precomputed tower tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dp-probe", action="store_true",
                     help="skip the 1-rank RCCL probe (steps re-timed with the bucketed all-reduce forced on)")
@@ -212,9 +216,14 @@ def main():
     import torch.distributed as dist
 
     L, B = args.seq_len, args.pairs_per_gpu
-    cfg = LlavaConfig(layers=args.layers, model_max_length=L)
     lora = LoraConfig(r=args.lora_r) if args.lora else None        # peft defaults of train_llava15_lora.py:111-116
-    model = LlavaDPOModel(cfg, device=dev, lora=lora)
+    if args.omnilmm:
+        from rlaif_v_amd.omnilmm import OmniLMMConfig, OmniLMMDPOModel
+        cfg = OmniLMMConfig(layers=args.layers, model_max_length=L)
+        model = OmniLMMDPOModel(cfg, device=dev, lora=lora)
+    else:
+        cfg = LlavaConfig(layers=args.layers, model_max_length=L)
+        model = LlavaDPOModel(cfg, device=dev, lora=lora)
     model.init_random(seed=0)            # identical weights on every rank
     reducer = BucketedAllReduce(model.store.flat_g) if world > 1 else None
     targs = TrainingArguments(max_steps=1000, per_device_train_batch_size=B, lora_enable=args.lora,
@@ -224,8 +233,14 @@ def main():
 
     class _Tok:
         pad_token_id = cfg.pad_token_id
-    ds = SyntheticPreferenceDataset(n=B * world, vocab=cfg.vocab, text_len=L - (cfg.n_patches - 1), prompt_len=64,
-                                    image_size=cfg.image_size, seed=1234)
+    if args.omnilmm:      # the image span does not change the length: text length = L; 1024 tower tokens of width 1792 per image
+        ds = SyntheticPreferenceDataset(n=B * world, vocab=32000, text_len=L, prompt_len=64 + cfg.num_query + 2, seed=1234,
+                                        omnilmm=dict(tokens=(cfg.im_patch_token, cfg.im_start_token, cfg.im_end_token),
+                                                     num_query=cfg.num_query, tower_tokens=(cfg.image_size // 14) ** 2,
+                                                     width=cfg.vision_width))
+    else:
+        ds = SyntheticPreferenceDataset(n=B * world, vocab=cfg.vocab, text_len=L - (cfg.n_patches - 1), prompt_len=64,
+                                        image_size=cfg.image_size, seed=1234)
     collate = DataCollatorForDPODataset(_Tok(), beta=0.1, mod_token_weight=1.0)
     batch = collate([ds[rank * B + i] for i in range(B)])
     batch["images"] = batch["images"].to(dev)       # inputs resident in HBM before the timed region
@@ -289,21 +304,30 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         pairs_per_s = B * world * args.steps / dt
         lr_ = args.lora_r if args.lora else 0
-        fp_nominal = flops_per_pair(L, layers=args.layers, lora_r=lr_)       # LM head on every position
+        if args.omnilmm:     # resampler fwd + bwd per image: kv_proj, k / v / q / out / proj projections, 64 x N attention
+            nt_, w_, d_, nq_ = (cfg.image_size // 14) ** 2, cfg.vision_width, cfg.hidden, cfg.num_query
+            vis = 3.0 * (2 * nt_ * w_ * d_ + 2 * 2 * nt_ * d_ * d_ + 3 * 2 * nq_ * d_ * d_ + 4 * nq_ * nt_ * d_)
+        else:
+            vis = 0.366e12 + 3 * 0.024e12
+        dims = dict(d=cfg.hidden, f=cfg.ffn, V=cfg.vocab, kvd=cfg.kv_dim, vision=vis)
+        fp_nominal = flops_per_pair(L, layers=args.layers, lora_r=lr_, **dims)       # LM head on every position
         # FLOPs actually required (report the MFMA fraction on these): the LM head runs only on
         # the rows whose next label is a target, and the shared prefix of each pair is computed once
         plan = model.last_out.plan
         shared = plan.shared_len or [0] * B
-        saved = sum(flops_per_seq(p, layers=args.layers, lora_r=lr_, n_tgt=0) for p in shared) / max(len(shared), 1)
-        fp = flops_per_pair(L, layers=args.layers, lora_r=lr_, n_tgt=plan.n_sel / (2.0 * B)) - saved
+        seq_dims = {k: v for k, v in dims.items() if k != "vision"}
+        saved = sum(flops_per_seq(p, layers=args.layers, lora_r=lr_, n_tgt=0, **seq_dims) for p in shared) / max(len(shared), 1)
+        fp = flops_per_pair(L, layers=args.layers, lora_r=lr_, n_tgt=plan.n_sel / (2.0 * B), **dims) - saved
         step_tflops_per_gpu = fp * (pairs_per_s / world) / 1e12
         line = {
-            "metric": "preference-pairs/sec (DPO step) LLaVA-1.5-7B bf16", "value": pairs_per_s, "unit": "pairs/s",
+            "metric": "preference-pairs/sec (DPO step) " + ("OmniLMM-12B (tower excluded)" if args.omnilmm else "LLaVA-1.5-7B") + " bf16", "value": pairs_per_s, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B) "
+            "config": {"workload": ("OmniLMM-12B language side (Mistral-7B: 8 kv heads, f 14336) + Resampler (64 queries x 1024 "
+                                    "tower tokens); frozen EVA02-E tower NOT run (precomputed synthetic tower tokens) "
+                                    if args.omnilmm else "LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B) ")
                                    + (f"LoRA (r={args.lora_r}, all 7 decoder projections, dropout 0.05)" if args.lora else "full-FT")
-                                   + f" DPO step, 336px, seq_len={L}, {B} pairs/GPU, random-init weights",
+                                   + f" DPO step, {cfg.image_size}px, seq_len={L}, {B} pairs/GPU, random-init weights",
                        "pairs_per_gpu": B, "global_batch_pairs": B * world, "seq_len": L, "llm_layers": args.layers,
                        "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0",
                        "trainable_params": int(model.store.n_train),
@@ -338,7 +362,7 @@ def main():
             if "ms_per_step" in dp_probe:
                 dp_probe["exposed_ms_per_step"] = dp_probe["ms_per_step"] - ms_per_step
             line["dp_overlap_probe_1rank"] = dp_probe
-        if world == 1 and not args.no_cpu_baseline and not args.lora:     # the CPU leg times the full-FT oracle step
+        if world == 1 and not args.no_cpu_baseline and not args.lora and not args.omnilmm:     # the CPU leg times the full-FT oracle step
             line["cpu_baseline"] = cpu_baseline()
     if world > 1:
         dist.barrier()

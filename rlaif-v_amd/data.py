@@ -15,6 +15,7 @@ from dataclasses import dataclass
 from typing import Dict, List, Sequence, Tuple
 
 import torch
+from typing import Optional
 
 IGNORE_INDEX = -100
 IMAGE_TOKEN_INDEX = -200
@@ -150,9 +151,15 @@ class SyntheticPreferenceDataset(torch.utils.data.Dataset):
     exercised.  No tokenizer / parquet / JPEG is involved (none exist offline)."""
 
     def __init__(self, n: int, vocab: int, text_len: int, prompt_len: int = 64, image_size: int = 336,
-                 image_pos: int = 35, seed: int = 0, ragged: bool = False):
+                 image_pos: int = 35, seed: int = 0, ragged: bool = False, omnilmm: Optional[dict] = None):
+        """``omnilmm`` = dict(tokens=(im_patch, im_start, im_end), num_query=, tower_tokens=, width=): the OmniLMM token
+        convention (<im_start> <im_patch> x num_query <im_end> inside the prompt, omnilmm.py:221-257) and, as ``image``,
+        precomputed tower tokens [tower_tokens, width] (the tower is frozen; rlaif-v_amd/omnilmm.py)."""
         self.n, self.vocab, self.text_len, self.prompt_len = n, vocab, text_len, prompt_len
         self.image_size, self.image_pos, self.seed, self.ragged = image_size, min(image_pos, prompt_len - 2), seed, ragged
+        self.omnilmm = omnilmm
+        if omnilmm is not None and self.image_pos + omnilmm["num_query"] + 2 > prompt_len:
+            raise ValueError("prompt_len too short for <im_start> + num_query patches + <im_end>")
 
     def __len__(self):
         return self.n
@@ -161,8 +168,15 @@ class SyntheticPreferenceDataset(torch.utils.data.Dataset):
         g = torch.Generator().manual_seed(self.seed * 1000003 + i)
         prompt = torch.randint(3, self.vocab, (self.prompt_len,), generator=g)
         prompt[0] = 1
-        prompt[self.image_pos] = IMAGE_TOKEN_INDEX
-        image = torch.randn(3, self.image_size, self.image_size, generator=g)
+        if self.omnilmm is None:
+            prompt[self.image_pos] = IMAGE_TOKEN_INDEX
+            image = torch.randn(3, self.image_size, self.image_size, generator=g)
+        else:
+            o = self.omnilmm
+            pt, st, en = o["tokens"]
+            nq, a = o["num_query"], self.image_pos
+            prompt[a], prompt[a + 1:a + 1 + nq], prompt[a + 1 + nq] = st, pt, en
+            image = torch.randn(o["tower_tokens"], o["width"], generator=g).to(torch.bfloat16)
         out = []
         for tag in ("rej", "win"):
             if self.ragged:
