@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 1
+#define RV_ABI_VERSION 2
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
@@ -96,15 +96,17 @@ int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, flo
 /* ---- fused LM head + log-softmax + label gather (replaces lm_head + get_batch_logps,
  *      muffin/eval/muffin_inference_logp.py:82-115; logits [rows, V] never reach HBM).
  *   fwd : per selected row m and 64-column block j:  pmax[m][j], psum[m][j] = max / sum exp(x - max);
- *         tgt_logit[m] = logit of tgt[m].   V % 64 == 0.
+ *         tgt_logit[m] = logit of tgt[m].   V = rows of W = a multiple of 64; columns [V_valid, V) are vocabulary
+ *         padding (a tokenizer with added tokens, e.g. OmniLMM's 32000 + 9): left out of the softmax, zero in dlogits.
  *   finish: lse[m], logp[m] = tgt_logit[m] - lse[m].
  *   bwd : dlogits[m][n] = coef[m] * ((n == tgt[m]) - exp(logit - lse[m]))  (bf16, recomputed logits). */
-int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, int M, int V, int K,
+int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, int M, int V, int V_valid, int K,
                        float* pmax, float* psum, float* tgt_logit, int variant, void* stream);
 int rv_logp_finish(const float* pmax, const float* psum, const float* tgt_logit, int nblk, int M, float* lse,
                    float* logp, void* stream);
 int rv_lmhead_logp_bwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, const float* lse,
-                       const float* coef, void* dlogits, long ldd, int M, int V, int K, int variant, void* stream);
+                       const float* coef, void* dlogits, long ldd, int M, int V, int V_valid, int K, int variant,
+                       void* stream);
 /* (per_token_logps * loss_mask).sum(-1) and loss_mask.sum(-1) of get_batch_logps (:103-104); rows of
  * sequence s are seq_off[s] .. seq_off[s+1]; optional per-row weight (compute_weighted_logp,
  * muffin/train/trainers.py:128-137). Fixed summation order. */

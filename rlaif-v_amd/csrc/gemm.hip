@@ -401,23 +401,26 @@ int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, flo
   return dispatch(g, epi, variant, stream);
 }
 
-int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, int M, int V, int K,
+int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, int M, int V, int V_valid, int K,
                        float* pmax, float* psum, float* tgt_logit, int variant, void* stream) {
   if (M == 0) return 0;
   GemmShape g{(const bf16_t*)h, (const bf16_t*)W, M, V, K, ldh, ldw, g_group};
   if (check_shape(g, "rv_lmhead_logp_fwd")) return 1;
-  RV_REQUIRE(V % 64 == 0, "rv_lmhead_logp_fwd: vocabulary must be a multiple of 64");
-  EpiLogpFwd epi{tgt, pmax, psum, tgt_logit};
+  RV_REQUIRE(V % 64 == 0, "rv_lmhead_logp_fwd: the STORED vocabulary (rows of W) must be a multiple of 64; pad with zero rows");
+  RV_REQUIRE(V_valid > V - 64 && V_valid <= V, "rv_lmhead_logp_fwd: V - 64 < V_valid <= V");
+  EpiLogpFwd epi{tgt, pmax, psum, tgt_logit, V_valid};
   return dispatch(g, epi, variant, stream);
 }
 
 int rv_lmhead_logp_bwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, const float* lse,
-                       const float* coef, void* dlogits, long ldd, int M, int V, int K, int variant, void* stream) {
+                       const float* coef, void* dlogits, long ldd, int M, int V, int V_valid, int K, int variant,
+                       void* stream) {
   if (M == 0) return 0;
   GemmShape g{(const bf16_t*)h, (const bf16_t*)W, M, V, K, ldh, ldw, g_group};
   if (check_shape(g, "rv_lmhead_logp_bwd")) return 1;
   RV_REQUIRE(ldd % 4 == 0, "rv_lmhead_logp_bwd: ldd must be a multiple of 4");
-  EpiLogpBwd epi{tgt, lse, coef, (bf16_t*)dlogits, ldd};
+  RV_REQUIRE(V_valid > V - 64 && V_valid <= V, "rv_lmhead_logp_bwd: V - 64 < V_valid <= V");
+  EpiLogpBwd epi{tgt, lse, coef, (bf16_t*)dlogits, ldd, V_valid};
   return dispatch(g, epi, variant, stream);
 }
 

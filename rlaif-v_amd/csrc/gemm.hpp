@@ -1395,9 +1395,19 @@ struct EpiLogpFwd {
   float* pmax;         // [M][N/64]
   float* psum;         // [M][N/64]
   float* tgt_logit;    // [M]
+  int n_valid;         // columns [n_valid, N) are vocabulary padding (N % 64 == 0, N - 64 < n_valid <= N): not in the softmax
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
     const int nblk = N >> 6;
     if (nw >= N) return;
+    if (nw + 64 > n_valid) {           // the last 64-column block of a padded vocabulary (wave-uniform)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (nw + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) >= n_valid) acc[tm][tn][r] = -INFINITY;
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int m = mw + tm * 32 + (lane & 31);
@@ -1432,6 +1442,7 @@ struct EpiLogpFwd {
 struct EpiLogpBwd {
   const int* tgt; const float* lse; const float* coef;
   bf16_t* dlogits; long ldd;
+  int n_valid;         // columns [n_valid, N): vocabulary padding, written as zeros
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -1449,7 +1460,7 @@ struct EpiLogpBwd {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float p = __expf(acc[tm][tn][rg * 4 + j] - l);
-            v[j] = c * (((n + j) == t ? 1.f : 0.f) - p);
+            v[j] = (n + j < n_valid) ? c * (((n + j) == t ? 1.f : 0.f) - p) : 0.f;
           }
           uint2 o;
           o.x = pack2bf(v[0], v[1]);

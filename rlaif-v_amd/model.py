@@ -59,6 +59,13 @@ class LlavaConfig:
     arch = "llava"                      # class attribute: "llava" (CLIP + mlp2x_gelu projector) | "omnilmm" (omnilmm.py)
 
     @property
+    def vocab_padded(self) -> int:
+        """Rows of embed_tokens / lm_head as stored: the tokenizer's vocabulary rounded up to the fused LM head's 64-column
+        blocks.  The padding rows are zero, are never indexed, never enter the softmax (rv_lmhead_logp_* V_valid) and get
+        zero gradient, so they stay zero under AdamW; HF tensors map to the first ``vocab`` rows."""
+        return ops.round_up(self.vocab, 64)
+
+    @property
     def n_image_tokens(self) -> int:
         """Sequence positions one image occupies after the splice."""
         return self.n_patches
@@ -142,7 +149,7 @@ class ParamStore:
     """Flat parameter / gradient / optimizer-state buffers with named views."""
 
     def __init__(self, cfg: LlavaConfig, device, with_optimizer: bool = True, lora: Optional[LoraConfig] = None):
-        d, f, V, cd, kvd = cfg.hidden, cfg.ffn, cfg.vocab, cfg.clip_hidden, cfg.kv_dim
+        d, f, V, cd, kvd = cfg.hidden, cfg.ffn, cfg.vocab_padded, cfg.clip_hidden, cfg.kv_dim
         if cfg.heads % cfg.n_kv_heads != 0:
             raise ValueError("kv_heads must divide heads")
         if lora is not None and kvd != d:
@@ -279,7 +286,7 @@ class ParamStore:
             m[p + "input_layernorm.weight"] = (f"layers.{i}.ln1", 0, d, 1)
             m[p + "post_attention_layernorm.weight"] = (f"layers.{i}.ln2", 0, d, 1)
         for k in ["lm_head.weight", "model.embed_tokens.weight", "model.norm.weight"] + self.vision_keys:
-            m[k] = (k, 0, self.offsets[k][1][0], 1)
+            m[k] = (k, 0, cfg.vocab if k in ("lm_head.weight", "model.embed_tokens.weight") else self.offsets[k][1][0], 1)
         return m
 
     @staticmethod
@@ -403,6 +410,9 @@ class LlavaDPOModel:
                 st.flat_p[a:b] = (torch.randn(b - a, device=self.device, generator=g) * std).to(BF16)
         if self.lora is not None:
             self.reset_lora_parameters(seed + 1, lora_b_std)
+        if cfg.vocab_padded != cfg.vocab:                       # vocabulary padding rows are zero (LlavaConfig.vocab_padded)
+            st.p("lm_head.weight")[cfg.vocab:].zero_()
+            st.p("model.embed_tokens.weight")[cfg.vocab:].zero_()
         st.sync_master_from_params()
         st.refresh_transposes()
         self._init_tower(g, std)
@@ -719,7 +729,7 @@ class LlavaDPOModel:
         hsel = torch.zeros(n_pad, d, dtype=BF16, device=self.device)
         if n_sel > 0:
             _, rstd_f = ops.rmsnorm_fwd(x, st.p("model.norm.weight"), cfg.rms_eps, row_idx=plan.sel_idx, out=hsel[:n_sel])
-            logp, lse_v = ops.lmhead_logp_fwd(hsel, st.p("lm_head.weight"), plan.tgt, n_sel)
+            logp, lse_v = ops.lmhead_logp_fwd(hsel, st.p("lm_head.weight"), plan.tgt, n_sel, v_valid=cfg.vocab)
         else:
             rstd_f = torch.empty(0, dtype=torch.float32, device=self.device)
             logp = torch.empty(0, dtype=torch.float32, device=self.device)
@@ -758,7 +768,8 @@ class LlavaDPOModel:
         dx = torch.zeros(N, d, dtype=BF16, device=self.device)
         if n_sel > 0:
             rc = ops.row_coef(coef, plan.seq_of_row, ctx["w_rows"])
-            dlog = ops.lmhead_logp_bwd(ctx["hsel"], st.p("lm_head.weight"), plan.tgt, ctx["lse_v"], rc, n_sel)
+            dlog = ops.lmhead_logp_bwd(ctx["hsel"], st.p("lm_head.weight"), plan.tgt, ctx["lse_v"], rc, n_sel,
+                                       v_valid=cfg.vocab)
             dh = ops.linear(dlog, st.pT("lm_head.weight"), st.p("lm_head.weight"))
             if not lora:
                 wgrad(dlog, ctx["hsel"], "lm_head.weight")
@@ -847,8 +858,8 @@ class LlavaDPOModel:
         for i in range(cfg.layers):
             x, _ = self._layer_fwd(i, x, plan, cos, sin, False)
         h, _ = ops.rmsnorm_fwd(x, st.p("model.norm.weight"), cfg.rms_eps, want_rstd=False)
-        logits = ops.gemm_nt(h, st.p("lm_head.weight"))
-        return SimpleNamespace(logits=logits.view(S, L, cfg.vocab), loss=None)
+        logits = ops.gemm_nt(h, st.p("lm_head.weight"))[:, :cfg.vocab]          # drop the vocabulary padding columns
+        return SimpleNamespace(logits=logits.reshape(S, L, cfg.vocab), loss=None)
 
     __call__ = forward
 

@@ -34,7 +34,7 @@ class OmniLMMConfig(LlavaConfig):
     448-px images, EVA02-E/14 width 1792; three added tokens <im_patch>, <im_start>, <im_end>)."""
     ffn: int = 14336
     kv_heads: Optional[int] = 8
-    vocab: int = 32064                  # 32000 + added tokens, padded to the LM-head kernel's 64-column blocks (INTEGRATION.md)
+    vocab: int = 32009                  # 32000 + <im_patch> <im_start> <im_end> + 6 box / ref / quad tokens (omnilmm.py:388-420)
     image_size: int = 448
     num_query: int = 64
     vision_width: int = 1792

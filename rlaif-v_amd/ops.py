@@ -383,10 +383,12 @@ def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv:
 
 
 # ------------------------------------------------------------------------------------- LM head / loss
-def lmhead_logp_fwd(h: torch.Tensor, w: torch.Tensor, tgt: torch.Tensor, n_rows: int):
-    """h: [rows_padded, d] (rows >= n_rows), w: [V, d], tgt int32 [n_rows] -> (logp, lse) fp32 [n_rows]."""
+def lmhead_logp_fwd(h: torch.Tensor, w: torch.Tensor, tgt: torch.Tensor, n_rows: int, v_valid: Optional[int] = None):
+    """h: [rows_padded, d] (rows >= n_rows), w: [V, d], tgt int32 [n_rows] -> (logp, lse) fp32 [n_rows].
+    ``v_valid``: the tokenizer's vocabulary when w carries padding rows up to a multiple of 64."""
     _chk2d(h, "h"), _chk2d(w, "w")
     V = w.shape[0]
+    v_valid = V if v_valid is None else v_valid
     nblk = V // 64
     dev = h.device
     pmax = torch.empty(n_rows, nblk, dtype=torch.float32, device=dev)
@@ -394,17 +396,18 @@ def lmhead_logp_fwd(h: torch.Tensor, w: torch.Tensor, tgt: torch.Tensor, n_rows:
     tl = torch.zeros(n_rows, dtype=torch.float32, device=dev)
     lse = torch.empty(n_rows, dtype=torch.float32, device=dev)
     logp = torch.empty(n_rows, dtype=torch.float32, device=dev)
-    hip.call("rv_lmhead_logp_fwd", h, h.stride(0), w, w.stride(0), tgt, n_rows, V, h.shape[1], pmax, psum, tl, -1)
+    hip.call("rv_lmhead_logp_fwd", h, h.stride(0), w, w.stride(0), tgt, n_rows, V, v_valid, h.shape[1], pmax, psum, tl, -1)
     hip.call("rv_logp_finish", pmax, psum, tl, nblk, n_rows, lse, logp)
     return logp, lse
 
 
-def lmhead_logp_bwd(h, w, tgt, lse, coef, n_rows: int, out: Optional[torch.Tensor] = None):
-    """dlogits bf16 [rows_padded, V]; rows >= n_rows are zero."""
+def lmhead_logp_bwd(h, w, tgt, lse, coef, n_rows: int, out: Optional[torch.Tensor] = None, v_valid: Optional[int] = None):
+    """dlogits bf16 [rows_padded, V]; rows >= n_rows and columns >= v_valid are zero."""
     V = w.shape[0]
+    v_valid = V if v_valid is None else v_valid
     if out is None:
         out = torch.zeros(h.shape[0], V, dtype=BF16, device=h.device)
-    hip.call("rv_lmhead_logp_bwd", h, h.stride(0), w, w.stride(0), tgt, lse, coef, out, out.stride(0), n_rows, V,
+    hip.call("rv_lmhead_logp_bwd", h, h.stride(0), w, w.stride(0), tgt, lse, coef, out, out.stride(0), n_rows, V, v_valid,
              h.shape[1], -1)
     return out
 

@@ -102,11 +102,11 @@ def compress_grads(grads):
             out[k] = dict(norm=float(g.double().norm()), proj=float((g.double() * r.double()).sum()),
                           block=g2[:8, :64].clone())
     return out
-TOKENS = (317, 318, 319)            # <im_patch>, <im_start>, <im_end>: the last ids of the 320-token toy vocabulary
+TOKENS = (322, 323, 324)            # <im_patch>, <im_start>, <im_end>: the last ids of a 325-token toy vocabulary (NOT a multiple of 64: padded-head path)
 
 
 def tiny_cfg() -> O.LlavaCfg:
-    return O.LlavaCfg(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=320, model_max_length=256)
+    return O.LlavaCfg(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=325, model_max_length=256)
 
 
 def lm_weights(cfg, seed=3):

@@ -480,6 +480,31 @@ def test_lmhead_logp_fwd_bwd(ops):
     close(dW, wf.grad, rel=2e-2, what="lm head dW")
 
 
+@pytest.mark.parametrize("v_valid", [449, 457, 511])
+def test_lmhead_logp_padded_vocabulary(ops, v_valid):
+    """A tokenizer with added tokens (OmniLMM: 32000 + 9): the stored head has zero rows up to a multiple of 64; those columns
+    must not enter the softmax (forward) and get zero dlogits (backward) - compared with the UNPADDED fp32 computation."""
+    dev = _dev()
+    n, d, V = 100, 256, 512
+    npad = ops.round_up(n, 64)
+    h = torch.zeros(npad, d, dtype=BF, device=dev)
+    h[:n] = rnd(n, d, seed=1, dev=dev)
+    w = rnd(V, d, seed=2, dev=dev, scale=0.2)
+    w[v_valid:] = 0
+    tgt = torch.randint(0, v_valid, (n,), generator=torch.Generator().manual_seed(3)).to(torch.int32).to(dev)
+    tgt[0], tgt[1] = 0, v_valid - 1
+    logp, lse = ops.lmhead_logp_fwd(h, w, tgt, n, v_valid=v_valid)
+    logits = h[:n].float() @ w[:v_valid].float().t()
+    ref_lp = logits.log_softmax(-1).gather(1, tgt.long()[:, None])[:, 0]
+    torch.testing.assert_close(lse, torch.logsumexp(logits, -1), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(logp, ref_lp, rtol=1e-4, atol=1e-3)
+    coef = torch.randn(n, generator=torch.Generator().manual_seed(4)).to(dev)
+    dlog = ops.lmhead_logp_bwd(h, w, tgt, lse, coef, n, v_valid=v_valid)
+    p = torch.softmax(logits, -1)
+    close(dlog[:n, :v_valid], coef[:, None] * (F.one_hot(tgt.long(), v_valid).float() - p), rel=1e-2, what="dlogits (valid columns)")
+    assert dlog[:, v_valid:].abs().sum() == 0 and dlog[n:].abs().sum() == 0
+
+
 def test_seq_sum_and_dpo_loss(ops):
     dev = _dev()
     from oracle import dpo_oracle as O

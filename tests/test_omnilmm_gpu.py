@@ -33,13 +33,13 @@ def _cos(a, b):
 def _cfg(meta):
     from rlaif_v_amd.omnilmm import OmniLMMConfig
     pt, st, en = meta["tokens"]
-    return OmniLMMConfig(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=320, model_max_length=256,
+    return OmniLMMConfig(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=325, model_max_length=256,
                          num_query=meta["num_query"], vision_width=meta["kv_dim"], image_size=84,
                          im_patch_token=pt, im_start_token=st, im_end_token=en)
 
 
 def _weights(meta):
-    ocfg = O.LlavaCfg(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=320, model_max_length=256)
+    ocfg = O.LlavaCfg(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=325, model_max_length=256)
     W = {k: v for k, v in O.make_weights(ocfg, seed=3).items() if "vision_tower" not in k and "mm_projector" not in k}
     W.update(OO.make_resampler_weights(512, meta["kv_dim"], meta["num_query"]))
     return W

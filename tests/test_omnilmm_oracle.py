@@ -13,7 +13,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "omnilmm_tiny.pt")
 
 
 def _cfg():
-    return O.LlavaCfg(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=320, model_max_length=256)
+    return O.LlavaCfg(hidden=512, layers=2, heads=4, kv_heads=2, ffn=768, vocab=325, model_max_length=256)
 
 
 def _weights(cfg, meta):
