@@ -183,6 +183,13 @@ static int check_shape(const GemmShape& g, const char* who) {
   return 0;
 }
 
+// RV_GEMM_MI16 (default 1): the 16x16x32-MFMA main loop of the 64-deep-A NN kernel (gemm.hpp "MI16"); 0 = 32x32x16
+static int nn_mi16() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RV_GEMM_MI16"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 // NN GEMM with one of the SwiGLU epilogues: the 64-deep-A kernel when K allows, else the 32-deep one
 template <class Epi>
 static int launch_nn_epi(const GemmShape& g, const Epi& epi, hipStream_t st) {
@@ -190,10 +197,13 @@ static int launch_nn_epi(const GemmShape& g, const Epi& epi, hipStream_t st) {
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_nn_256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
     hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<Epi, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
     attr_done = true;
   }
   const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
-  if (g.K % 64 == 0 && g.K >= 512)
+  if (g.K % 64 == 0 && g.K >= 512 && nn_mi16())
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<Epi, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES, st, g, epi);
+  else if (g.K % 64 == 0 && g.K >= 512)
     hipLaunchKernelGGL((gemm_nn_a64_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES, st, g, epi);
   else
     hipLaunchKernelGGL((gemm_nn_256_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G2_LDS_BYTES, st, g, epi);
@@ -273,12 +283,16 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_nn_256_kernel<EpiStore>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
     hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
     const char* e = getenv("RV_GEMM_NN_A64");
     if (e) use_a64 = atoi(e);
     attr_done = true;
   }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
-  if (use_a64 && K % 64 == 0 && K >= 512)
+  if (use_a64 && K % 64 == 0 && K >= 512 && nn_mi16())
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  else if (use_a64 && K % 64 == 0 && K >= 512)
     hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
                        (hipStream_t)stream, g, epi);
   else

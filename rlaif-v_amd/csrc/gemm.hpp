@@ -910,6 +910,40 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 16x16x32 MFMA variant ("MI16").  profiles/r02_mfma_shape_power_probe.log: under the package power cap a pure
+// v_mfma_f32_16x16x32_bf16 loop sustains 1953 TFLOP/s at 2.03 GHz, v_mfma_f32_32x32x16_bf16 1750 at 1.85 GHz: the small
+// shape touches half as many accumulator registers per flop, and these GEMMs are power-bound.
+// The main loop is the same schedule with 32 MFMAs of 4 passes per phase instead of 16 of 8; the epilogues still see the
+// 32x32 accumulator layout - acc16_block_to_acc32() moves a 64 x 64 block of the wave's tile from
+//     16x16 tiles:  lane l, register j of tile (t_m, t_n)  <->  m = 16 t_m + (l & 15),  n = 16 t_n + 4 (l >> 4) + j
+// to  32x32 tiles:  lane L, register r of tile (T_m, T_n)  <->  m = 32 T_m + (L & 31),  n = 32 T_n + (r & 3) + 8 (r >> 2) + 4 (L >> 5)
+// i.e. target (L, r) = source tile (2 T_m + ((L >> 4) & 1), 2 T_n + (r >> 3)), lane (L & 15) | ((L >> 5) << 4) | (((r >> 2) & 1) << 5),
+// register r & 3: two ds_bpermute + one select per register, 256 per wave per output tile (~1 % of a K = 4096 tile).
+// ---------------------------------------------------------------------------------------------
+// (element access through a helper: __builtin_bit_cast(int, vec[j]) on a vector-element lvalue reads element 0 for every j
+//  with this hipcc - seen as 64 instead of 256 ds_bpermute in the ISA and as "every 4 columns equal" on the GPU)
+__device__ __forceinline__ int acc16_elem_bits(const f32x4_t& v, int j) {
+  const float f = j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+  return __builtin_bit_cast(int, f);
+}
+__device__ __forceinline__ void acc16_block_to_acc32(const f32x4_t (&a)[4][4], f32x16_t (&out)[2][2], int lane) {
+  const int base = (lane & 15) | ((lane >> 5) << 4);
+  const bool odd = (lane >> 4) & 1;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int src_lane = base | (((r >> 2) & 1) << 5);
+        const int v0 = __builtin_amdgcn_ds_bpermute(src_lane << 2, acc16_elem_bits(a[2 * tm][2 * tn + (r >> 3)], r & 3));
+        const int v1 = __builtin_amdgcn_ds_bpermute(src_lane << 2, acc16_elem_bits(a[2 * tm + 1][2 * tn + (r >> 3)], r & 3));
+        out[tm][tn][r] = __builtin_bit_cast(float, odd ? v1 : v0);
+      }
+}
+
 // =============================================================================================
 // NN GEMM with FULL-LINE fetches on BOTH operands ("A64"): as gemm_nn_256_kernel, but the A operand is staged in
 // 64-deep tiles - one LDS-DMA piece = 8 rows x 128 B, a whole cache line per row - held in a 3-stage ring of its own
@@ -932,7 +966,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
 // EXT: second contraction segment (A2 slices / B2 [K2][N], K2 % 64 == 0: the fused LoRA form).  The steady loop only
 // covers phases whose fetches lie in the main segment; the few phases around the seam and the adapter's own K2/32
 // phases run in the generic form (addresses rebuilt on the fly, full drain per phase).
-template <class Epi, bool EXT = false>
+template <class Epi, bool EXT = false, bool MI16 = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const smA = smem;
@@ -968,7 +1002,10 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 2 + (lane >> 5);
     const int c = lane & 31;
-    const int col = (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3);
+    // MI16: k rows 8..15 and 24..31 additionally swap the two 32-byte halves of every 64-byte block, so that the two
+    // 16-lane groups of a transposing read (k rows 8 apart, same 16 columns) hit disjoint banks
+    const int slot = MI16 ? ((c & 3) ^ (((r >> 3) & 1) << 1)) : (c & 3);
+    const int col = (((c >> 2) ^ (r & 3)) << 5) + (slot << 3);
     b_src[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
   }
   const uint32_t a_piece0 = (uint32_t)(wave * 4) * 1024u, b_piece0 = (uint32_t)(wave * 2) * 1024u;
@@ -993,13 +1030,31 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
 #pragma unroll
   for (int t = 0; t < 2; ++t) q_blk[t] = lane_part + (uint32_t)((((wn * 2 + t) ^ (s16 >> 2))) << 6);
 
-  f32x16_t acc[4][2];
+  // MI16 fragments: A tile t_m (16 rows): row wm*128 + 16 t_m + s16, 16-byte chunk 4h + g4 of the 64-deep row;
+  // B tile t_n (16 columns): k rows 8 g4 + (s16 >> 2) (+4 for the second read of the pair), 64-byte block wn*2 + (t_n >> 1),
+  // half (t_n & 1) ^ (g4 & 1), 8-byte chunk s16 & 3: the transposing read hands lane s16 of the group column s16, 4 k values
+  const uint32_t a16_pre = (uint32_t)((wm * 128 + s16) * 128) + (uint32_t)((g4 ^ (s16 >> 1)) << 4);
+  uint32_t q16[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int t = 0; t < 4; ++t)
+    q16[t] = (uint32_t)((8 * g4 + (s16 >> 2)) * 512) + (uint32_t)(((wn * 2 + (t >> 1)) ^ (s16 >> 2)) << 6) +
+             (uint32_t)((((t & 1) ^ (g4 & 1)) << 5) + 8 * (s16 & 3));
+
+  f32x16_t acc[MI16 ? 1 : 4][2];
+  f32x4_t acc16[MI16 ? 8 : 1][4];
+  if (MI16) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < 4; ++j) acc16[MI16 ? i : 0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[MI16 ? 0 : i][j][r] = 0.f;
+  }
 
   const int nt1 = g.K / G2_BK;                          // 32-deep phases of the main segment (even)
   const int nt = nt1 + (EXT ? g.K2 / G2_BK : 0);        // + the second segment
@@ -1015,7 +1070,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   };
   auto b_tile_src = [&](int t, int i) -> const bf16_t* {          // piece i (0..1) of B tile t
     const int r = (wave * 2 + i) * 2 + (lane >> 5), c = lane & 31;
-    const int col = min(n0 + (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3), g.N - 8);
+    const int slot = MI16 ? ((c & 3) ^ (((r >> 3) & 1) << 1)) : (c & 3);
+    const int col = min(n0 + (((c >> 2) ^ (r & 3)) << 5) + (slot << 3), g.N - 8);
     if (EXT && t >= nt1) return g.B2 + ((long)(t - nt1) * G2_BK + r) * g.ldb2 + col;
     return g.B + ((long)t * G2_BK + r) * ldb + col;
   };
@@ -1058,17 +1114,24 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
     const uint8_t* stA = smA + ((p >> 1) % 3) * G4_A_STAGE;
     const uint32_t stB = lds_addr_of(smB + (p % 4) * G4_B_STAGE);
     const uint32_t hx = (uint32_t)h << 6;
-    bf16x8_t af[2][4], bfr[2][2];
+    bf16x8_t af[2][4], bfr[2][2];           // MI16 views: af16[t_m] = af[t_m >> 2][t_m & 3], bfr16[t_n] = bfr[t_n >> 1][t_n & 1]
+    if (MI16) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const uint32_t a0 = stB + q_blk[t];
+      for (int t = 0; t < 4; ++t) bfr[t >> 1][t & 1] = ds_tr16_pair_asm(stB + q16[t], 0, 2048);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) bfr[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
+      for (int t = 0; t < 8; ++t) af[t >> 2][t & 3] = *(const bf16x8_t*)(stA + (a16_pre ^ hx) + t * 2048);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t a0 = stB + q_blk[t];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bfr[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[ks][t] = *(const bf16x8_t*)(stA + (a_pre[ks] ^ hx) + t * 4096);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) af[ks][t] = *(const bf16x8_t*)(stA + (a_pre[ks] ^ hx) + t * 4096);
     if (MODE == 1) {
       if (p == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // prologue: only B tile 2 may still be in flight
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1081,14 +1144,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
     __builtin_amdgcn_sched_barrier(0);
     if (RV_GEMM_PRIO_NN == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
-          const int k = (ks * 4 + tm) * 2 + tn;
-          if ((k & 3) == RV_GEMM_DMA_SLOT) {
+    for (int kk = 0; kk < (MI16 ? 32 : 16); ++kk) {
+          if (MI16) {
+            const int tm = kk >> 2, tn = kk & 3;
+            acc16[MI16 ? tm : 0][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn >> 1][tn & 1], af[tm >> 2][tm & 3],
+                                                                            acc16[MI16 ? tm : 0][tn], 0, 0, 0);
+          } else {
+            const int ks = kk >> 3, tm = (kk >> 1) & 3, tn = kk & 1;
+            acc[MI16 ? 0 : tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[MI16 ? 0 : tm][tn], 0, 0, 0);
+          }
+          const int k = MI16 ? (kk >> 1) : kk;                       // DMA slots: every 4th (MI16: 8th) MFMA
+          if ((k & 3) == RV_GEMM_DMA_SLOT && (!MI16 || (kk & 1) == 1)) {
             const int j = k >> 2;                                  // 0: A, 1: B, 2: A, 3: B
             __builtin_amdgcn_sched_barrier(0);
             if (MODE == 1) {
@@ -1101,7 +1167,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
+    }
     if (RV_GEMM_PRIO_NN == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1122,8 +1188,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   for (; p < nt; ++p) phase(p, p & 1, I0{}, I0{});
   if (wm == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count
 
-  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
-  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
+  if (MI16) {
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm) {
+      f32x16_t blk[2][2];
+      acc16_block_to_acc32(*reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[MI16 ? 4 * hm : 0]), blk, lane);
+      epi.apply(blk, m0 + wm * 128 + hm * 64, n0 + wn * 64, lane, g.M, g.N);
+    }
+  } else {
+    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
+    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[MI16 ? 0 : 2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
