@@ -54,6 +54,13 @@ static int launch_gemm256x64(const GemmShape& g, const Epi& epi, hipStream_t st)
   return 0;
 }
 
+// RV_GEMM_MI16 (default 1): the 16x16x32-MFMA main loops of the 64-deep-A NN kernel and the TN kernel (gemm.hpp "MI16"); 0 = 32x32x16
+static int nn_mi16() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RV_GEMM_MI16"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 static int g_tn_dist = 3;   // prefetch distance of the TN kernel (RV_GEMM_TN_DIST = 3 | 4; measured equal, 3 = 128 KiB LDS)
 
 template <class Epi, int DIST>
@@ -63,11 +70,16 @@ static int launch_gemm_tn_d(const bf16_t* P, long ldp, const bf16_t* Q, long ldq
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_tn_256_kernel<Epi, DIST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_tn_256_kernel<Epi, DIST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   const int tiles_i = (I + 255) / 256, tiles_j = (J + 255) / 256;
-  hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST>), dim3(tiles_i * tiles_j, splits), dim3(G2_THREADS), LDS, st, P,
-                     ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride, g_group);
+  if (nn_mi16())
+    hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST, true>), dim3(tiles_i * tiles_j, splits), dim3(G2_THREADS), LDS, st, P,
+                       ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride, g_group);
+  else
+    hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST>), dim3(tiles_i * tiles_j, splits), dim3(G2_THREADS), LDS, st, P,
+                       ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride, g_group);
   RV_CHECK_LAUNCH();
   return 0;
 }
@@ -181,13 +193,6 @@ static int check_shape(const GemmShape& g, const char* who) {
   if (((uintptr_t)g.A | (uintptr_t)g.B) & 15) { rv_set_error("GEMM: A/B must be 16-byte aligned"); return 1; }
   (void)who;
   return 0;
-}
-
-// RV_GEMM_MI16 (default 1): the 16x16x32-MFMA main loop of the 64-deep-A NN kernel (gemm.hpp "MI16"); 0 = 32x32x16
-static int nn_mi16() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RV_GEMM_MI16"); v = e ? atoi(e) : 1; }
-  return v;
 }
 
 // NN GEMM with one of the SwiGLU epilogues: the 64-deep-A kernel when K allows, else the 32-deep one
@@ -351,12 +356,16 @@ int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_nn_256_kernel<EpiStore, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
     hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
     const char* e = getenv("RV_GEMM_NN_A64");
     if (e) use_a64 = atoi(e);
     attr_done = true;
   }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
-  if (use_a64 && K % 64 == 0 && K2 % 64 == 0 && K >= 512)
+  if (use_a64 && K % 64 == 0 && K2 % 64 == 0 && K >= 512 && nn_mi16())
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, true, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  else if (use_a64 && K % 64 == 0 && K2 % 64 == 0 && K >= 512)
     hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
                        (hipStream_t)stream, g, epi);
   else

@@ -551,9 +551,42 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256x64_kernel(GemmShape
 // read hit 4 different quarters of the 256-byte bank row); applied on the DMA source address.
 // Rows r >= R of the last tile are redirected to a zero row (zero_row: >= 512 zero bytes in HBM).
 // =============================================================================================
+// ---------------------------------------------------------------------------------------------
+// 16x16x32 MFMA variant ("MI16").  profiles/r02_mfma_shape_power_probe.log: under the package power cap a pure
+// v_mfma_f32_16x16x32_bf16 loop sustains 1953 TFLOP/s at 2.03 GHz, v_mfma_f32_32x32x16_bf16 1750 at 1.85 GHz: the small
+// shape touches half as many accumulator registers per flop, and these GEMMs are power-bound (DESIGN.md section 5).
+// The main loop is the same schedule with 32 MFMAs of 4 passes per phase instead of 16 of 8; the epilogues still see the
+// 32x32 accumulator layout - acc16_block_to_acc32() moves a 64 x 64 block of the wave's tile from
+//     16x16 tiles:  lane l, register j of tile (t_m, t_n)  <->  m = 16 t_m + (l & 15),  n = 16 t_n + 4 (l >> 4) + j
+// to  32x32 tiles:  lane L, register r of tile (T_m, T_n)  <->  m = 32 T_m + (L & 31),  n = 32 T_n + (r & 3) + 8 (r >> 2) + 4 (L >> 5)
+// i.e. target (L, r) = source tile (2 T_m + ((L >> 4) & 1), 2 T_n + (r >> 3)), lane (L & 15) | ((L >> 5) << 4) | (((r >> 2) & 1) << 5),
+// register r & 3: two ds_bpermute + one select per register, 256 per wave per output tile (~1 % of a K = 4096 tile).
+// ---------------------------------------------------------------------------------------------
+// (element access through a helper: __builtin_bit_cast(int, vec[j]) on a vector-element lvalue reads element 0 for every j
+//  with this hipcc - seen as 64 instead of 256 ds_bpermute in the ISA and as "every 4 columns equal" on the GPU)
+__device__ __forceinline__ int acc16_elem_bits(const f32x4_t& v, int j) {
+  const float f = j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+  return __builtin_bit_cast(int, f);
+}
+__device__ __forceinline__ void acc16_block_to_acc32(const f32x4_t (&a)[4][4], f32x16_t (&out)[2][2], int lane) {
+  const int base = (lane & 15) | ((lane >> 5) << 4);
+  const bool odd = (lane >> 4) & 1;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int src_lane = base | (((r >> 2) & 1) << 5);
+        const int v0 = __builtin_amdgcn_ds_bpermute(src_lane << 2, acc16_elem_bits(a[2 * tm][2 * tn + (r >> 3)], r & 3));
+        const int v1 = __builtin_amdgcn_ds_bpermute(src_lane << 2, acc16_elem_bits(a[2 * tm + 1][2 * tn + (r >> 3)], r & 3));
+        out[tm][tn][r] = __builtin_bit_cast(float, odd ? v1 : v0);
+      }
+}
+
 __device__ bf16_t g_zero_row[256];   // 512 zero bytes: DMA source for contraction rows beyond R
 
-template <class Epi, int DIST = 3>
+template <class Epi, int DIST = 3, bool MI16 = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t* __restrict__ P, long ldp,
                                                                     const bf16_t* __restrict__ Q, long ldq, int R,
                                                                     int I, int J, Epi epi, int r_chunk,
@@ -590,7 +623,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   // source column (elements) of LDS chunk c = lane&31 of row r: 64-byte block (c>>2) ^ (r&3), 16-byte slot c&3
   auto src_col = [&](int r, int base, int limit) {
     const int c = lane & 31;
-    const int col = (((c >> 2) ^ (r & 3)) << 5) + ((c & 3) << 3);
+    // MI16: rows 8..15 / 24..31 swap the 32-byte halves of every 64-byte block (see gemm_nn_a64_kernel)
+    const int slot = MI16 ? ((c & 3) ^ (((r >> 3) & 1) << 1)) : (c & 3);
+    const int col = (((c >> 2) ^ (r & 3)) << 5) + (slot << 3);
     return min(base + col, limit - 8);
   };
   const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
@@ -624,13 +659,31 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
 #pragma unroll
   for (int t = 0; t < 4; ++t) p_blk[t] = lane_part + (uint32_t)((((wi * 4 + t) ^ (s16 >> 2))) << 6);
 
-  f32x16_t acc[4][2];
+  // MI16 fragments (16x16x32 MFMAs): contraction rows 8 g4 + (s16 >> 2) (+4), 16 columns = half (t & 1) of 64-byte block t >> 1
+  const uint32_t lane16 = (uint32_t)((8 * g4 + (s16 >> 2)) * 512 + 8 * (s16 & 3));
+  uint32_t q16[4], p16[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int t = 0; t < 4; ++t)
+    q16[t] = lane16 + 16384u + (uint32_t)(((wj * 2 + (t >> 1)) ^ (s16 >> 2)) << 6) + (uint32_t)(((t & 1) ^ (g4 & 1)) << 5);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int t = 0; t < 8; ++t)
+    p16[t] = lane16 + (uint32_t)(((wi * 4 + (t >> 1)) ^ (s16 >> 2)) << 6) + (uint32_t)(((t & 1) ^ (g4 & 1)) << 5);
+
+  f32x16_t acc[MI16 ? 1 : 4][2];
+  f32x4_t acc16[MI16 ? 8 : 1][4];
+  if (MI16) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc16[MI16 ? i : 0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[MI16 ? 0 : i][j][r] = 0.f;
+  }
 
   const int nt = (R + 31) / 32;
   issue(0);
@@ -670,19 +723,26 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   auto tile = [&](const int p, auto steady_c) {
     constexpr bool STEADY = decltype(steady_c)::value;
     const uint8_t* st = smem + (p % NST) * G2_STAGE_BYTES;
-    bf16x8_t qf[2][2], pf[2][4];
+    bf16x8_t qf[2][2], pf[2][4];            // MI16 views: qf16[t] = qf[t >> 1][t & 1], pf16[t] = pf[t >> 2][t & 3]
     const uint32_t sta = lds_addr_of(st);
+    if (MI16) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const uint32_t a0 = sta + q_blk[t];
+      for (int t = 0; t < 4; ++t) qf[t >> 1][t & 1] = ds_tr16_pair_asm(sta + q16[t], 0, 2048);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) qf[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
-    }
+      for (int t = 0; t < 8; ++t) pf[t >> 2][t & 3] = ds_tr16_pair_asm(sta + p16[t], 0, 2048);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint32_t a0 = sta + p_blk[t];
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t a0 = sta + q_blk[t];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) pf[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
+        for (int ks = 0; ks < 2; ++ks) qf[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t a0 = sta + p_blk[t];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) pf[ks][t] = ds_tr16_pair_asm(a0, ks * 8192, ks * 8192 + 2048);
+      }
     }
     {
       const int newer = STEADY ? DIST - 2 : min(DIST - 2, nt - 2 - p);   // tiles p+2 .. p+DIST-1 (p+DIST comes after this wait)
@@ -697,20 +757,23 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
     if (RV_GEMM_PRIO_TN == 0) __builtin_amdgcn_s_setprio(1);
     const bool dma = (p + DIST < nt);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks][tj], pf[ks][ti], acc[ti][tj], 0, 0, 0);
-          const int k = (ks * 4 + ti) * 2 + tj;
-          if ((k & 3) == RV_GEMM_DMA_SLOT) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (STEADY) issue_piece_run(p + DIST, k >> 2);
-            else if (dma) issue_piece(p + DIST, k >> 2);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+    for (int kk = 0; kk < (MI16 ? 32 : 16); ++kk) {
+      if (MI16) {
+        const int ti = kk >> 2, tj = kk & 3;
+        acc16[MI16 ? ti : 0][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[tj >> 1][tj & 1], pf[ti >> 2][ti & 3],
+                                                                        acc16[MI16 ? ti : 0][tj], 0, 0, 0);
+      } else {
+        const int ks = kk >> 3, ti = (kk >> 1) & 3, tj = kk & 1;
+        acc[MI16 ? 0 : ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks][tj], pf[ks][ti], acc[MI16 ? 0 : ti][tj], 0, 0, 0);
+      }
+      const int k = MI16 ? (kk >> 1) : kk;                       // DMA slots: every 4th (MI16: 8th) MFMA
+      if ((k & 3) == RV_GEMM_DMA_SLOT && (!MI16 || (kk & 1) == 1)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (STEADY) issue_piece_run(p + DIST, k >> 2);
+        else if (dma) issue_piece(p + DIST, k >> 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     if (RV_GEMM_PRIO_TN == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -726,8 +789,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t
   }
   if (wi == 0) __builtin_amdgcn_s_barrier();
 
-  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), i0 + wi * 128, j0 + wj * 64, lane, I, J);
-  epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), i0 + wi * 128 + 64, j0 + wj * 64, lane, I, J);
+  if (MI16) {
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm) {
+      f32x16_t blk[2][2];
+      acc16_block_to_acc32(*reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[MI16 ? 4 * hm : 0]), blk, lane);
+      epi.apply(blk, i0 + wi * 128 + hm * 64, j0 + wj * 64, lane, I, J);
+    }
+  } else {
+    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), i0 + wi * 128, j0 + wj * 64, lane, I, J);
+    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[MI16 ? 0 : 2]), i0 + wi * 128 + 64, j0 + wj * 64, lane, I, J);
+  }
 }
 
 // =============================================================================================
@@ -910,39 +982,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
   epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// 16x16x32 MFMA variant ("MI16").  profiles/r02_mfma_shape_power_probe.log: under the package power cap a pure
-// v_mfma_f32_16x16x32_bf16 loop sustains 1953 TFLOP/s at 2.03 GHz, v_mfma_f32_32x32x16_bf16 1750 at 1.85 GHz: the small
-// shape touches half as many accumulator registers per flop, and these GEMMs are power-bound (DESIGN.md section 5).
-// The main loop is the same schedule with 32 MFMAs of 4 passes per phase instead of 16 of 8; the epilogues still see the
-// 32x32 accumulator layout - acc16_block_to_acc32() moves a 64 x 64 block of the wave's tile from
-//     16x16 tiles:  lane l, register j of tile (t_m, t_n)  <->  m = 16 t_m + (l & 15),  n = 16 t_n + 4 (l >> 4) + j
-// to  32x32 tiles:  lane L, register r of tile (T_m, T_n)  <->  m = 32 T_m + (L & 31),  n = 32 T_n + (r & 3) + 8 (r >> 2) + 4 (L >> 5)
-// i.e. target (L, r) = source tile (2 T_m + ((L >> 4) & 1), 2 T_n + (r >> 3)), lane (L & 15) | ((L >> 5) << 4) | (((r >> 2) & 1) << 5),
-// register r & 3: two ds_bpermute + one select per register, 256 per wave per output tile (~1 % of a K = 4096 tile).
-// ---------------------------------------------------------------------------------------------
-// (element access through a helper: __builtin_bit_cast(int, vec[j]) on a vector-element lvalue reads element 0 for every j
-//  with this hipcc - seen as 64 instead of 256 ds_bpermute in the ISA and as "every 4 columns equal" on the GPU)
-__device__ __forceinline__ int acc16_elem_bits(const f32x4_t& v, int j) {
-  const float f = j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
-  return __builtin_bit_cast(int, f);
-}
-__device__ __forceinline__ void acc16_block_to_acc32(const f32x4_t (&a)[4][4], f32x16_t (&out)[2][2], int lane) {
-  const int base = (lane & 15) | ((lane >> 5) << 4);
-  const bool odd = (lane >> 4) & 1;
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int src_lane = base | (((r >> 2) & 1) << 5);
-        const int v0 = __builtin_amdgcn_ds_bpermute(src_lane << 2, acc16_elem_bits(a[2 * tm][2 * tn + (r >> 3)], r & 3));
-        const int v1 = __builtin_amdgcn_ds_bpermute(src_lane << 2, acc16_elem_bits(a[2 * tm + 1][2 * tn + (r >> 3)], r & 3));
-        out[tm][tn][r] = __builtin_bit_cast(float, odd ? v1 : v0);
-      }
-}
 
 // =============================================================================================
 // NN GEMM with FULL-LINE fetches on BOTH operands ("A64"): as gemm_nn_256_kernel, but the A operand is staged in
