@@ -568,7 +568,15 @@ __device__ __forceinline__ int acc16_elem_bits(const f32x4_t& v, int j) {
   const float f = j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
   return __builtin_bit_cast(int, f);
 }
+// Two lane-swap instructions per register pair instead: with a = tile row bit, p / q = source lane bits 4 / 5 the move is the
+// rotation (a -> lane bit 4, p -> lane bit 5, q -> register bit 2):
+//   v_permlane16_swap(S[a=0], S[a=1])  exchanges the register bit a with lane bit 4  (odd 16-lane rows of the first operand <->
+//                                      even rows of the second): Y[p] holds a in lane bit 4;
+//   v_permlane32_swap(Y[0], Y[1])      exchanges the register bit p with lane bit 5  (upper half of the first <-> lower half of
+//                                      the second): Z[q] holds p in lane bit 5;   target register r = 8 b + 4 q + j.
+// 128 VALU swaps per wave per output tile (RV_GEMM_MI16_BPERMUTE: the ds_bpermute form above, 256 + 128 selects).
 __device__ __forceinline__ void acc16_block_to_acc32(const f32x4_t (&a)[4][4], f32x16_t (&out)[2][2], int lane) {
+#ifdef RV_GEMM_MI16_BPERMUTE
   const int base = (lane & 15) | ((lane >> 5) << 4);
   const bool odd = (lane >> 4) & 1;
 #pragma unroll
@@ -582,6 +590,25 @@ __device__ __forceinline__ void acc16_block_to_acc32(const f32x4_t (&a)[4][4], f
         const int v1 = __builtin_amdgcn_ds_bpermute(src_lane << 2, acc16_elem_bits(a[2 * tm + 1][2 * tn + (r >> 3)], r & 3));
         out[tm][tn][r] = __builtin_bit_cast(float, odd ? v1 : v0);
       }
+#else
+  (void)lane;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned s0 = (unsigned)acc16_elem_bits(a[2 * tm][2 * tn + b], j);
+          const unsigned s1 = (unsigned)acc16_elem_bits(a[2 * tm + 1][2 * tn + b], j);
+          const u32x2_t y = __builtin_amdgcn_permlane16_swap(s0, s1, false, false);
+          const u32x2_t z = __builtin_amdgcn_permlane32_swap(y[0], y[1], false, false);
+          out[tm][tn][8 * b + j] = __builtin_bit_cast(float, (unsigned)z[0]);
+          out[tm][tn][8 * b + 4 + j] = __builtin_bit_cast(float, (unsigned)z[1]);
+        }
+#endif
 }
 
 __device__ bf16_t g_zero_row[256];   // 512 zero bytes: DMA source for contraction rows beyond R
