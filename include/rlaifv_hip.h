@@ -25,6 +25,10 @@ extern "C" {
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
+/* A/B and test knob: 1 (default, also RV_GEMM_MI16) = the NN-A64 / fused-LoRA NN / TN main loops issue 16x16x32 MFMAs
+ * (more flops per joule under the package power cap, profiles/r02_mfma_shape_power_probe.log); 0 = the 32x32x16 loops.
+ * Same results to fp32 accumulation order. */
+int rv_set_gemm_mi16(int on);
 /* GEMM kernel selection: -1 = auto (default), 0 = 128x128x64 register-staged, 1 = 128x128x64 global_load_lds,
  * 2 = 256x256x32 ping-pong (two wave groups alternating MFMA / load segments). */
 int rv_set_gemm_variant(int variant);

@@ -55,10 +55,10 @@ static int launch_gemm256x64(const GemmShape& g, const Epi& epi, hipStream_t st)
 }
 
 // RV_GEMM_MI16 (default 1): the 16x16x32-MFMA main loops of the 64-deep-A NN kernel and the TN kernel (gemm.hpp "MI16"); 0 = 32x32x16
+static int g_mi16 = -1;
 static int nn_mi16() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RV_GEMM_MI16"); v = e ? atoi(e) : 1; }
-  return v;
+  if (g_mi16 < 0) { const char* e = getenv("RV_GEMM_MI16"); g_mi16 = e ? atoi(e) : 1; }
+  return g_mi16;
 }
 
 static int g_tn_dist = 3;   // prefetch distance of the TN kernel (RV_GEMM_TN_DIST = 3 | 4; measured equal, 3 = 128 KiB LDS)
@@ -227,6 +227,11 @@ int rv_set_gemm_variant(int variant) {
 }
 
 int rv_abi_version(void) { return RV_ABI_VERSION; }
+
+int rv_set_gemm_mi16(int on) {
+  g_mi16 = on ? 1 : 0;
+  return 0;
+}
 
 int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* bias, const void* residual, long ldr, int act, float alpha, int variant,

@@ -211,6 +211,28 @@ def test_gemm_nn(ops, M, N, K):
     assert torch.equal(ops.gemm_nn(a, b), out)
 
 
+def test_gemm_mfma_shape_variants_agree(ops):
+    """The 16x16x32-MFMA main loops (default) and the 32x32x16 loops (rv_set_gemm_mi16(0)) of the NN-A64 and TN kernels
+    compute the same products: both against fp32 torch, and against each other to bf16 rounding of the output."""
+    from rlaif_v_amd import hip
+    dev = _dev()
+    a, b = rnd(3000, 1024, seed=61, dev=dev), rnd(1024, 1536, seed=62, dev=dev)
+    p, q = rnd(5000, 768, seed=63, dev=dev), rnd(5000, 1280, seed=64, dev=dev)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            hip.lib().call("rv_set_gemm_mi16", mode)
+            outs[mode] = (ops.gemm_nn(a, b), ops.gemm_tn(p, q))
+    finally:
+        hip.lib().call("rv_set_gemm_mi16", 1)
+    for mode in (1, 0):
+        close(outs[mode][0], a.float() @ b.float(), what=f"gemm_nn mi16={mode}")
+        close(outs[mode][1], p.float().t() @ q.float(), what=f"gemm_tn mi16={mode}")
+    for x, y in zip(outs[1], outs[0]):
+        d = (x.float() - y.float()).abs().max().item()
+        assert d <= 2.0 ** -7 * y.float().abs().max().item(), d       # one bf16 ulp of the largest magnitude
+
+
 def test_gemm_f32_out(ops):
     dev = _dev()
     a, b = rnd(190, 128, seed=9, dev=dev), rnd(260, 128, seed=10, dev=dev)

@@ -10,7 +10,7 @@ b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 
 VARIANTS = {
-    "p1": ("RV_GEMM_PRIO_MODE=1",), "p2": ("RV_GEMM_PRIO_MODE=2",),
+    "p0": ("RV_GEMM_PRIO_MODE=0",), "p1": ("RV_GEMM_PRIO_MODE=1",), "p2": ("RV_GEMM_PRIO_MODE=2",),
     "s0": ("RV_GEMM_DMA_SLOT=0",), "s2": ("RV_GEMM_DMA_SLOT=2",), "s3": ("RV_GEMM_DMA_SLOT=3",),
     "p1s3": ("RV_GEMM_PRIO_MODE=1", "RV_GEMM_DMA_SLOT=3"),
 }
