@@ -199,3 +199,73 @@ def make_omnilmm_batch(cfg: O.LlavaCfg, n_pairs: int, text_len: int, num_query: 
             "ref_win_logp": -20.0 - 5.0 * torch.rand(B, generator=gg), "ref_rej_logp": -20.0 - 5.0 * torch.rand(B, generator=gg),
             "ref_win_avg_logp": -2.0 - torch.rand(B, generator=gg), "ref_rej_avg_logp": -2.0 - torch.rand(B, generator=gg),
             "beta": 0.1}
+
+
+# --------------------------------------------------------------------------------------------
+# EVA02-E/14 tower: PARITY UNPINNED (timm is not vendored by the reference and absent offline).  A restatement of timm 0.9.10
+# models/eva.py ``Eva(use_post_norm=True)`` as documented in rlaif-v_amd/eva_tower.py, used only to check that the HIP tower
+# computes what its own docstring says.
+# --------------------------------------------------------------------------------------------
+
+def eva_weight_shapes(width: int, depth: int, heads: int, mlp: int, patch: int, pretrain_grid: int) -> Dict[str, Tuple[int, ...]]:
+    s = {"patch_embed.proj.weight": (width, 3, patch, patch), "patch_embed.proj.bias": (width,), "cls_token": (1, 1, width),
+         "pos_embed": (1, pretrain_grid * pretrain_grid + 1, width), "norm.weight": (width,), "norm.bias": (width,)}
+    for i in range(depth):
+        p = f"blocks.{i}."
+        s[p + "attn.qkv.weight"] = (3 * width, width)
+        s[p + "attn.q_bias"] = (width,)
+        s[p + "attn.v_bias"] = (width,)
+        s[p + "attn.proj.weight"] = (width, width)
+        s[p + "attn.proj.bias"] = (width,)
+        for n in ("norm1", "norm2"):
+            s[p + n + ".weight"] = (width,)
+            s[p + n + ".bias"] = (width,)
+        s[p + "mlp.fc1.weight"] = (mlp, width)
+        s[p + "mlp.fc1.bias"] = (mlp,)
+        s[p + "mlp.fc2.weight"] = (width, mlp)
+        s[p + "mlp.fc2.bias"] = (width,)
+    return s
+
+
+def make_eva_weights(width, depth, heads, mlp, patch, pretrain_grid, seed: int = 11) -> Dict[str, torch.Tensor]:
+    out = {}
+    for idx, (k, shp) in enumerate(eva_weight_shapes(width, depth, heads, mlp, patch, pretrain_grid).items()):
+        g = torch.Generator().manual_seed(seed * 1000003 + idx)
+        if "norm" in k and k.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith("bias"):
+            t = 0.02 * torch.randn(shp, generator=g)
+        else:
+            t = 0.03 * torch.randn(shp, generator=g)
+        out[k] = t.to(torch.bfloat16).to(torch.float32)
+    return out
+
+
+def eva_forward_features(pixels: torch.Tensor, W: Dict[str, torch.Tensor], heads: int, patch: int, pretrain_grid: int,
+                         blocks_used: int, eps: float = 1e-6) -> torch.Tensor:
+    """[B, 3, S, S] -> [B, (S/patch)^2, width]: forward_features with the prefix token stripped (omnilmm.py:107-119)."""
+    B = pixels.shape[0]
+    x = F.conv2d(pixels, W["patch_embed.proj.weight"], W["patch_embed.proj.bias"], stride=patch)
+    grid = x.shape[-1]
+    x = x.flatten(2).transpose(1, 2)
+    d = x.shape[-1]
+    hd = d // heads
+    pos = W["pos_embed"][0]
+    if grid != pretrain_grid:
+        g = pos[1:].reshape(1, pretrain_grid, pretrain_grid, d).permute(0, 3, 1, 2)
+        g = F.interpolate(g, size=(grid, grid), mode="bicubic", antialias=True, align_corners=False)
+        pos = torch.cat([pos[:1], g.permute(0, 2, 3, 1).reshape(grid * grid, d)], 0)
+    x = torch.cat([W["cls_token"].expand(B, -1, -1), x], 1) + pos
+    T = x.shape[1]
+    for i in range(blocks_used):
+        p = f"blocks.{i}."
+        bias = torch.cat([W[p + "attn.q_bias"], torch.zeros(d), W[p + "attn.v_bias"]])
+        qkv = F.linear(x, W[p + "attn.qkv.weight"], bias).view(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        att = torch.softmax((qkv[0] @ qkv[1].transpose(-1, -2)) * hd ** -0.5, dim=-1)
+        a = (att @ qkv[2]).transpose(1, 2).reshape(B, T, d)
+        a = F.linear(a, W[p + "attn.proj.weight"], W[p + "attn.proj.bias"])
+        x = x + F.layer_norm(a, (d,), W[p + "norm1.weight"], W[p + "norm1.bias"], eps)
+        m = F.linear(F.gelu(F.linear(x, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])), W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"])
+        x = x + F.layer_norm(m, (d,), W[p + "norm2.weight"], W[p + "norm2.bias"], eps)
+    x = F.layer_norm(x, (d,), W["norm.weight"], W["norm.bias"], eps)
+    return x[:, 1:]

@@ -12,8 +12,9 @@ the splice planner.  Pinned by tests/golden/omnilmm_tiny.pt (the reference's own
 The vision tower: timm's ``eva02_enormous_patch14_clip_224`` (omnilmm.py:31-43) is not vendored in the reference and timm is
 absent offline, so no oracle of it can be pinned; the tower is frozen in this path, its output is a pure function of the
 image, and ``images`` may therefore be handed over as PRECOMPUTED tower tokens [B, N, width] (3-D tensor) - which is also
-what one would cache across the 4 epochs of a run.  Pixel input needs a tower implementation registered through
-``set_vision_tower`` (any callable pixels -> [B, N, width]); none ships: "parity unpinned" would be the best it could claim.
+what one would cache across the 4 epochs of a run.  Pixel input goes through a tower registered with ``set_vision_tower``
+(any callable pixels -> [B, N, width]); ``rlaif-v_amd/eva_tower.py`` restates timm's EVA02-E/14 on the HIP kernels - PARITY
+UNPINNED (checked only against the author's own torch restatement, tests/test_omnilmm_gpu.py).
 """
 from __future__ import annotations
 

@@ -138,3 +138,37 @@ def test_pixel_input_without_tower_fails_loudly():
     model = OmniLMMDPOModel(_cfg(G["meta"]), with_optimizer=False)
     with pytest.raises(NotImplementedError):
         model.encode_images(torch.zeros(1, 3, 84, 84))
+
+
+def test_eva_tower_matches_its_restatement_and_feeds_the_model():
+    """EVA02 tower: PARITY UNPINNED (see rlaif-v_amd/eva_tower.py) - the HIP tower against the author's own torch restatement
+    (head dim 112 on the 128-wide kernels, post-norm blocks, resampled positions), then pixels -> tower -> resampler -> DPO
+    forward through ``set_vision_tower`` equals the same forward fed with the tower tokens."""
+    _need_gpu()
+    from rlaif_v_amd.eva_tower import EvaConfig, EvaTower
+    from rlaif_v_amd.omnilmm import OmniLMMDPOModel
+    G = torch.load(GOLD, weights_only=False)
+    meta, case = G["meta"], G["dpo"]
+    ec = EvaConfig(width=448, depth=4, heads=4, mlp=768, patch=14, pretrain_grid=3)     # head dim 112, as EVA02-E
+    We = OO.make_eva_weights(ec.width, ec.depth, ec.heads, ec.mlp, ec.patch, ec.pretrain_grid)
+    tower = EvaTower(ec)
+    tower.load_state_dict(We)
+    px = torch.randn(2, 3, 84, 84, generator=torch.Generator().manual_seed(2))        # 6 x 6 grid: positions are resampled from 3 x 3
+    ref = OO.eva_forward_features(px, We, ec.heads, ec.patch, ec.pretrain_grid, ec.blocks_used)
+    got = tower(px).float().cpu()
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    print(f"eva tower: max err / max |ref| = {err:.3e}, cosine {_cos(got, ref):.6f}")
+    assert got.shape == ref.shape == (2, 36, 448)
+    assert err <= 3e-2 and _cos(got, ref) >= 0.9995
+    # pixels in, through the model
+    cfg = _cfg(meta)
+    cfg.vision_width = 448
+    model = OmniLMMDPOModel(cfg, with_optimizer=False)
+    W = _weights(meta)
+    W.update(OO.make_resampler_weights(512, 448, meta["num_query"]))
+    model.load_state_dict(W)
+    model.set_vision_tower(tower)
+    b = case["batch"]
+    out_px = model.forward_logps(b["concatenated_input_ids"], b["concatenated_labels"], px, save_for_backward=False)
+    out_tok = model.forward_logps(b["concatenated_input_ids"], b["concatenated_labels"], tower(px), save_for_backward=False)
+    assert torch.equal(out_px.seq_logp, out_tok.seq_logp)
