@@ -203,6 +203,9 @@ struct TileDma {
 
 // ABL (experiment builds, -DRV_ATTN_EXPERIMENTS; results WRONG by construction): 1 = no softmax arithmetic, 2 = no PV MFMAs,
 // 3 = no QK^T MFMAs, 6 = no LDS-DMA of the following tiles.
+#ifndef RV_ATTN_FWD_PRIO
+#define RV_ATTN_FWD_PRIO 1     // 1 = s_setprio 1 in the QK^T / PV MFMA phases (measured -0.5..-3 % vs 0, profiles/r02_attn_fwd_prio.log); 2 = in the softmax section (+1..2 %)
+#endif
 template <int HD, bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                            int k_col0, int v_col0, bf16_t* __restrict__ out, long ldo,
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         zero16(sacc[0]);
         zero16(sacc[1]);
         bf16x8_t kA[4], kB[4];                       // element j of a group: half kt = j & 1, k step 2 g + (j >> 1)
+        if (RV_ATTN_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) kA[j] = ds_read_b128_asm(ka0 ^ (uint32_t)((j >> 1) << 5), (j & 1) * 32 * HD * 2);
 #pragma unroll
@@ -321,6 +325,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         // the softmax VALU work; afterwards the fragments of 16-key group kk+1 are in flight while group kk multiplies.
         const uint32_t vs_addr = lds_addr_of(Vs);
         bf16x8_t vA[ET], vB[ET];
+        if (RV_ATTN_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (RV_ATTN_FWD_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int e = 0; e < ET; ++e) vA[e] = tro.read(vs_addr, 0, e);
         float tmax = -INFINITY;                      // raw-score maximum (c > 0 keeps the order)
@@ -352,6 +358,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
         }
+        if (RV_ATTN_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (RV_ATTN_FWD_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const bf16x8_t pf = pack_frag(sacc[kk >> 1], (kk & 1) * 8);
@@ -372,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
           }
         }
       }
+      if (RV_ATTN_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
