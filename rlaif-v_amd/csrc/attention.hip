@@ -203,6 +203,9 @@ struct TileDma {
 
 // ABL (experiment builds, -DRV_ATTN_EXPERIMENTS; results WRONG by construction): 1 = no softmax arithmetic, 2 = no PV MFMAs,
 // 3 = no QK^T MFMAs, 6 = no LDS-DMA of the following tiles.
+#ifndef RV_DKV_S2
+#define RV_DKV_S2 1            // dK/dV kernel: S^T accumulated as two independent partial sums (0: one 8-deep dependent chain)
+#endif
 #ifndef RV_ATTN_FWD_PRIO
 #define RV_ATTN_FWD_PRIO 1     // 1 = s_setprio 1 in the QK^T / PV MFMA phases (measured -0.5..-3 % vs 0, profiles/r02_attn_fwd_prio.log); 2 = in the softmax section (+1..2 %)
 #endif
@@ -939,52 +942,46 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
         issue_tile(hq, tn, BUF ^ 1);
       } else {
         bf16x8_t fq[KS], fo[KS];                   // row fragments of the current sub-tile: Q[ks], dO[ks]
-        // batch 0 (k steps 0-3) of sub-tile 0; batch 1 follows behind the first wait
+        // Row fragments: batch 0 = the 8 Q fragments (all k steps), batch 1 = the 8 dO fragments.  The S^T chain runs on batch 0
+        // while batch 1 lands; the dP^T chain then runs UNDER the exp section, which needs S^T only (the first version
+        // interleaved the two chains step by step and started the exponentials after both: 8 MFMAs of exposed VALU wait).
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          fq[ks] = ds_read_b128_asm(rb[ks], SB);
-          fo[ks] = ds_read_b128_asm(rb[ks], SB + 16384);
-        }
+        for (int ks = 0; ks < KS; ++ks) fq[ks] = ds_read_b128_asm(rb[ks], SB);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           const int QO = SB + qt * 8192;           // immediate part of this sub-tile's row-fragment reads
           f32x16_t sacc, pacc;
-          // ---- S^T = Q K^T, dP^T = dO V^T : batch 1 in flight while batch 0 multiplies
 #pragma unroll
-          for (int ks = 4; ks < KS; ++ks) {
-            if (ABL == 5 && qt == 1) continue;
-            fq[ks] = ds_read_b128_asm(rb[ks], QO);
-            fo[ks] = ds_read_b128_asm(rb[ks], QO + 16384);
-          }
-          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // batch 0 landed (8 reads of batch 1 may be in flight)
+          for (int ks = 0; ks < KS; ++ks) fo[ks] = ds_read_b128_asm(rb[ks], QO + 16384);
+          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the Q fragments landed (the 8 dO reads may be in flight)
           __builtin_amdgcn_sched_barrier(0);
+          // ---- S^T = Q K^T as TWO partial sums (even / odd k steps): an MFMA that accumulates on the previous one's result
+          // cannot issue before that result exists (16 passes) while independent ones issue every 8 - a single 8-deep chain
+          // runs at half rate.  The halves are added inside the exponent's argument.
+          f32x16_t sacc2;
+#if RV_DKV_S2
           smfma_first<0>(sacc, fq[0]);
-          smfma_first<8>(pacc, fo[0]);
+          smfma_first<1>(sacc2, fq[1]);
           static_for<3>([&](auto ic) {
-            constexpr int ks = decltype(ic)::value + 1;
-            if (ABL == 3) { asm volatile("" ::"v"(fq[ks]), "v"(fo[ks])); return; }
+            constexpr int ks = 2 * (decltype(ic)::value + 1);
             smfma<ks>(sacc, fq[ks]);
-            smfma<8 + ks>(pacc, fo[ks]);
+            smfma<ks + 1>(sacc2, fq[ks + 1]);
           });
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // batch 1 landed
+#else
+          smfma_first<0>(sacc, fq[0]);
+          static_for<KS - 1>([&](auto ic) { smfma<decltype(ic)::value + 1>(sacc, fq[decltype(ic)::value + 1]); });
+          zero16(sacc2);
+#endif
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the dO fragments landed under the chain above
           __builtin_amdgcn_sched_barrier(0);
-          static_for<3>([&](auto ic) {
-            constexpr int ks = decltype(ic)::value + 4;
-            if (ABL == 3) { asm volatile("" ::"v"(fq[ks]), "v"(fo[ks])); return; }
-            smfma<ks>(sacc, fq[ks]);
-            smfma<8 + ks>(pacc, fo[ks]);
-          });
-          smfma_last2(sacc, fq[KS - 1], pacc, fo[KS - 1]);
-          // lse and delta of this lane's 16 queries (4 consecutive floats per accumulator row group): explicit reads
-          // issued AHEAD of the transposing reads - the exp section never waits for a fresh LDS round trip.  Two halves
-          // (rows groups 0-1, then 2-3) to keep the register footprint at 16.
-          f32x4_t lsev[2], delv[2];
+          // lse and delta of this lane's 16 queries (4 consecutive floats per accumulator row group), then the transposed
+          // fragments of the first 16 queries (independent of P / dS): all requested before the dP^T chain starts
+          f32x4_t lsev[4], delv[4];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < 4; ++j) {
             lsev[j] = ds_read_f32x4_asm(lh, SB + qt * 128 + j * 32);
             delv[j] = ds_read_f32x4_asm(lh, SB + 256 + qt * 128 + j * 32);
           }
-          // transposed fragments of the first 16 queries (independent of P / dS): latency hidden by the exp section
           bf16x8_t dotf0[ET], qtf0[ET], dotf1[ET], qtf1[ET];
           const int TO = SB + qt * 32 * 256;
 #pragma unroll
@@ -994,35 +991,49 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
             qtf0[e] = __builtin_shufflevector(ds_tr16_b64_asm(tb[0][e], TO), ds_tr16_b64_asm(tb[1][e], TO), 0, 1, 2, 3, 4, 5,
                                               6, 7);
           }
+          // ---- dP^T = dO V^T: the first three MFMAs also serve as the XDL-write -> VALU wait states of the S^T chain
+          // (>= 64 cycles pass before the third can issue); nothing that reads sacc may be scheduled above this fence
+          smfma_first<8>(pacc, fo[0]);
+          smfma<9>(pacc, fo[1]);
+          smfma<10>(pacc, fo[2]);
+          asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");   // lse / delta (the 8 oldest of 24 reads) landed
+          __builtin_amdgcn_sched_barrier(0);
           const int qsub = qs0 + qt * 32;                      // first query of this 32-row sub-tile
           const bool need_mask = (qsub + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qsub) ||
                                  (qsub + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
           if (need_mask) kmask.apply(sacc, qsub + 4 * half);
-          asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");   // first lse / delta half landed (the 16 transposing reads stay in flight)
+          // exponentials (S^T only), three per remaining dP^T MFMA; the fences pin the interleave
+          auto exps = [&](int r0, int r1) {
+#pragma unroll
+            for (int r = r0; r < r1; ++r)
+              sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r] + sacc2[r], c, -LOG2E * lsev[r >> 2][r & 3]));
+          };
+          exps(0, 3);
           __builtin_amdgcn_sched_barrier(0);
+          smfma<11>(pacc, fo[3]);
+          __builtin_amdgcn_sched_barrier(0);
+          exps(3, 6);
+          __builtin_amdgcn_sched_barrier(0);
+          smfma<12>(pacc, fo[4]);
+          __builtin_amdgcn_sched_barrier(0);
+          exps(6, 9);
+          __builtin_amdgcn_sched_barrier(0);
+          smfma<13>(pacc, fo[5]);
+          __builtin_amdgcn_sched_barrier(0);
+          exps(9, 12);
+          __builtin_amdgcn_sched_barrier(0);
+          smfma<14>(pacc, fo[6]);
+          __builtin_amdgcn_sched_barrier(0);
+          exps(12, 14);
+          __builtin_amdgcn_sched_barrier(0);
+          smfma<15>(pacc, fo[7]);
+          __builtin_amdgcn_sched_barrier(0);
+          exps(14, 16);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 15\n\ts_nop 3" : "+v"(pacc));      // XDL write -> VALU read wait states of the dP^T chain
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            if (ABL == 1) { asm volatile("" ::"v"(lsev[r >> 2]), "v"(delv[r >> 2])); continue; }
-            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -LOG2E * lsev[r >> 2][r & 3]));
-            sacc[r] = p;
-            pacc[r] = p * (pacc[r] - delv[r >> 2][r & 3]);
-          }
-          // second half: requested now (behind the transposing reads in the LDS queue), consumed after the first pack
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            lsev[j] = ds_read_f32x4_asm(lh, SB + qt * 128 + (j + 2) * 32);
-            delv[j] = ds_read_f32x4_asm(lh, SB + 256 + qt * 128 + (j + 2) * 32);
-          }
+          for (int r = 0; r < 16; ++r) pacc[r] = sacc[r] * (pacc[r] - delv[r >> 2][r & 3]);
           const bf16x8_t pf0 = pack_frag(sacc, 0), dsf0 = pack_frag(pacc, 0);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r = 8; r < 16; ++r) {
-            if (ABL == 1) { asm volatile("" ::"v"(lsev[(r >> 2) - 2]), "v"(delv[(r >> 2) - 2])); continue; }
-            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -LOG2E * lsev[(r >> 2) - 2][r & 3]));
-            sacc[r] = p;
-            pacc[r] = p * (pacc[r] - delv[(r >> 2) - 2][r & 3]);
-          }
           const bf16x8_t pf1 = pack_frag(sacc, 8), dsf1 = pack_frag(pacc, 8);
 #pragma unroll
           for (int e = 0; e < ET; ++e)
@@ -1046,11 +1057,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
             // both batches' worth of registers are free (their MFMAs were issued long ago): request batch 0 of the
             // second sub-tile now, its latency hides under the remaining dV / dK MFMAs
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              if (ABL == 5) continue;
-              fq[ks] = ds_read_b128_asm(rb[ks], SB + 8192);
-              fo[ks] = ds_read_b128_asm(rb[ks], SB + 8192 + 16384);
-            }
+            for (int ks = 0; ks < KS; ++ks) fq[ks] = ds_read_b128_asm(rb[ks], SB + 8192);
             asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // dotf1 landed (16 younger reads may be in flight)
           } else {
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // dotf1 landed
