@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 2
+#define RV_ABI_VERSION 3
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
@@ -141,10 +141,14 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
  * backward (hd = 128): O = the forward output (rv_attn_fwd's `out`), delta = [S, H, L] fp32 WORKSPACE: the dQ kernel fills
  * it with rowsum(dO * O) (what rv_attn_delta computes) on the fly and the dK/dV kernel reads it.  Writes dQ, dK, dV into
  * dqkv at the column offsets of qkv.  Deterministic (no atomics): one kernel per 128-query block for dQ, one per 128-key
- * block for dK/dV.  Packed rows: key tiles / query tiles that a whole block cannot see are never fetched. */
+ * block for dK/dV.  Packed rows: key tiles / query tiles that a whole block cannot see are never fetched.
+ * rope_cos / rope_sin (fp32 [positions][64], both NULL = off) + rope_pos (int32 [S * L] position of every row, NULL = row
+ * index inside its sequence): dQ and dK are written ALREADY rotated back (apply_rotary_pos_emb's autograd, HF
+ * modeling_llama.py) - the separate rv_rope_inplace(backward) pass over dqkv is not needed. */
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
                 const void* O, long ldo, const float* lse, float* delta, void* dqkv, long lddq, int S, int L, int H,
-                int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group, void* stream);
+                int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
+                const float* rope_cos, const float* rope_sin, const int* rope_pos, void* stream);
 int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
                   void* stream);
 

@@ -405,6 +405,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   }  // pass
 }
 
+// Inverse RoPE fused into the stores of dQ / dK (apply_rotary_pos_emb's autograd, HF modeling_llama: the half-split pairs
+// (i, i + 64) of a 128-wide head sit in accumulator tiles e and e + 2 at the same lane and register).  The values are first
+// rounded to bf16 - what the separate rv_rope_inplace(backward) pass used to read back - then rotated in fp32:
+//   dx1 = dy1 cos + dy2 sin,   dx2 = dy2 cos - dy1 sin.
+__device__ __forceinline__ void store_rope_bwd_pair(const f32x16_t& lo, const f32x16_t& hi, float scale, const float* cr,
+                                                    const float* sr, int e01, int half, bf16_t* head_base) {
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int i0 = e01 * 32 + rg * 8 + 4 * half;
+    const f32x4_t cc = *(const f32x4_t*)(cr + i0), ss = *(const f32x4_t*)(sr + i0);
+    float o1[4], o2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bf2f(f2bf(lo[rg * 4 + j] * scale)), b = bf2f(f2bf(hi[rg * 4 + j] * scale));
+      o1[j] = a * cc[j] + b * ss[j];
+      o2[j] = b * cc[j] - a * ss[j];
+    }
+    uint2 w;
+    w.x = pack2bf(o1[0], o1[1]);
+    w.y = pack2bf(o1[2], o1[3]);
+    *(uint2*)(head_base + i0) = w;
+    w.x = pack2bf(o2[0], o2[1]);
+    w.y = pack2bf(o2[2], o2[3]);
+    *(uint2*)(head_base + 64 + i0) = w;
+  }
+}
+
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                               int k_col0, int v_col0, const bf16_t* __restrict__ dO,
@@ -413,7 +440,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
                                                               float* __restrict__ delta,
                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
                                                               int nx, float scale, const int* __restrict__ seg_sh,
-                                                              const int* __restrict__ seg_e1, int kv_group) {
+                                                              const int* __restrict__ seg_e1, int kv_group,
+        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
   constexpr int HD = 128, KS = 8, ET = 4, TILE = 64 * HD * 2, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -567,15 +595,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 
     if (q < L) {
       bf16_t* op = dqkv + (tok0 + q) * lddq + q_col0 + h * HD;
+      if (rope_cos) {
+        const long pos = rope_pos ? rope_pos[tok0 + q] : q;
+        store_rope_bwd_pair(dq[0], dq[2], scale, rope_cos + pos * 64, rope_sin + pos * 64, 0, half, op);
+        store_rope_bwd_pair(dq[1], dq[3], scale, rope_cos + pos * 64, rope_sin + pos * 64, 1, half, op);
+      } else {
 #pragma unroll
-      for (int e = 0; e < ET; ++e)
+        for (int e = 0; e < ET; ++e)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          uint2 w;
-          w.x = pack2bf(dq[e][rg * 4 + 0] * scale, dq[e][rg * 4 + 1] * scale);
-          w.y = pack2bf(dq[e][rg * 4 + 2] * scale, dq[e][rg * 4 + 3] * scale);
-          *(uint2*)(op + e * 32 + rg * 8 + 4 * half) = w;
-        }
+          for (int rg = 0; rg < 4; ++rg) {
+            uint2 w;
+            w.x = pack2bf(dq[e][rg * 4 + 0] * scale, dq[e][rg * 4 + 1] * scale);
+            w.y = pack2bf(dq[e][rg * 4 + 2] * scale, dq[e][rg * 4 + 3] * scale);
+            *(uint2*)(op + e * 32 + rg * 8 + 4 * half) = w;
+          }
+      }
     }
   }  // pass
 }
@@ -602,7 +636,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
                                                                const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, long lddq, int L, int H,
                                                                int nx, float scale, const int* __restrict__ seg_sh,
-                                                               const int* __restrict__ seg_e1, int kv_group) {
+                                                               const int* __restrict__ seg_e1, int kv_group,
+        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
   // H = number of KEY/VALUE heads (the grid walks kv heads); the kv_group query heads h*G .. h*G+G-1 that share kv head h
   // are accumulated into the same dK / dV tile (grouped-query attention; kv_group = 1: plain multi-head attention)
   constexpr int HD = 128, KS = 8, ET = 4;
@@ -776,6 +811,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
     }  // query heads of the group
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
 
+    if (key < L && rope_cos) {
+      const long pos = rope_pos ? rope_pos[tok0 + key] : key;
+      bf16_t* kb = dqkv + (tok0 + key) * lddq + h * HD + k_col0;
+      store_rope_bwd_pair(dk[0], dk[2], scale, rope_cos + pos * 64, rope_sin + pos * 64, 0, half, kb);
+      store_rope_bwd_pair(dk[1], dk[3], scale, rope_cos + pos * 64, rope_sin + pos * 64, 1, half, kb);
+    }
     if (key < L) {
       bf16_t* kp = dqkv + (tok0 + key) * lddq + h * HD;
 #pragma unroll
@@ -783,9 +824,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           uint2 w;
-          w.x = pack2bf(dk[e][rg * 4 + 0] * scale, dk[e][rg * 4 + 1] * scale);
-          w.y = pack2bf(dk[e][rg * 4 + 2] * scale, dk[e][rg * 4 + 3] * scale);
-          *(uint2*)(kp + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
+          if (!rope_cos) {
+            w.x = pack2bf(dk[e][rg * 4 + 0] * scale, dk[e][rg * 4 + 1] * scale);
+            w.y = pack2bf(dk[e][rg * 4 + 2] * scale, dk[e][rg * 4 + 3] * scale);
+            *(uint2*)(kp + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
+          }
           w.x = pack2bf(dv[e][rg * 4 + 0], dv[e][rg * 4 + 1]);
           w.y = pack2bf(dv[e][rg * 4 + 2], dv[e][rg * 4 + 3]);
           *(uint2*)(kp + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
@@ -822,7 +865,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
                                                                const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, long lddq, int L, int H,
                                                                int nx, float scale, const int* __restrict__ seg_sh,
-                                                               const int* __restrict__ seg_e1, int kv_group) {
+                                                               const int* __restrict__ seg_e1, int kv_group,
+        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
   constexpr int HD = 128, KS = 8, ET = 4;
   constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64] = 0x8200
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1108,18 +1152,30 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
 
     bf16_t* kp_out = dqkv + (tok0 + keyc) * lddq + h * HD;
+    if (rope_cos) {       // dK leaves through the inverse rotation (pairs = tiles e, e + 2)
+      const long pos = rope_pos ? rope_pos[tok0 + keyc] : keyc;
+      static_for<2>([&](auto ic) {
+        constexpr int e = decltype(ic)::value;
+        f32x16_t lo, hi;
+        acc_read<e>(lo);
+        acc_read<e + 2>(hi);
+        if (key < L) store_rope_bwd_pair(lo, hi, scale, rope_cos + pos * 64, rope_sin + pos * 64, e, half, kp_out + k_col0);
+      });
+    }
     static_for<ET>([&](auto ic) {
       constexpr int e = decltype(ic)::value;
       f32x16_t dk_e, dv_e;
-      acc_read<e>(dk_e);
+      if (!rope_cos) acc_read<e>(dk_e);
       acc_read<4 + e>(dv_e);
       if (key < L) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           uint2 w;
-          w.x = pack2bf(dk_e[rg * 4 + 0] * scale, dk_e[rg * 4 + 1] * scale);
-          w.y = pack2bf(dk_e[rg * 4 + 2] * scale, dk_e[rg * 4 + 3] * scale);
-          *(uint2*)(kp_out + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
+          if (!rope_cos) {
+            w.x = pack2bf(dk_e[rg * 4 + 0] * scale, dk_e[rg * 4 + 1] * scale);
+            w.y = pack2bf(dk_e[rg * 4 + 2] * scale, dk_e[rg * 4 + 3] * scale);
+            *(uint2*)(kp_out + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
+          }
           w.x = pack2bf(dv_e[rg * 4 + 0], dv_e[rg * 4 + 1]);
           w.y = pack2bf(dv_e[rg * 4 + 2], dv_e[rg * 4 + 3]);
           *(uint2*)(kp_out + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
@@ -1181,8 +1237,9 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
                 const void* O, long ldo, const float* lse, float* delta, void* dqkv, long lddq, int S, int L, int H,
                 int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
-                void* stream) {
+                const float* rope_cos, const float* rope_sin, const int* rope_pos, void* stream) {
   RV_REQUIRE(hd == 128, "rv_attn_bwd: head dim must be 128");
+  RV_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), "rv_attn_bwd: rope_cos and rope_sin go together");
   RV_REQUIRE(O != nullptr && delta != nullptr && ldo % 8 == 0, "rv_attn_bwd: O (forward output) and the delta workspace are required");
   RV_REQUIRE(kv_group >= 1 && H % kv_group == 0, "rv_attn_bwd: kv_group must divide the number of query heads");
   RV_REQUIRE((seg_sh == nullptr) == (seg_e1 == nullptr), "rv_attn_bwd: seg_sh and seg_e1 go together");
@@ -1225,7 +1282,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   const int Hkv = H / kv_group;
   dim3 grid_kv(nxr * Hkv * S);
 #define BWD_HEAD (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo
-#define BWD_TAIL(HH) (bf16_t*)dqkv, lddq, L, HH, nx, scale, seg_sh, seg_e1, kv_group
+#define BWD_TAIL(HH) (bf16_t*)dqkv, lddq, L, HH, nx, scale, seg_sh, seg_e1, kv_group, rope_cos, rope_sin, rope_pos
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_HEAD, (const bf16_t*)O, ldo, lse, delta, BWD_TAIL(H));
     RV_CHECK_LAUNCH();

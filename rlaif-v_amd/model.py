@@ -354,6 +354,7 @@ class LlavaDPOModel:
         self.grad_ready_hook = None     # callable(name, start, end) fired when a slice of flat_g is final
         # compute the prefix shared by the chosen and rejected sequence of a pair once (splice.build_packed_plan)
         self.share_prefix = os.environ.get("RV_SHARE_PREFIX", "1") != "0"
+        self.fuse_rope_bwd = os.environ.get("RV_FUSE_ROPE_BWD", "1") != "0"
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -808,10 +809,12 @@ class LlavaDPOModel:
                                      dres=dx)
             del dxn2
             dattn = self._proj_bwd(dx_mid, c["attn"], c["t_o"], i, "o", drop_slot=1, xd=c["xd_o"])
+            # dQ / dK leave the attention backward already rotated back (RV_FUSE_ROPE_BWD=0: separate rv_rope_inplace pass)
             dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, d + cfg.kv_dim,
-                                seg=plan.seg, kv_group=cfg.kv_group)
+                                seg=plan.seg, kv_group=cfg.kv_group, rope=(cos, sin, plan.pos) if self.fuse_rope_bwd else None)
             del dattn
-            ops.rope_inplace(dqkv, cos, sin, L, H + cfg.n_kv_heads, hd, backward=True, pos=plan.pos)
+            if not self.fuse_rope_bwd:
+                ops.rope_inplace(dqkv, cos, sin, L, H + cfg.n_kv_heads, hd, backward=True, pos=plan.pos)
             xn = c["xn"] if c["xn"] is not None else \
                 ops.rmsnorm_fwd(c["x"], st.p(f"layers.{i}.ln1"), cfg.rms_eps, want_rstd=False)[0]
             c["xn"] = None

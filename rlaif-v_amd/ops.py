@@ -370,15 +370,17 @@ def attn_fwd(qkv: torch.Tensor, S: int, L: int, H: int, hd: int, causal: bool, q
 
 
 def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv: Optional[torch.Tensor] = None,
-             seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, kv_group: int = 1):
-    """Returns dqkv with dQ/dK/dV written at the qkv column offsets."""
+             seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, kv_group: int = 1, rope=None):
+    """Returns dqkv with dQ/dK/dV written at the qkv column offsets.  ``rope`` = (cos, sin, pos | None): dQ and dK come out
+    already rotated back (the backward of apply_rotary_pos_emb fused into the stores)."""
     _chk2d(qkv, "qkv"), _chk2d(o, "o"), _chk2d(do, "do")
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     delta = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)      # workspace: filled by the dQ kernel
     hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, do, do.stride(0), o, o.stride(0), lse, delta,
              dqkv, dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None,
-             seg[1] if seg else None, int(kv_group))
+             seg[1] if seg else None, int(kv_group), rope[0] if rope else None, rope[1] if rope else None,
+             rope[2] if rope else None)
     return dqkv
 
 

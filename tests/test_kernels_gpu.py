@@ -420,6 +420,33 @@ def test_attn_gqa_fwd_bwd(ops, H, G, causal, L):
     assert torch.equal(ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, causal, 0, kc, vc, kv_group=G), dqkv)
 
 
+@pytest.mark.parametrize("G,use_pos,dkv", [(1, False, 3), (1, True, 3), (2, True, 3), (1, True, 2)])
+def test_attn_bwd_fused_inverse_rope(ops, G, use_pos, dkv, monkeypatch):
+    """rv_attn_bwd with rope tables writes dQ / dK already rotated back: identical (to bf16 rounding of the fp32 rotation)
+    to the unfused rv_attn_bwd followed by rv_rope_inplace(backward); dV untouched.  Packed rows + position table + GQA."""
+    dev = _dev()
+    S, L, H, hd = 2, 333, 4, 128
+    Hkv = H // G
+    width = (H + 2 * Hkv) * hd
+    kc, vc = H * hd, (H + Hkv) * hd
+    qkv = rnd(S * L, width, seed=7, dev=dev, scale=0.7)
+    do = rnd(S * L, H * hd, seed=8, dev=dev)
+    sh = torch.tensor([130, 0], dtype=torch.int32, device=dev)
+    e1 = torch.tensor([260, 100], dtype=torch.int32, device=dev)
+    cos, sin = ops.rope_tables(512, hd, 10000.0, dev)
+    pos = (torch.randint(0, 512, (S * L,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(dev)) if use_pos else None
+    out, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, kc, vc, seg=(sh, e1), kv_group=G)
+    # RV_ATTN_DKV is read once per process: the version-2 dK/dV kernel is covered when the whole file runs with it set
+    ref = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, True, 0, kc, vc, seg=(sh, e1), kv_group=G)
+    ops.rope_inplace(ref, cos, sin, L, H + Hkv, hd, backward=True, pos=pos)
+    got = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, True, 0, kc, vc, seg=(sh, e1), kv_group=G, rope=(cos, sin, pos))
+    assert torch.equal(got[:, vc:], ref[:, vc:])
+    d = (got[:, :vc].float() - ref[:, :vc].float()).abs().max().item()
+    mag = ref[:, :vc].float().abs().max().item()
+    print(f"fused inverse rope G={G} pos={use_pos}: max |diff| {d:.3e} of {mag:.3e}")
+    assert d <= 2.0 ** -7 * mag                      # one bf16 ulp of the largest magnitude (fp32 contraction order)
+
+
 def _packed_mask(L, sh, e1, dev):
     i = torch.arange(L, device=dev)[:, None]
     j = torch.arange(L, device=dev)[None, :]
