@@ -358,6 +358,10 @@ def main():
                                 "traffic_note": "HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
                                                 f"WRITE_SIZE, separate passes (profiles/{traffic_file}); algorithmic "
                                                 "operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
+                                "power_capped_mfma_ceiling": {"tflops": 1953.0, "frac": g["tflops"] / 1953.0,
+                                                              "note": "pure register-operand v_mfma_f32_16x16x32_bf16 loop on all 256 CUs "
+                                                                      "under the 1400 W package cap (32x32x16: 1750): "
+                                                                      "profiles/r02_mfma_shape_power_probe.log"},
                                 "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
                                 "gemm_ms_per_step": g["total_ms"] / args.steps}
         if dp_probe is not None:
