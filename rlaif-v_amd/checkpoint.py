@@ -18,7 +18,23 @@ import torch
 
 
 def hf_config_dict(cfg) -> Dict:
-    """LlavaConfig (HF ``llava_llama``) fields of the checkpoint's config.json."""
+    """LlavaConfig (HF ``llava_llama``) fields of the checkpoint's config.json; for the OmniLMM branch the fields
+    ``OmniLMMModel.initialize_vision_modules`` writes into its Mistral config (omnilmm/model/omnilmm.py:76-80)."""
+    if getattr(cfg, "arch", "llava") == "omnilmm":
+        return {
+            "architectures": ["OmniLMMForCausalLM"], "model_type": "omnilmm",
+            "hidden_size": cfg.hidden, "intermediate_size": cfg.ffn, "num_hidden_layers": cfg.layers,
+            "num_attention_heads": cfg.heads, "num_key_value_heads": cfg.n_kv_heads, "vocab_size": cfg.vocab,
+            "rms_norm_eps": cfg.rms_eps, "rope_theta": cfg.rope_theta, "max_position_embeddings": 32768,
+            "sliding_window": 4096, "pad_token_id": cfg.pad_token_id, "bos_token_id": 1, "eos_token_id": 2,
+            "hidden_act": "silu", "torch_dtype": "bfloat16", "tie_word_embeddings": False, "use_cache": True,
+            "mm_vision_tower": "eva02_enormous_patch14_clip_224.laion2b_plus", "use_mm_proj": True,
+            "num_query": cfg.num_query, "image_size": cfg.image_size,
+            # not HF fields: what this package needs to rebuild the model without a tokenizer
+            "rlaifv_vision_width": cfg.vision_width, "rlaifv_im_patch_token": cfg.im_patch_token,
+            "rlaifv_im_start_token": cfg.im_start_token, "rlaifv_im_end_token": cfg.im_end_token,
+            "tokenizer_model_max_length": cfg.model_max_length,
+        }
     return {
         "architectures": ["LlavaLlamaForCausalLM"], "model_type": "llava_llama",
         "hidden_size": cfg.hidden, "intermediate_size": cfg.ffn, "num_hidden_layers": cfg.layers,
@@ -36,6 +52,17 @@ def hf_config_dict(cfg) -> Dict:
 
 def config_from_hf(d: Dict, **overrides):
     from .model import LlavaConfig
+    if d.get("model_type") == "omnilmm":
+        from .omnilmm import OmniLMMConfig
+        kw = dict(hidden=d["hidden_size"], layers=d["num_hidden_layers"], heads=d["num_attention_heads"],
+                  kv_heads=d.get("num_key_value_heads", d["num_attention_heads"]), ffn=d["intermediate_size"],
+                  vocab=d["vocab_size"], rms_eps=d.get("rms_norm_eps", 1e-5), rope_theta=d.get("rope_theta", 10000.0),
+                  num_query=d.get("num_query", 64), image_size=d.get("image_size", 448),
+                  vision_width=d.get("rlaifv_vision_width", 1792), im_patch_token=d.get("rlaifv_im_patch_token", 32000),
+                  im_start_token=d.get("rlaifv_im_start_token", 32001), im_end_token=d.get("rlaifv_im_end_token", 32002),
+                  model_max_length=d.get("tokenizer_model_max_length", 2048), pad_token_id=d.get("pad_token_id") or 0)
+        kw.update(overrides)
+        return OmniLMMConfig(**kw)
     kw = dict(hidden=d["hidden_size"], layers=d["num_hidden_layers"], heads=d["num_attention_heads"],
               ffn=d["intermediate_size"], vocab=d["vocab_size"], rms_eps=d.get("rms_norm_eps", 1e-5),
               rope_theta=d.get("rope_theta", 10000.0), clip_hidden=d.get("mm_hidden_size", 1024),

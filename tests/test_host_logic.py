@@ -441,3 +441,21 @@ def test_omnilmm_splice_plan_matches_oracle_bit_exact():
     bad[0, int(torch.where(ids[0] == tokens[2])[0][0])] = 7
     with pytest.raises(ValueError):
         sp.build_splice_plan(bad, lab, 16, 3, 256, splicer=sp.make_omnilmm_splicer(*tokens))
+
+
+def test_omnilmm_config_json_round_trip():
+    """config.json of an OmniLMM checkpoint: the fields the reference's initialize_vision_modules sets (omnilmm.py:76-80)
+    plus what is needed to rebuild OmniLMMConfig; a Mistral sliding window of 4096 is written because the path never
+    exceeds it (model_max_length 2048)."""
+    import importlib
+    ck = importlib.import_module("rlaif-v_amd.checkpoint")
+    om = importlib.import_module("rlaif-v_amd.omnilmm")
+    cfg = om.OmniLMMConfig(layers=3, model_max_length=1024, im_patch_token=32003)
+    d = ck.hf_config_dict(cfg)
+    assert d["model_type"] == "omnilmm" and d["num_query"] == 64 and d["image_size"] == 448 and d["vocab_size"] == 32009
+    assert d["num_key_value_heads"] == 8 and d["intermediate_size"] == 14336
+    back = ck.config_from_hf(d)
+    assert isinstance(back, om.OmniLMMConfig) and back == cfg and back.vocab_padded == 32064
+    # the LLaVA dictionary is untouched
+    lc = importlib.import_module("rlaif-v_amd.model").LlavaConfig()
+    assert ck.hf_config_dict(lc)["model_type"] == "llava_llama" and ck.config_from_hf(ck.hf_config_dict(lc)) == lc
