@@ -193,6 +193,18 @@ def from_pretrained(ckpt_dir: str, device="cuda:0", with_optimizer: bool = True,
     if vt_dir is not None:
         vt = load_state_dict_dir(vt_dir)
         sd.update({("model.vision_tower.vision_tower." + k if not k.startswith("model.") else k): v for k, v in vt.items()})
+    if getattr(cfg, "arch", "llava") == "omnilmm":
+        # OmniLMMForCausalLM checkpoint: language model + model.resampler.*; tower tensors (model.vision_tower.*, timm names)
+        # go to the unpinned EvaTower when they are present, else the caller feeds precomputed tower tokens
+        from .omnilmm import OmniLMMDPOModel
+        model = OmniLMMDPOModel(cfg, device=device, with_optimizer=with_optimizer, lora=lora)
+        model.load_state_dict(sd)
+        if any(k.startswith("model.vision_tower.blocks.") for k in sd):
+            from .eva_tower import EvaConfig, EvaTower
+            tower = EvaTower(EvaConfig(width=cfg.vision_width), device=device)
+            tower.load_state_dict(sd, prefix="model.vision_tower.")
+            model.set_vision_tower(tower)
+        return model
     model = LlavaDPOModel(cfg, device=device, with_optimizer=with_optimizer, lora=lora)
     model.load_state_dict(sd)
     return model
