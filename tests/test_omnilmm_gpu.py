@@ -172,3 +172,58 @@ def test_eva_tower_matches_its_restatement_and_feeds_the_model():
     out_px = model.forward_logps(b["concatenated_input_ids"], b["concatenated_labels"], px, save_for_backward=False)
     out_tok = model.forward_logps(b["concatenated_input_ids"], b["concatenated_labels"], tower(px), save_for_backward=False)
     assert torch.equal(out_px.seq_logp, out_tok.seq_logp)
+
+
+def test_omnilmm_full_width_shallow_vs_oracle(monkeypatch):
+    """OmniLMM-12B widths (Mistral-7B: d 4096, f 14336, 32 query / 8 key-value heads, the 32009-token vocabulary; Resampler
+    64 queries x 1024 tower tokens of width 1792, 32 heads) with 2 decoder layers against the fp32 CPU oracle (itself pinned
+    by the reference-class golden at small widths): the production tile shapes of the resampler and of the GQA decoder."""
+    _need_gpu()
+    from rlaif_v_amd.omnilmm import OmniLMMConfig, OmniLMMDPOModel
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    monkeypatch.setenv("SFT_weight", "0.0")
+    monkeypatch.setenv("DPO_weight", "1.0")
+    cfg = OmniLMMConfig(layers=2, model_max_length=256)
+    ocfg = O.LlavaCfg(hidden=cfg.hidden, layers=2, heads=cfg.heads, kv_heads=cfg.n_kv_heads, ffn=cfg.ffn, vocab=cfg.vocab,
+                      model_max_length=256)
+    W = {k: v for k, v in O.make_weights(ocfg, seed=9).items() if "vision_tower" not in k and "mm_projector" not in k}
+    W.update(OO.make_resampler_weights(cfg.hidden, cfg.vision_width, cfg.num_query, seed=4))
+    tokens = (cfg.im_patch_token, cfg.im_start_token, cfg.im_end_token)
+    lo_cfg = O.LlavaCfg(hidden=cfg.hidden, layers=2, heads=cfg.heads, kv_heads=cfg.n_kv_heads, ffn=cfg.ffn, vocab=32000)
+    batch = OO.make_omnilmm_batch(lo_cfg, 1, 112, cfg.num_query, tokens, seed=6)          # text ids below 32000
+    tok = torch.randn(1, 1024, cfg.vision_width, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).float()
+    # oracle first: the reference log-probs of the batch are then placed next to the policy's so that the DPO loss is O(1)
+    # (random weights give sequence log-probs near -300; against the generator's -20 the loss would be exp(-28))
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    ref = OO.omnilmm_step_forward(batch, tok, Wg, ocfg, cfg.hidden // 128, tokens)
+    batch["ref_win_logp"] = ref["policy_win_logp"].detach() - 3.0
+    batch["ref_rej_logp"] = ref["policy_rej_logp"].detach() + 2.0
+    losses, _, _ = O.dpo_loss(ref["policy_win_logp"], ref["policy_rej_logp"], batch["ref_win_logp"], batch["ref_rej_logp"],
+                              batch["beta"])
+    ref_loss = losses.mean()
+    model = OmniLMMDPOModel(cfg)
+    model.load_state_dict(W)
+    tr = LLaVA15DPOTrainer(model=model, args=TrainingArguments())
+    b = dict(batch)
+    b["images"] = tok
+    loss = tr.compute_loss(model, b)
+    out = model.last_out
+    err = (out.seq_logp.cpu() - ref["log_prob"].detach()).abs()
+    print("omnilmm full-width shallow: seq logp", out.seq_logp.tolist(), "ref", ref["log_prob"].tolist(), "loss", float(loss),
+          float(ref_loss))
+    assert bool((err <= 1e-3 * ref["log_prob"].detach().abs()).all())
+    # the loss is a function of beta * (difference of two sums of magnitude ~300): log-prob errors of 1e-4 RELATIVE (0.03 and
+    # 0.05 absolute, measured) move it by ~1e-3 absolute = 2.3e-3 relative; the 1e-3 bar is asserted on the log-probs above
+    assert abs(float(loss) - float(ref_loss)) <= 5e-3 * abs(float(ref_loss))
+    ref_loss.backward()
+    model.backward(out, model.last_coef)
+    grads = model.grads_state_dict()
+    for k in ("model.layers.1.mlp.gate_proj.weight", "model.layers.0.self_attn.k_proj.weight", "lm_head.weight",
+              "model.resampler.kv_proj.weight", "model.resampler.attn.in_proj_weight", "model.resampler.query",
+              "model.resampler.proj", "model.resampler.ln_kv.weight"):
+        g, r = grads[k], Wg[k].grad
+        c = _cos(g, r)
+        rel = abs(float(g.double().norm()) - float(r.double().norm())) / float(r.double().norm())
+        print(f"  grad {k}: cos {c:.5f} norm rel err {rel:.3e}")
+        assert c >= 0.99 and rel <= 5e-2, (k, c, rel)
