@@ -50,73 +50,84 @@ def flops_per_pair(L: int, layers: int = 32, d: int = 4096, f: int = 11008, V: i
 
 
 class GemmTimer:
-    """HIP-event timing of every rv_gemm_nt_bf16 launch on the stream it is launched on."""
+    """HIP-event timing of EVERY MFMA GEMM launch of the step (plain NN / NT / TN, the fused-LoRA forms, the SwiGLU-epilogue
+    GEMMs and the fused LM-head log-prob kernels), on the stream each is launched on.  Per launch: algorithmic flops
+    2 x M x N x K and operand + result bytes; ``summary()`` gives the total and a per-kernel-class table."""
+
+    # ops function -> (class label, flops(args), bytes(args)); a, b ... are the positional tensor arguments
+    SPECS = {
+        "gemm_nt": ("nt", lambda a, b, *r, **k: 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
+                    lambda a, b, *r, **k: 2.0 * (a.numel() + b.numel() + a.shape[0] * b.shape[0])),
+        "gemm_nn": ("nn", lambda a, b, *r, **k: 2.0 * a.shape[0] * b.shape[1] * a.shape[1],
+                    lambda a, b, *r, **k: 2.0 * (a.numel() + b.numel() + a.shape[0] * b.shape[1])),
+        "gemm_tn": ("tn", lambda p, q, *r, **k: 2.0 * p.shape[0] * p.shape[1] * q.shape[1],
+                    lambda p, q, *r, **k: 2.0 * (p.numel() + q.numel() + p.shape[1] * q.shape[1])),
+        "gemm_tn_skinny": ("tn_splitk", lambda p, q, *r, **k: 2.0 * p.shape[0] * p.shape[1] * q.shape[1],
+                           lambda p, q, *r, **k: 2.0 * (p.numel() + q.numel() + p.shape[1] * q.shape[1])),
+        "gemm_nt_lora": ("nt_lora", lambda a, b, a2, b2, *r, **k: 2.0 * a.shape[0] * b.shape[0] * (a.shape[1] + b2.shape[1]),
+                         lambda a, b, a2, b2, *r, **k: 2.0 * (a.numel() + b.numel() + b2.numel() + a.shape[0] * b2.shape[1]
+                                                               + a.shape[0] * b.shape[0])),
+        "gemm_nn_lora": ("nn_lora", lambda a, b, a2, b2, *r, **k: 2.0 * a.shape[0] * b.shape[1] * (a.shape[1] + b2.shape[0]),
+                         lambda a, b, a2, b2, *r, **k: 2.0 * (a.numel() + b.numel() + b2.numel() + a.shape[0] * b2.shape[0]
+                                                               + a.shape[0] * b.shape[1])),
+        "gemm_nt_dropout": ("nt_dropout", lambda a, b, *r, **k: 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
+                            lambda a, b, *r, **k: 2.0 * (a.numel() + b.numel() + 2 * a.shape[0] * b.shape[0])),
+        # gate|up projection with SwiGLU in the epilogue: writes gu [M, 2f] and act [M, f]
+        "linear_swiglu": ("nn_swiglu", lambda x, wT, *r, **k: 2.0 * x.shape[0] * wT.shape[1] * x.shape[1],
+                          lambda x, wT, *r, **k: 2.0 * (x.numel() + wT.numel() + 1.5 * x.shape[0] * wT.shape[1])),
+        # down projection's input gradient with SwiGLU backward in the epilogue: reads gu [M, 2f], writes dgu [M, 2f]
+        "linear_swiglu_bwd": ("nn_swiglu_bwd", lambda dy, w, gu, *r, **k: 2.0 * dy.shape[0] * w.shape[1] * dy.shape[1],
+                              lambda dy, w, gu, *r, **k: 2.0 * (dy.numel() + w.numel() + 2 * gu.numel())),
+        # fused LM head: logits tile -> online log-softmax statistics (forward), recomputed tile -> dlogits (backward)
+        "lmhead_logp_fwd": ("lmhead_fwd", lambda h, w, tgt, n, *r, **k: 2.0 * n * w.shape[0] * w.shape[1],
+                            lambda h, w, tgt, n, *r, **k: 2.0 * (n * w.shape[1] + w.numel())),
+        "lmhead_logp_bwd": ("lmhead_bwd", lambda h, w, tgt, lse, coef, n, *r, **k: 2.0 * n * w.shape[0] * w.shape[1],
+                            lambda h, w, tgt, lse, coef, n, *r, **k: 2.0 * (n * w.shape[1] + w.numel() + n * w.shape[0])),
+    }
 
     def __init__(self):
-        self.records = []
+        self.records = []          # (start event, end event, flops, bytes, class label)
+        self._orig = {}
 
     def install(self):
-        from rlaif_v_amd import ops, hip
-        orig = ops.gemm_nt
+        from rlaif_v_amd import ops
         recs = self.records
+        for fname, (label, flops, nbytes) in self.SPECS.items():
+            orig = getattr(ops, fname)
+            self._orig[fname] = orig
 
-        def timed(a, b, out=None, **kw):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig(a, b, out=out, **kw)
-            e.record()
-            recs.append((s, e, 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
-                         2.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[0])))
-            return r
+            def timed(*a, _orig=orig, _label=label, _flops=flops, _bytes=nbytes, **kw):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = _orig(*a, **kw)
+                e.record()
+                recs.append((s, e, _flops(*a, **kw), _bytes(*a, **kw), _label))
+                return r
 
-        ops.gemm_nt = timed
-        orig_tn = ops.gemm_tn
+            setattr(ops, fname, timed)
 
-        def timed_tn(p, q, out=None, **kw):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_tn(p, q, out=out, **kw)
-            e.record()
-            recs.append((s, e, 2.0 * p.shape[0] * p.shape[1] * q.shape[1],
-                         2.0 * (p.shape[0] * p.shape[1] + q.shape[0] * q.shape[1] + p.shape[1] * q.shape[1])))
-            return r
-
-        ops.gemm_tn = timed_tn
-        orig_lora = ops.gemm_nt_lora
-
-        def timed_lora(a, b, a2, b2, **kw):       # fused LoRA GEMM: K + K2 contraction steps
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_lora(a, b, a2, b2, **kw)
-            e.record()
-            kk = a.shape[1] + b2.shape[1]
-            recs.append((s, e, 2.0 * a.shape[0] * b.shape[0] * kk,
-                         2.0 * (a.shape[0] * kk + b.shape[0] * kk + a.shape[0] * b.shape[0])))
-            return r
-
-        ops.gemm_nt_lora = timed_lora
-        orig_nn = ops.gemm_nn
-
-        def timed_nn(a, b, out=None, **kw):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_nn(a, b, out=out, **kw)
-            e.record()
-            recs.append((s, e, 2.0 * a.shape[0] * b.shape[1] * a.shape[1],
-                         2.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[1])))
-            return r
-
-        ops.gemm_nn = timed_nn
-        self._restore = lambda: (setattr(ops, "gemm_nt", orig), setattr(ops, "gemm_tn", orig_tn),
-                                 setattr(ops, "gemm_nt_lora", orig_lora), setattr(ops, "gemm_nn", orig_nn))
+    def _restore(self):
+        from rlaif_v_amd import ops
+        for fname, orig in self._orig.items():
+            setattr(ops, fname, orig)
+        self._orig = {}
 
     def summary(self):
-        tot_ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        tot_fl = sum(r[2] for r in self.records)
-        alg_bytes = sum(r[3] for r in self.records)
+        by = {}
+        for s, e, fl, nb, label in self.records:
+            d = by.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, alg_bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["alg_bytes"] += nb
+        for d in by.values():
+            d["tflops"] = d["flops"] / max(d["ms"], 1e-9) / 1e9
+            d["avg_ms"] = d["ms"] / max(d["launches"], 1)
+        tot_ms = sum(d["ms"] for d in by.values())
+        tot_fl = sum(d["flops"] for d in by.values())
         n = len(self.records)
         return dict(launches=n, total_ms=tot_ms, avg_ms=tot_ms / max(n, 1), tflops=tot_fl / max(tot_ms, 1e-9) / 1e9,
-                    flops=tot_fl, alg_bytes=alg_bytes)
+                    flops=tot_fl, alg_bytes=sum(d["alg_bytes"] for d in by.values()), by_kernel=by)
 
 
 def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
@@ -147,6 +158,13 @@ def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
                host_cores=cores, step_s_extrapolated=step,
                phases_s={k[:-2]: round(v, 2) for k, v in full.items()},
                measured_s={str(d): {k[:-2]: round(v, 2) for k, v in res[d].items()} for d in res})
+    try:       # the SAME step measured once at all 32 layers on a GPU box's host (tools/full_depth_parity.py; no extrapolation)
+        with open(os.path.join(REPO, "profiles", "r03_parity_full_depth.json")) as fh:
+            fd = json.load(fh)["cpu_step_measured"]
+        out["full_depth_measured"] = dict(fd, unit="pairs/s", value=fd["pairs_per_s"], source="profiles/r03_parity_full_depth.json",
+                                          extrapolation_over_measured=step / fd["step_s"])
+    except Exception:
+        pass
     try:
         with open(os.path.join(REPO, "profiles", "r02_cpu_reference_baseline.json")) as fh:
             ref = json.load(fh)
@@ -197,7 +215,9 @@ def main():
                          "64 image tokens; the frozen EVA02 tower is NOT run - synthetic precomputed tower tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dp-probe", action="store_true",
-                    help="skip the 1-rank RCCL probe (steps re-timed with the bucketed all-reduce forced on)")
+                    help="skip the single-GPU data-parallel probe (steps re-timed with a concurrent reduce-copy kernel on a "
+                         "side stream at every gradient bucket)")
+    ap.add_argument("--dp-probe-wgs", default="4,8,16", help="stand-in workgroup counts (= RCCL channels) to sweep")
     ap.add_argument("--no-gemm-timer", action="store_true")
     args = ap.parse_args()
 
@@ -211,7 +231,7 @@ def main():
     dev = torch.device("cuda", local)
 
     from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel, LoraConfig
-    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments, GradReducer as GradReducerBase
     from rlaif_v_amd.data import SyntheticPreferenceDataset, DataCollatorForDPODataset
     import torch.distributed as dist
 
@@ -271,36 +291,76 @@ def main():
 
     dp_probe = None
     if world == 1 and not args.no_dp_probe:
-        # the data-parallel exchange on ONE rank: the same bucketed all-reduce schedule the N-GPU run issues (RCCL kernels
-        # on RCCL's stream, overlapped with backward, optimizer waits on the handles), forced on in a 1-rank group.  It
-        # prices the launch / stream / CU-sharing side of the overlap; the xGMI transfer itself needs >= 2 GPUs.
+        # The data-parallel exchange priced on ONE GPU.  No xGMI peer exists here and a 1-rank RCCL all-reduce never launches
+        # a device kernel, so the communication side is played by a REAL concurrent kernel: at every on_bucket_ready of the
+        # N-GPU schedule (same bucket merging, same 13.5 GB per step) `n_wg` persistent workgroups on a side stream stream
+        # dst = grad + peer (two loads + one store per element: the receive-reduce-send of a ring step; 40 GB of HBM traffic
+        # per step vs ~59 GB for a real 8-rank ring) while backward keeps launching 256-workgroup GEMMs; the optimizer
+        # waits for the side stream.  n_wg = 8 is the channel cap dist.init_process_group_from_env offers (RV_RCCL_CHANNELS).
         try:
-            os.environ.update(RANK="0", LOCAL_RANK=str(local), WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
-                              MASTER_PORT=str(_free_port()))
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            red = BucketedAllReduce(model.store.flat_g, force=True)
-            sent = []
-            _launch = red._launch
-            red._launch = lambda a, b: (sent.append(b - a), _launch(a, b))[1]
-            trainer.reducer, trainer._reduce_hook = red, red.on_bucket_ready
-            model.grad_ready_hook = trainer._bucket_ready
+            from rlaif_v_amd import ops as _ops
+
+            class StandInReducer(BucketedAllReduce):
+                def __init__(self, flat, n_wg):
+                    super().__init__(flat, force=True)
+                    self.n_wg, self.side = n_wg, torch.cuda.Stream(device=dev)
+                    self.peer = self.stage = None
+
+                def _launch(self, start, end):
+                    n = end - start
+                    if n <= 0:
+                        return
+                    if self.peer is None or self.peer.numel() < n:
+                        self.peer = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+                        self.stage = torch.empty(n, dtype=torch.bfloat16, device=dev)
+                    self.launched.append((start, end))
+                    self.side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(self.side):
+                        _ops.reduce_copy_persistent(self.flat[start:end], self.peer, self.stage, self.n_wg)
+
+                def finish(self):
+                    if self._pending is not None:
+                        self._launch(*self._pending)
+                        self._pending = None
+                    torch.cuda.current_stream(dev).wait_stream(self.side)
+                    done, self.launched = self.launched, []
+                    return done
+
             if not args.no_gemm_timer:
                 timer._restore()
-            one_step()
-            torch.cuda.synchronize()
-            sent.clear()
-            per_step = []
-            for _ in range(3):        # median of three: RCCL's lazy channel setup can land in any one of the first steps
-                t1 = time.perf_counter()
+
+            def timed_steps(n=3):
                 one_step()
                 torch.cuda.synchronize()
-                per_step.append((time.perf_counter() - t1) * 1e3)
-            ms_forced = sorted(per_step)[1]
-            dp_probe = dict(ms_per_step=ms_forced, ms_each=[round(x, 1) for x in per_step], collectives_per_step=len(sent) // 3,
-                            bytes_per_step=sum(sent) // 3 * model.store.flat_g.element_size())
-            dist.destroy_process_group()
+                per = []
+                for _ in range(n):
+                    t1 = time.perf_counter()
+                    one_step()
+                    torch.cuda.synchronize()
+                    per.append((time.perf_counter() - t1) * 1e3)
+                return sorted(per)[len(per) // 2], per
+
+            base_ms, base_each = timed_steps()            # same loop, no communication stand-in (and no GEMM event timers)
+            dp_probe = dict(kind="single-GPU stand-in: persistent reduce-copy workgroups on a side stream at every on_bucket_ready",
+                            baseline_ms_per_step=base_ms, baseline_ms_each=[round(x, 1) for x in base_each], sweep={})
+            for n_wg in [int(x) for x in args.dp_probe_wgs.split(",") if x]:
+                red = StandInReducer(model.store.flat_g, n_wg)
+                trainer.reducer, trainer._reduce_hook = red, red.on_bucket_ready
+                model.grad_ready_hook = trainer._bucket_ready
+                sent = []
+                _l = red._launch
+                red._launch = lambda a, b, _l=_l: (sent.append(b - a), _l(a, b))[1]
+                ms, each = timed_steps()
+                nb = len(sent) // 4
+                dp_probe["sweep"][str(n_wg)] = dict(ms_per_step=ms, ms_each=[round(x, 1) for x in each],
+                                                    exposed_ms_per_step=ms - base_ms, launches_per_step=nb,
+                                                    grad_bytes_per_step=sum(sent) // 4 * model.store.flat_g.element_size())
+                del red
+            trainer.reducer = GradReducerBase()
+            trainer._reduce_hook = None
+            model.grad_ready_hook = None
         except Exception as e:          # the probe must never cost the headline line
-            dp_probe = dict(error=repr(e)[:200])
+            dp_probe = dict(error=repr(e)[:300])
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -344,7 +404,7 @@ def main():
         if not args.no_gemm_timer:
             g = timer.summary()
             traffic, traffic_file = None, None
-            for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # newest committed PMC passes first
+            for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # newest committed PMC passes first
                 try:   # HBM bytes per GEMM launch (profiles/, separate rocprofv3 --pmc runs of this same command)
                     with open(os.path.join(REPO, "profiles", name)) as fh:
                         traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
@@ -352,12 +412,27 @@ def main():
                     break
                 except Exception:
                     pass
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nn_a64_kernel / gemm_tn_256_kernel (+ gemm_nn_256 / gemm_nt_256 for the shapes they serve): 256x256 ping-pong tiles; all rv_gemm_nn_bf16 + rv_gemm_tn_bf16 + rv_gemm_nt_bf16 launches",
+            KNAME = {"nn": "gemm_nn_a64_kernel<EpiStore> (rv_gemm_nn_bf16)", "tn": "gemm_tn_256_kernel (rv_gemm_tn_bf16)",
+                     "nt": "gemm_nt_256_kernel / gemm_nt_kernel (rv_gemm_nt_bf16)",
+                     "nn_swiglu": "gemm_nn_a64_kernel<EpiSwiGLU> (rv_gemm_nn_swiglu_bf16)",
+                     "nn_swiglu_bwd": "gemm_nn_a64_kernel<EpiSwiGLUBwd> (rv_gemm_nn_swiglu_bwd_bf16)",
+                     "lmhead_fwd": "gemm_nt_256_kernel<EpiLogpFwd> (rv_lmhead_logp_fwd)",
+                     "lmhead_bwd": "gemm_nt_256_kernel<EpiLogpBwd> (rv_lmhead_logp_bwd)"}
+            by = {k: dict(kernel=KNAME.get(k, k), launches=d["launches"], avg_launch_ms=d["avg_ms"], ms_per_step=d["ms"] / args.steps,
+                          achieved=d["tflops"], frac=d["tflops"] / PEAK_BF16_TFLOPS,
+                          alg_bytes_per_launch=d["alg_bytes"] / max(d["launches"], 1))
+                  for k, d in sorted(g["by_kernel"].items(), key=lambda kv: -kv[1]["ms"])}
+            dom = next(iter(by)) if by else None
+            line["roofline"] = {"bound": "mfma",
+                                "kernel": "ALL MFMA GEMM launches of the step (plain NN / TN / NT, SwiGLU-epilogue NN forward and "
+                                          "backward, fused LM-head log-prob forward and backward, fused-LoRA forms): 256x256 ping-pong tiles",
                                 "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                 "traffic_note": "HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
                                                 f"WRITE_SIZE, separate passes (profiles/{traffic_file}); algorithmic "
                                                 "operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
+                                "dominant": dict(by[dom], label=dom) if dom else None,
+                                "by_kernel": by,
                                 "power_capped_mfma_ceiling": {"tflops": 1953.0, "frac": g["tflops"] / 1953.0,
                                                               "note": "pure register-operand v_mfma_f32_16x16x32_bf16 loop on all 256 CUs "
                                                                       "under the 1400 W package cap (32x32x16: 1750): "
@@ -365,9 +440,7 @@ def main():
                                 "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
                                 "gemm_ms_per_step": g["total_ms"] / args.steps}
         if dp_probe is not None:
-            if "ms_per_step" in dp_probe:
-                dp_probe["exposed_ms_per_step"] = dp_probe["ms_per_step"] - ms_per_step
-            line["dp_overlap_probe_1rank"] = dp_probe
+            line["dp_standin_probe_1gpu"] = dp_probe
         if world == 1 and not args.no_cpu_baseline and not args.lora and not args.omnilmm:     # the CPU leg times the full-FT oracle step
             line["cpu_baseline"] = cpu_baseline()
     if world > 1:

@@ -232,6 +232,11 @@ int rv_adamw_step(void* p, float* master, float* m, float* v, const void* g, lon
  * gradients.  mode 0: acc = g;  1: acc += g;  2: g = bf16((acc + g) * scale)  (scale = 1 / accumulation steps). */
 int rv_grad_accum(float* acc, void* g, long n, int mode, float scale, void* stream);
 
+/* ---- measurement helper (bench.py's single-GPU data-parallel probe; replaces nothing in the reference): dst = a + b
+ *      (bf16, n elements) streamed by n_wg persistent 256-thread workgroups - the CU footprint of n_wg RCCL channels
+ *      doing the receive-reduce-send of a ring all-reduce step (script/zero2.json:16-22 is what the real exchange replaces). */
+int rv_reduce_copy_persistent(const void* a, const void* b, void* dst, long n, int n_wg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

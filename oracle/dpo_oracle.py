@@ -169,10 +169,11 @@ def make_weights(cfg: LlavaCfg, seed: int = 0, std: float = 0.02, bf16_round: bo
 
 def make_synthetic_batch(cfg: LlavaCfg, n_pairs: int, text_len: int, prompt_len: int = 64,
                          seed: int = 0, ragged: bool = True, image_pos: int = 35,
-                         beta: float = 0.1) -> Dict[str, object]:
+                         beta: float = 0.1, answer_lens: Optional[List[Tuple[int, int]]] = None) -> Dict[str, object]:
     """Batch dict with exactly the collator's schema (muffin/train/train_muffin.py:43-112,
     muffin/eval/muffin_inference_logp.py:187-208): all wins then all rejects, right-padded with
-    pad id 0 / label -100, one -200 image placeholder inside the shared prompt."""
+    pad id 0 / label -100, one -200 image placeholder inside the shared prompt.
+    ``answer_lens``: explicit (chosen, rejected) answer lengths per pair instead of the ragged draw."""
     g = torch.Generator().manual_seed(seed)
     image_pos = min(image_pos, prompt_len - 2)
     prompt = torch.randint(3, cfg.vocab, (n_pairs, prompt_len), generator=g)
@@ -181,7 +182,10 @@ def make_synthetic_batch(cfg: LlavaCfg, n_pairs: int, text_len: int, prompt_len:
     wins, rejs = [], []
     for b in range(n_pairs):
         for dst in (wins, rejs):
-            if ragged:
+            if answer_lens is not None:
+                alen = int(answer_lens[b][0 if dst is wins else 1])
+                assert 2 <= alen <= text_len - prompt_len
+            elif ragged:
                 lo = max(2, (text_len - prompt_len) // 2)
                 alen = int(torch.randint(lo, text_len - prompt_len + 1, (1,), generator=g))
             else:
@@ -192,7 +196,7 @@ def make_synthetic_batch(cfg: LlavaCfg, n_pairs: int, text_len: int, prompt_len:
             lab = ids.clone()
             lab[:prompt_len] = IGNORE_INDEX
             dst.append(dict(input_ids=ids, labels=lab))
-    if ragged and n_pairs > 0:
+    if ragged and n_pairs > 0 and answer_lens is None:
         # make sure the batch really reaches text_len so shapes are deterministic
         w0 = wins[0]
         if w0["input_ids"].numel() < text_len:
@@ -534,6 +538,19 @@ def dpo_step_forward(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg: 
                 reward_accuracies=acc, policy_win_logp=pw, policy_rej_logp=pr,
                 per_token_logps=per_token, log_prob=log_prob, average_log_prob=avg,
                 labels=new_labels, embeds=embeds, image_features=feats)
+
+
+def emulate_bf16(batch: Dict[str, object], W: Dict[str, torch.Tensor]):
+    """Calibration leg: the SAME restatement evaluated the way the reference runs under ``--bf16`` (model loaded in
+    bf16, train_llava15.py:203; tower forced to bf16, :242; HF 4.35 rounds every module output to bf16, keeps RMSNorm
+    statistics / softmax / rotary tables in fp32 and upcasts the logits AFTER the bf16 lm_head GEMM): weights and pixels
+    are cast to bf16, every function above is dtype-generic and follows its input dtype (CPU bf16 matmuls accumulate in
+    fp32 like the GPU GEMMs).  Its distance from the fp32 run is what "bf16 tolerance" means for this model and batch;
+    the HIP path (fp32 norms / RoPE / log-softmax, one rounding per op) is asserted to sit no further from fp32."""
+    Wb = {k: v.detach().to(torch.bfloat16) for k, v in W.items()}
+    bb = dict(batch)
+    bb["images"] = batch["images"].to(torch.bfloat16)
+    return bb, Wb
 
 
 def preference_metrics(out: Dict[str, torch.Tensor], batch, task: str = "train") -> Dict[str, float]:

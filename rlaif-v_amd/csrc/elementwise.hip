@@ -885,6 +885,42 @@ inline int grid_for(long work, int block, int cap = 4096) {
 
 #define STREAM(s) ((hipStream_t)(s))
 
+// A gradient exchange seen from ONE GPU: `n_wg` persistent 256-thread workgroups (the footprint of n_wg RCCL channels -
+// one CU each, for as long as the bucket lasts) stream  dst[i] = a[i] + b[i]  (the receive-reduce-send of a ring step:
+// two 16-byte loads and one 16-byte store per 8 gradients).  bench.py launches it on a side stream at every
+// on_bucket_ready to measure what CUs lent to communication cost the backward GEMMs on a single GPU, where no xGMI
+// peer exists; it is not on the training path.
+__global__ __launch_bounds__(256) void reduce_copy_persistent_kernel(const u32x4_t* __restrict__ a,
+                                                                      const u32x4_t* __restrict__ b,
+                                                                      u32x4_t* __restrict__ dst, long n16) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i0 = (long)blockIdx.x * 256 * 4 + threadIdx.x; i0 < n16; i0 += stride) {
+    u32x4_t va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = i0 + u * 256;
+      if (i < n16) {
+        va[u] = a[i];
+        vb[u] = b[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = i0 + u * 256;
+      if (i < n16) {
+        u32x4_t r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf2f((bf16_t)(va[u][j] & 0xffffu)) + bf2f((bf16_t)(vb[u][j] & 0xffffu));
+          const float hi = bf2f((bf16_t)(va[u][j] >> 16)) + bf2f((bf16_t)(vb[u][j] >> 16));
+          r[j] = pack2bf(lo, hi);
+        }
+        dst[i] = r;
+      }
+    }
+  }
+}
+
 extern "C" {
 
 int rv_rmsnorm_fwd(const void* x, long ldx, const int* row_idx, const void* w, void* y, long ldy, float* rstd,
@@ -1223,6 +1259,16 @@ int rv_cast_bf16_to_f32(const void* in, float* out, long n, void* stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, STREAM(stream),
                      (const bf16_t*)in, out, n);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_reduce_copy_persistent(const void* a, const void* b, void* dst, long n, int n_wg, void* stream) {
+  RV_REQUIRE(n % 8 == 0, "rv_reduce_copy_persistent: n must be a multiple of 8 bf16 elements");
+  RV_REQUIRE(n_wg >= 1 && n_wg <= 256, "rv_reduce_copy_persistent: 1 <= n_wg <= 256");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(reduce_copy_persistent_kernel, dim3(n_wg), dim3(256), 0, STREAM(stream), (const u32x4_t*)a,
+                     (const u32x4_t*)b, (u32x4_t*)dst, n / 8);
   RV_CHECK_LAUNCH();
   return 0;
 }

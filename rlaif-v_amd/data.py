@@ -160,6 +160,9 @@ class SyntheticPreferenceDataset(torch.utils.data.Dataset):
         self.omnilmm = omnilmm
         if omnilmm is not None and self.image_pos + omnilmm["num_query"] + 2 > prompt_len:
             raise ValueError("prompt_len too short for <im_start> + num_query patches + <im_end>")
+        if omnilmm is not None and vocab > min(omnilmm["tokens"]):
+            raise ValueError(f"vocab {vocab} reaches the image tokens {tuple(omnilmm['tokens'])}: random ids would plant stray "
+                             "<im_patch>/<im_start>/<im_end> tokens; pass the text vocabulary (ids below the special tokens)")
 
     def __len__(self):
         return self.n

@@ -9,7 +9,7 @@ all-gathers (C2).  Design for 8 x MI355X (xGMI, 7 links x ~153 GB/s per GPU):
     contiguous slices that become final front to back; each slice is all-reduced asynchronously on
     RCCL's own stream as soon as backward has produced it and overlaps with the remaining layers;
   * small neighbouring slices are merged up to ``bucket_bytes`` (default 400 MB ~ one decoder layer) so a
-    full fine-tune issues ~35 large collectives per step instead of hundreds of small ones;
+    full fine-tune issues 18 large collectives per step (counted by bench.py's probe) instead of hundreds of small ones;
   * the 1/world averaging is folded into the gradient-clip factor (rv_grad_norm pre_scale), so no
     extra pass over the 13.5 GB buffer is needed.
 Works unchanged on CPU tensors with the gloo backend (tests/test_dist_gloo.py, world_size 2).
@@ -33,10 +33,11 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (the host driver has no legacy IPC)
         # RCCL next to 256-CU GEMMs: every RCCL channel is a persistent workgroup that takes a CU away
-        # from the one-workgroup-per-CU GEMMs for as long as a collective runs.  The step needs 2 x 7/8 x 13.5 GB = 23.6 GB
-        # per GPU inside ~0.7 s of backward (34 GB/s) - a fraction of xGMI - so the channel count is capped low instead of
-        # letting RCCL take its default 32+ CUs.  RV_RCCL_CHANNELS overrides (0 = leave RCCL's defaults alone).
-        ch = int(os.environ.get("RV_RCCL_CHANNELS", "8"))
+        # from the one-workgroup-per-CU GEMMs for as long as a collective runs, while the step only needs 2 x 7/8 x 13.5 GB
+        # = 23.6 GB per GPU inside ~0.7 s of backward (34 GB/s).  RV_RCCL_CHANNELS=n caps RCCL at n channels; it is OPT-IN
+        # (default 0 = RCCL's own choice) until an 8-GPU A/B exists - the single-GPU stand-in sweep of bench.py
+        # (dp_standin_probe_1gpu: 4 / 8 / 16 / 32 persistent workgroups beside backward) prices only the CU-lending side.
+        ch = int(os.environ.get("RV_RCCL_CHANNELS", "0"))
         if ch > 0:
             os.environ.setdefault("NCCL_MAX_NCHANNELS", str(ch))
             os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(ch, 4)))

@@ -690,7 +690,8 @@ class LlavaDPOModel:
         B = len(images)                  # tensor [B, 3, H, W] or a list of raw uint8 [H, W, 3] images
         ctx: dict = {}
         w_rows = None
-        self._dropout_step += 1
+        if self.training:            # evaluation passes between steps must not shift the dropout seeds of later steps
+            self._dropout_step += 1
         self._cur_drop_step = ctx["dropout_step"] = self._dropout_step
         if all_rows:
             if save_for_backward:
@@ -873,6 +874,7 @@ class LlavaDPOModel:
             raise NotImplementedError("the DPO path passes attention_mask=None (trainers.py:199)")
         feats = self.encode_images(images)      # one feature block per row of `images`, like the reference
         n_img = len(images)
-        plan = build_splice_plan(input_ids, labels, self.cfg.n_patches, n_img, self.cfg.model_max_length).to(self.device)
+        plan = build_splice_plan(input_ids, labels, self.cfg.n_image_tokens, n_img, self.cfg.model_max_length,
+                                 splicer=self._row_splicer()).to(self.device)
         emb = ops.splice_fwd(plan.src, self.store.p("model.embed_tokens.weight"), feats, self.cfg.hidden)
         return None, None, None, past_key_values, emb.view(plan.S, plan.L, -1), plan.labels.to(self.device)

@@ -501,6 +501,17 @@ def cast_f32_to_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None):
     return out
 
 
+def reduce_copy_persistent(a: torch.Tensor, b: torch.Tensor, dst: torch.Tensor, n_wg: int):
+    """dst = a + b (flat bf16) streamed by ``n_wg`` persistent workgroups: the single-GPU stand-in for the CU footprint of an
+    RCCL ring step (bench.py's data-parallel probe; not on the training path)."""
+    n = a.numel()
+    if a.dtype != BF16 or b.dtype != BF16 or dst.dtype != BF16 or b.numel() < n or dst.numel() < n or not (
+            a.is_contiguous() and b.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("reduce_copy_persistent: contiguous bf16 buffers, b and dst at least as long as a")
+    hip.call("rv_reduce_copy_persistent", a, b, dst, n, int(n_wg))
+    return dst
+
+
 # ------------------------------------------------------------------------------------- optimizer
 def grad_norm(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = None, pre_scale: float = 1.0):
     """out2 = [||pre_scale*g||, pre_scale * clip coefficient] on device (no host sync)."""

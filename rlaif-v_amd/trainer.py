@@ -359,33 +359,47 @@ class LLaVA15DPOTrainer:
                           num_workers=nw)
 
     def get_eval_dataloader(self, eval_dataset=None):
+        """This rank's share of the WHOLE evaluation set (rank-strided, nothing truncated; the last batch may be partial),
+        like the HF Trainer's evaluation loop."""
         from torch.utils.data import DataLoader
         ds = eval_dataset if eval_dataset is not None else self.eval_dataset
         if ds is None:
             raise ValueError("evaluate() needs an eval_dataset")
-        bs = min(int(getattr(self.args, "per_device_eval_batch_size", 8)), max(1, len(ds) // self.reducer.world_size))
-        idx = self._rank_indices(ds, 0, False, bs)
-        return DataLoader(ds, batch_size=bs, sampler=idx, collate_fn=self.data_collator, drop_last=True,
+        world, rank = self.reducer.world_size, int(os.environ.get("RANK", "0"))
+        idx = list(range(len(ds)))[rank::world]
+        bs = max(1, min(int(getattr(self.args, "per_device_eval_batch_size", 8)), len(idx)))
+        return DataLoader(ds, batch_size=bs, sampler=idx, collate_fn=self.data_collator, drop_last=False,
                           num_workers=int(getattr(self.args, "dataloader_num_workers", 0) or 0))
 
     def evaluate(self, eval_dataset=None) -> Dict[str, float]:
         """The evaluation pass of the HF Trainer over ``compute_loss`` with ``model.training == False``: the reference
         then logs the same preference metrics under ``*_test/*`` (trainers.py:303).  Forward only (no activations kept);
-        returns the batch-mean of every metric plus ``eval_loss``, averaged over ranks."""
+        every sample of the set is evaluated once; returns the SAMPLE-weighted mean of every metric plus ``eval_loss``
+        over all ranks (one fused all-reduce of [sums, count])."""
         was_training = self.model.training
         self.model.eval()
-        tot, n = None, 0
+        dev = self.model.device
+        tot, cnt = torch.zeros(8, dtype=torch.float32, device=dev), 0
         try:
             for batch in self.get_eval_dataloader(eval_dataset):
+                nb = int(batch["win_input_ids"].shape[0])
                 loss = self.compute_loss(self.model, batch)
-                v = torch.cat([self._pending_metrics, loss.detach().reshape(1)])
-                tot = v if tot is None else tot + v
-                n += 1
+                tot += nb * torch.cat([self._pending_metrics, loss.detach().reshape(1)])
+                cnt += nb
         finally:
             self.model.train(was_training)
-        self._pending_metrics, self._pending_task = tot[:7] / n, "test"
-        m = self.pop_metrics()
-        m["eval_loss"] = float(self.reducer.reduce_metrics(tot[7:] / n)[0])
+        # reduce_metrics returns the cross-rank MEAN: mean(sums) / mean(counts) = sum / count over all ranks
+        red = self.reducer.reduce_metrics(torch.cat([tot, torch.tensor([float(cnt)], device=dev)]))
+        if float(red[8]) <= 0:
+            raise ValueError("evaluate(): empty evaluation set")
+        mean = red[:8] / red[8]
+        self._pending_metrics, self._pending_task = mean[:7], "test"
+        keep, self.reducer = self.reducer, GradReducer()        # already reduced: pop_metrics must not average again
+        try:
+            m = self.pop_metrics()
+        finally:
+            self.reducer = keep
+        m["eval_loss"] = float(mean[7])
         self.log(m)
         return m
 
@@ -437,6 +451,16 @@ class LLaVA15DPOTrainer:
         with open(os.path.join(self.args.output_dir, "trainer_state.json"), "w") as f:
             json.dump(self.state, f)
 
+    def _optimizer_layout(self) -> dict:
+        """What the raw flat buffers of optimizer.pt mean: entry order / offsets (CRC), the gate|up row interleave of the
+        fused MLP weight (RV_FUSE_SWIGLU) and the vocabulary padding.  A blob written under another layout has the same
+        length but different row order - load_checkpoint refuses it instead of scrambling weights and Adam state."""
+        import zlib
+        st = self.model.store
+        order = "|".join(f"{k}:{st.offsets[k][0]}:{'x'.join(map(str, st.offsets[k][1]))}" for k, _, _ in st.entries)
+        return dict(version=1, interleave_gu=bool(st.interleave_gu), vocab_padded=int(self.model.cfg.vocab_padded),
+                    n_train=int(st.n_train), t0=int(st.t0), entries_crc32=zlib.crc32(order.encode()))
+
     def save_checkpoint(self, path: str):
         if int(os.environ.get("RANK", "0")) != 0:
             return
@@ -445,12 +469,25 @@ class LLaVA15DPOTrainer:
         # data position (epoch + batches consumed in it) rides in self.state; the LoRA dropout counter too, so that a
         # resumed run draws the masks the uninterrupted run would have drawn
         torch.save(dict(master=st.flat_master.cpu(), m=st.flat_m.cpu(), v=st.flat_v.cpu(), state=self.state,
-                        dropout_step=int(self.model._dropout_step)), os.path.join(path, "optimizer.pt"))
+                        dropout_step=int(self.model._dropout_step), layout=self._optimizer_layout()),
+                   os.path.join(path, "optimizer.pt"))
         self._save(path)
 
     def load_checkpoint(self, path: str):
         st = self.model.store
         blob = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
+        want = self._optimizer_layout()
+        # blobs written before the descriptor existed used block gate|up rows and an unpadded vocabulary
+        have = blob.get("layout") or dict(version=0, interleave_gu=False, vocab_padded=int(self.model.cfg.vocab),
+                                          n_train=int(blob["master"].numel()), t0=want["t0"], entries_crc32=None)
+        diff = [k for k in ("interleave_gu", "vocab_padded", "n_train", "t0") if have.get(k) != want[k]]
+        if have.get("entries_crc32") not in (None, want["entries_crc32"]):
+            diff.append("entries_crc32")
+        if diff:
+            raise ValueError(f"{path}/optimizer.pt was written under another parameter layout ({', '.join(diff)} differ: checkpoint "
+                             f"{ {k: have.get(k) for k in diff} } vs this model { {k: want[k] for k in diff} }); resume with the "
+                             "same RV_FUSE_SWIGLU / LoRA / vocabulary settings, or load the HF-layout weights "
+                             "(from_pretrained) and restart the optimizer")
         st.flat_master.copy_(blob["master"]), st.flat_m.copy_(blob["m"]), st.flat_v.copy_(blob["v"])
         ops.cast_f32_to_bf16(st.flat_master, st.train_p)
         st.refresh_transposes(trainable_only=True)

@@ -1,0 +1,258 @@
+"""Harness of the FULL-DEPTH parity cases: BASELINE configs 1 and 2 at all 32 layers of LLaVA-1.5-7B.
+
+  cfg1_step   BASELINE config 1 - 4 synthetic 336-px pairs, text length T = 512 -> spliced length L = 1087, ONE optimisation
+              step: forward, backward, clip_grad_norm_(1.0), AdamW (muffin/train/trainers.py:281-311 + the HF Trainer
+              defaults of train_llava15.py:75 / llava15_train.sh:31-34), lr 5e-7 (the script's peak rate; the schedule's own
+              first-step rate is 0 under warm-up, which would make the post-step comparison empty).
+  cfg2_fwd    BASELINE config 2's sequence shape - one pair at L = 2048, forward log-probs and loss.  The chosen answer is
+              twice as long as the rejected one, so the synthetic loss (beta x a difference of two sums of about -15,000 and
+              -7,800) is not a cancelling difference of near-equal sums: the 1e-3 bar is asserted on it as north_star states it.
+
+The fp32 oracle of the 7B model needs ~350 GB of host RAM and ~10 minutes of 128 cores for cfg1_step, so it runs ONCE on
+the GPU box's host (tools/full_depth_parity.py), next to the HIP path on the same weights and batch; what it produced is
+committed as tests/golden/fulldepth_*.pt (everything needed to re-check the HIP path: labels, per-token log-probs, loss,
+every per-tensor gradient norm, 1024 sampled elements of every gradient and of every post-step fp32 master, the clip
+factor, and the bf16-EMULATED oracle's log-probs for calibration).  tests/test_zz_baseline_configs_gpu.py replays the
+fixtures against the HIP path on every GPU run; RV_PARITY_LIVE=1 re-runs the oracle instead.
+
+Test infrastructure (imports oracle/): never imported by the product package.
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+import zlib
+from typing import Dict, Optional
+
+import torch
+
+from oracle import dpo_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WEIGHT_SEED = 41
+N_SAMPLE = 1024
+CASES = {
+    "cfg1_step": dict(seed=41, pairs=4, text_len=512, prompt_len=64, ragged=True, answer_lens=None, lr=5e-7, step=True),
+    "cfg2_fwd": dict(seed=42, pairs=1, text_len=2048 - 575, prompt_len=64, ragged=False, answer_lens=[(1409, 704)],
+                     lr=None, step=False),
+}
+
+
+def make_cfg(layers: int = 32) -> O.LlavaCfg:
+    return O.LlavaCfg(layers=layers, model_max_length=2048)
+
+
+def make_batch(case: str, cfg: O.LlavaCfg):
+    c = CASES[case]
+    return O.make_synthetic_batch(cfg, c["pairs"], c["text_len"], c["prompt_len"], seed=c["seed"], ragged=c["ragged"],
+                                  answer_lens=c["answer_lens"])
+
+
+def sample_index(name: str, numel: int, n: int = N_SAMPLE) -> torch.Tensor:
+    """Deterministic element sample of a tensor (same on every machine: CPU generator seeded by the tensor's name)."""
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    return torch.randint(0, numel, (min(n, numel),), generator=g)
+
+
+def _cos(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+# ------------------------------------------------------------------------------------------------ oracle side
+def _fwd_summary(ref: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    mask = ref["labels"][:, 1:] != O.IGNORE_INDEX
+    return dict(labels=ref["labels"].clone(), per_token=ref["per_token_logps"].detach().float()[mask].clone(),
+                log_prob=ref["log_prob"].detach().float().clone(), loss=float(ref["loss"].detach()))
+
+
+def oracle_case(case: str, W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, emulate: bool = True, log=print) -> Dict[str, object]:
+    """Runs the oracle for one case.  ``cfg1_step`` updates W in place (AdamW), so callers hand the HIP side its copy first."""
+    c = CASES[case]
+    batch = make_batch(case, cfg)
+    fx: Dict[str, object] = dict(case=case, layers=cfg.layers, weight_seed=WEIGHT_SEED, torch=torch.__version__,
+                                 threads=torch.get_num_threads())
+    if emulate:
+        t0 = time.time()
+        bb, Wb = O.emulate_bf16(batch, W)
+        with torch.no_grad():
+            emu = O.dpo_step_forward(bb, Wb, cfg, sft_weight=0.0, dpo_weight=1.0)
+        e = _fwd_summary(emu)
+        fx.update(emu_per_token=e["per_token"], emu_log_prob=e["log_prob"], emu_loss=e["loss"], emu_s=time.time() - t0)
+        del Wb, emu
+        log(f"[{case}] bf16-emulated oracle forward: {fx['emu_s']:.0f} s")
+    if not c["step"]:
+        t0 = time.time()
+        with torch.no_grad():
+            ref = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)
+        fx.update(_fwd_summary(ref), fwd_s=time.time() - t0)
+        log(f"[{case}] oracle forward: {fx['fwd_s']:.0f} s")
+        return fx
+    ph: Dict[str, float] = {}
+    opt_state: Dict[str, Dict[str, torch.Tensor]] = {}
+    ref, grads, gn = O.dpo_train_step(batch, W, cfg, opt_state, lr=c["lr"], step=1, timings=ph, sft_weight=0.0, dpo_weight=1.0)
+    fx.update(_fwd_summary(ref), timings=dict(ph), grad_norm_total=float(gn), clip_coef=min(1.0, 1.0 / (float(gn) + 1e-6)),
+              lr=c["lr"])
+    log(f"[{case}] oracle step: fwd {ph['fwd_s']:.0f} s, bwd {ph['bwd_s']:.0f} s, clip + AdamW {ph['opt_s']:.0f} s")
+    gnorm, gsamp, psamp = {}, {}, {}
+    for k in O.trainable_names(cfg):
+        if k not in grads:
+            continue
+        idx = sample_index(k, grads[k].numel())
+        gnorm[k] = float(grads[k].double().norm())
+        gsamp[k] = grads[k].flatten()[idx].float().clone()
+        psamp[k] = W[k].detach().flatten()[idx].float().clone()         # post-step fp32 parameter = the HIP fp32 master
+    fx.update(grad_norms=gnorm, grad_samples=gsamp, post_samples=psamp)
+    fx["_full_grads"] = grads                                            # live runs only; stripped before saving
+    return fx
+
+
+def save_fixture(fx: Dict[str, object], path: str):
+    torch.save({k: v for k, v in fx.items() if not k.startswith("_")}, path)
+
+
+# ------------------------------------------------------------------------------------------------ HIP side
+def build_model(cfg: O.LlavaCfg, W: Dict[str, torch.Tensor], with_optimizer: bool = True):
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)), with_optimizer=with_optimizer)
+    model.load_state_dict(W)
+    return model, LLaVA15DPOTrainer(model=model, args=TrainingArguments())
+
+
+def _trainable_views(model, flat: torch.Tensor):
+    """(HF name, view) over a trainable-relative flat buffer (flat_g / flat_master / flat_m / flat_v)."""
+    st, cfg = model.store, model.cfg
+    for name, (key, r0, n, step) in st.hf_slices(cfg).items():
+        if key not in st.trainable:
+            continue
+        off, shp = st.offsets[key]
+        off -= st.t0
+        yield name, st.rows(flat[off:off + math.prod(shp)].view(*shp), r0, n, step)
+
+
+def _take(view: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    idx = idx.to(view.device)
+    if view.dim() == 1:
+        return view[idx].float().cpu()
+    cols = view.shape[1]
+    return view[idx // cols, idx % cols].float().cpu()
+
+
+def hip_case(case: str, model, trainer, cfg: O.LlavaCfg, full_grads: bool = False) -> Dict[str, object]:
+    """The HIP path on the case's batch: compute_loss (+ backward + clip + AdamW for cfg1_step), through the C ABI."""
+    c = CASES[case]
+    batch = make_batch(case, cfg)
+    model.train(c["step"])
+    loss = trainer.compute_loss(model, dict(batch))
+    out = model.last_out
+    res: Dict[str, object] = dict(tgt=out.plan.tgt.cpu().long(), seq_cnt=out.seq_cnt.cpu(), log_prob=out.seq_logp.float().cpu(),
+                                  per_token=out.per_token_logp.float().cpu(), loss=float(loss), plan_S=out.plan.S, plan_L=out.plan.L,
+                                  spliced_labels=out.plan.labels.cpu() if out.plan.labels is not None else None)
+    if not c["step"]:
+        return res
+    model.backward(out, model.last_coef)
+    st = model.store
+    gnorm, gsamp = {}, {}
+    for name, v in _trainable_views(model, st.flat_g):
+        gnorm[name] = float(v.double().norm())
+        gsamp[name] = _take(v, sample_index(name, v.numel()))
+    if full_grads:
+        res["_full_grads"] = {name: v.detach().to("cpu", copy=True) for name, v in _trainable_views(model, st.flat_g)}   # bf16
+    trainer.optimizer_step(lr=c["lr"])
+    torch.cuda.synchronize()
+    clip = trainer._clip.cpu().tolist()                      # [||g||, clip coefficient]
+    psamp = {name: _take(v, sample_index(name, v.numel())) for name, v in _trainable_views(model, st.flat_master)}
+    msamp = {name: _take(v, sample_index(name, v.numel())) for name, v in _trainable_views(model, st.flat_m)}
+    res.update(grad_norms=gnorm, grad_samples=gsamp, grad_norm_total=clip[0], clip_coef=clip[1], post_samples=psamp,
+               m_samples=msamp)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ comparison
+def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Optional[Dict[str, torch.Tensor]] = None,
+            check: bool = True) -> Dict[str, object]:
+    """Metrics of HIP vs oracle fixture; with ``check`` the bars below are asserted.
+    Bars: token indexing bit exact; sequence log-prob sums and loss 1e-3 relative (north_star); per-token log-probs no
+    further from the fp32 oracle than the bf16-EMULATED oracle is (mean; worst token within 1.5 x the emulation's worst);
+    gradients: every tensor's norm within 3 %, direction cosine >= 0.99; total norm / clip factor within 1 %; post-step
+    fp32 masters: the AdamW update (master - initial weight) agrees with the oracle's on >= 95 % of the sampled elements
+    to 5 % of lr (+ 2 fp32 ulps of the value), and the first-moment sample has cosine >= 0.99."""
+    c = CASES[case]
+    labels = fx["labels"]
+    mask = labels[:, 1:] != O.IGNORE_INDEX
+    m: Dict[str, object] = dict(case=case, layers=fx["layers"], n_tokens=int(mask.sum()))
+    idx_ok = bool(torch.equal(hip["tgt"], labels[:, 1:][mask])) and hip["seq_cnt"].tolist() == mask.sum(1).float().tolist()
+    m["indexing_bit_exact"] = idx_ok
+    lp, lp_ref = hip["log_prob"], fx["log_prob"]
+    m["seq_logp"], m["seq_logp_oracle"] = lp.tolist(), lp_ref.tolist()
+    m["seq_logp_max_rel_err"] = float(((lp - lp_ref).abs() / lp_ref.abs()).max())
+    m["loss"], m["loss_oracle"] = hip["loss"], fx["loss"]
+    m["loss_rel_err"] = abs(hip["loss"] - fx["loss"]) / abs(fx["loss"])
+    d = (hip["per_token"] - fx["per_token"]).abs()
+    m["per_token_mean_abs_err"], m["per_token_max_abs_err"] = float(d.mean()), float(d.max())
+    m["per_token_mean_abs_value"] = float(fx["per_token"].abs().mean())
+    if "emu_per_token" in fx:
+        e = (fx["emu_per_token"] - fx["per_token"]).abs()
+        m["emu_bf16_per_token_mean_abs_err"], m["emu_bf16_per_token_max_abs_err"] = float(e.mean()), float(e.max())
+        m["emu_bf16_seq_logp_max_rel_err"] = float(((fx["emu_log_prob"] - lp_ref).abs() / lp_ref.abs()).max())
+        m["emu_bf16_loss_rel_err"] = abs(fx["emu_loss"] - fx["loss"]) / abs(fx["loss"])
+    if check:
+        assert idx_ok, "token indexing differs from the oracle's spliced labels"
+        assert m["seq_logp_max_rel_err"] <= 1e-3, m["seq_logp_max_rel_err"]
+        assert m["loss_rel_err"] <= 1e-3, (m["loss"], m["loss_oracle"])
+        if "emu_per_token" in fx:
+            assert m["per_token_mean_abs_err"] <= m["emu_bf16_per_token_mean_abs_err"], \
+                (m["per_token_mean_abs_err"], m["emu_bf16_per_token_mean_abs_err"])
+            assert m["per_token_max_abs_err"] <= 1.5 * m["emu_bf16_per_token_max_abs_err"]
+    if not c["step"]:
+        return m
+    # ---- backward
+    worst_norm, worst_cos, worst_full_cos = 0.0, 1.0, 1.0
+    per_tensor = {}
+    for k, n_ref in fx["grad_norms"].items():
+        if n_ref < 1e-9:
+            continue
+        rel = abs(hip["grad_norms"][k] - n_ref) / n_ref
+        cs = _cos(hip["grad_samples"][k], fx["grad_samples"][k])
+        per_tensor[k] = (rel, cs)
+        worst_norm, worst_cos = max(worst_norm, rel), min(worst_cos, cs)
+        if "_full_grads" in hip and "_full_grads" in fx:
+            fc = _cos(hip["_full_grads"][k], fx["_full_grads"][k])
+            worst_full_cos = min(worst_full_cos, fc)
+            per_tensor[k] += (fc,)
+        if check:
+            assert rel <= 3e-2 and cs >= 0.99, (k, rel, cs)
+    m.update(grad_tensors=len(per_tensor), grad_worst_norm_rel_err=worst_norm, grad_worst_sample_cosine=worst_cos)
+    if "_full_grads" in hip and "_full_grads" in fx:
+        m["grad_worst_full_cosine"] = worst_full_cos
+        if check:
+            assert worst_full_cos >= 0.99
+    m["grad_norm_total"], m["grad_norm_total_oracle"] = hip["grad_norm_total"], fx["grad_norm_total"]
+    m["clip_coef"], m["clip_coef_oracle"] = hip["clip_coef"], fx["clip_coef"]
+    gn_rel = abs(hip["grad_norm_total"] - fx["grad_norm_total"]) / fx["grad_norm_total"]
+    clip_rel = abs(hip["clip_coef"] - fx["clip_coef"]) / fx["clip_coef"]
+    m.update(grad_norm_total_rel_err=gn_rel, clip_coef_rel_err=clip_rel)
+    # ---- optimizer: post-step fp32 masters and first moment on the sampled elements
+    lr = c["lr"]
+    agree, total, worst_m_cos = 0, 0, 1.0
+    for k, p_ref in fx["post_samples"].items():
+        p_hip = hip["post_samples"][k]
+        total += p_ref.numel()
+        agree += int(((p_hip - p_ref).abs() <= 0.05 * lr + 2.4e-7 * p_ref.abs()).sum())      # 5 % of lr + 2 fp32 ulps
+        m_ref = 0.1 * fx["clip_coef"] * fx["grad_samples"][k]          # AdamW first moment after step 1: (1 - beta1) x clipped g
+        if float(m_ref.norm()) > 0:
+            worst_m_cos = min(worst_m_cos, _cos(hip["m_samples"][k], m_ref))
+    m.update(master_update_agree_frac=agree / max(total, 1), master_samples=total, adam_m_worst_sample_cosine=worst_m_cos)
+    if W0 is not None:      # how many sampled masters moved at all (guards against a vacuous comparison)
+        moved = sum(int(((hip["post_samples"][k] - W0[k].flatten()[sample_index(k, W0[k].numel())]).abs() > 0).sum())
+                    for k in fx["post_samples"])
+        m["master_moved_frac"] = moved / max(total, 1)
+    if check:
+        assert gn_rel <= 1e-2 and clip_rel <= 1e-2, (gn_rel, clip_rel)
+        assert m["master_update_agree_frac"] >= 0.95, m["master_update_agree_frac"]
+        assert worst_m_cos >= 0.99, worst_m_cos
+        if W0 is not None:
+            assert m["master_moved_frac"] >= 0.9
+    return m

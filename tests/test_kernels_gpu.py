@@ -250,6 +250,24 @@ def test_transpose(ops):
         assert t[:, R:].abs().sum() == 0
 
 
+@pytest.mark.parametrize("n,n_wg", [(8, 1), (8 * 1000 + 8, 4), (1 << 22, 8), (3 * (1 << 20) + 40, 16)])
+def test_reduce_copy_persistent(ops, n, n_wg):
+    """The data-parallel stand-in kernel (bench.py's single-GPU probe): dst = a + b, any length, any workgroup count,
+    also while another stream is busy."""
+    dev = _dev()
+    a, b = rnd(n, seed=n, dev=dev), rnd(n + 64, seed=n + 1, dev=dev)
+    dst = torch.full((n + 8,), 7.0, dtype=BF, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        ops.reduce_copy_persistent(a, b, dst, n_wg)
+    busy = ops.gemm_nt(rnd(512, 256, seed=3, dev=dev), rnd(512, 256, seed=4, dev=dev))      # main stream keeps working
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:n], (a.float() + b[:n].float()).to(BF)) and float(dst[n:].float().min()) == 7.0
+    assert torch.isfinite(busy.float()).all()
+
+
 # ------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("rows,d", [(333, 512), (1000, 1280), (5000, 4096), (3, 4096), (700, 5120)])
 def test_rmsnorm_fwd_bwd(ops, rows, d):

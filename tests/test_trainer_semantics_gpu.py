@@ -178,3 +178,53 @@ def test_resume_restores_data_position(tmp_path):
     assert seen == order_full[3:]                      # continues where it stopped; epoch 1 is a new permutation
     assert order_full[5:7] != order_full[0:2]
     assert torch.equal(res.model.store.flat_master, full.model.store.flat_master)
+
+
+def test_evaluate_covers_the_tail_batch():
+    """5 samples at eval batch 2 -> batches of 2, 2, 1: every sample counts once (sample-weighted mean), like the HF Trainer's
+    evaluation loop; evaluation does not advance the LoRA dropout counter."""
+    _need_gpu()
+    cfg = O.tiny_cfg()
+    model, W = _model(cfg, seed=12)
+    from rlaif_v_amd.data import DataCollatorForDPODataset, SyntheticPreferenceDataset
+
+    class Tok:
+        pad_token_id = cfg.pad_token_id
+    ds = SyntheticPreferenceDataset(n=5, vocab=cfg.vocab, text_len=40, prompt_len=12, image_size=cfg.image_size, seed=5)
+    tr = _trainer(model, per_device_eval_batch_size=2)
+    tr.eval_dataset, tr.data_collator = ds, DataCollatorForDPODataset(Tok(), beta=0.1, mod_token_weight=1.0)
+    step0 = model._dropout_step
+    m = tr.evaluate()
+    assert model._dropout_step == step0
+    tot = 0.0
+    for idx in ([0, 1], [2, 3], [4]):
+        batch = tr.data_collator([ds[i] for i in idx])
+        with torch.no_grad():
+            tot += len(idx) * float(O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)["loss"])
+    ref = tot / 5
+    assert abs(m["eval_loss"] - ref) <= 2e-3 * abs(ref), (m["eval_loss"], ref)
+
+
+def test_checkpoint_refuses_another_parameter_layout(tmp_path, monkeypatch):
+    """optimizer.pt carries a layout descriptor: a blob written with interleaved gate|up rows (RV_FUSE_SWIGLU=1) must not load
+    into a block-layout store (same length, different row order), nor may an untagged legacy blob load into an interleaved one."""
+    _need_gpu()
+    cfg = O.tiny_cfg()
+    model, _ = _model(cfg, seed=13)
+    assert model.store.interleave_gu
+    tr = _trainer(model, output_dir=str(tmp_path))
+    tr.save_checkpoint(str(tmp_path / "ck"))
+    blob = torch.load(str(tmp_path / "ck" / "optimizer.pt"), map_location="cpu")
+    assert blob["layout"]["interleave_gu"] is True and blob["layout"]["n_train"] == model.store.n_train
+    tr.load_checkpoint(str(tmp_path / "ck"))                                   # same layout: loads
+    monkeypatch.setenv("RV_FUSE_SWIGLU", "0")
+    other, _ = _model(cfg, seed=13)
+    assert not other.store.interleave_gu
+    with pytest.raises(ValueError, match="interleave_gu"):
+        _trainer(other).load_checkpoint(str(tmp_path / "ck"))
+    monkeypatch.delenv("RV_FUSE_SWIGLU")
+    del blob["layout"]                                                          # a blob from before the descriptor existed
+    os.makedirs(tmp_path / "old", exist_ok=True)
+    torch.save(blob, str(tmp_path / "old" / "optimizer.pt"))
+    with pytest.raises(ValueError, match="interleave_gu"):
+        tr.load_checkpoint(str(tmp_path / "old"))
