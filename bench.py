@@ -211,8 +211,11 @@ def main():
     ap.add_argument("--lora-r", type=int, default=64)
     ap.add_argument("--gradient-checkpointing", action="store_true", help="re-run each decoder layer in backward")
     ap.add_argument("--omnilmm", action="store_true",
-                    help="BASELINE config 4 shape: OmniLMM-12B language side (Mistral-7B, 8 kv heads, f 14336) + Resampler, "
-                         "64 image tokens; the frozen EVA02 tower is NOT run - synthetic precomputed tower tokens")
+                    help="BASELINE config 4: OmniLMM-12B - EVA02-E/14 tower at 448 px (63 blocks, width 1792, frozen, forward) -> "
+                         "Resampler (64 queries) -> Mistral-7B side (8 kv heads, f 14336), from pixels")
+    ap.add_argument("--omnilmm-precomputed-tower", action="store_true",
+                    help="with --omnilmm: hand over synthetic precomputed tower tokens instead of pixels (the tower is frozen, "
+                         "its output can be cached across epochs); the tower is then NOT in the number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dp-probe", action="store_true",
                     help="skip the single-GPU data-parallel probe (steps re-timed with a concurrent reduce-copy kernel on a "
@@ -237,10 +240,15 @@ def main():
 
     L, B = args.seq_len, args.pairs_per_gpu
     lora = LoraConfig(r=args.lora_r) if args.lora else None        # peft defaults of train_llava15_lora.py:111-116
+    tower = None
     if args.omnilmm:
         from rlaif_v_amd.omnilmm import OmniLMMConfig, OmniLMMDPOModel
         cfg = OmniLMMConfig(layers=args.layers, model_max_length=L)
         model = OmniLMMDPOModel(cfg, device=dev, lora=lora)
+        if not args.omnilmm_precomputed_tower:
+            from rlaif_v_amd.eva_tower import EvaConfig, EvaTower
+            tower = EvaTower(EvaConfig(), device=dev).init_random(seed=1)
+            model.set_vision_tower(tower)
     else:
         cfg = LlavaConfig(layers=args.layers, model_max_length=L)
         model = LlavaDPOModel(cfg, device=dev, lora=lora)
@@ -257,7 +265,8 @@ def main():
         ds = SyntheticPreferenceDataset(n=B * world, vocab=32000, text_len=L, prompt_len=64 + cfg.num_query + 2, seed=1234,
                                         omnilmm=dict(tokens=(cfg.im_patch_token, cfg.im_start_token, cfg.im_end_token),
                                                      num_query=cfg.num_query, tower_tokens=(cfg.image_size // 14) ** 2,
-                                                     width=cfg.vision_width))
+                                                     width=cfg.vision_width, pixels=tower is not None),
+                                        image_size=cfg.image_size)
     else:
         ds = SyntheticPreferenceDataset(n=B * world, vocab=cfg.vocab, text_len=L - (cfg.n_patches - 1), prompt_len=64,
                                         image_size=cfg.image_size, seed=1234)
@@ -369,6 +378,8 @@ def main():
         if args.omnilmm:     # resampler fwd + bwd per image: kv_proj, k / v / q / out / proj projections, 64 x N attention
             nt_, w_, d_, nq_ = (cfg.image_size // 14) ** 2, cfg.vision_width, cfg.hidden, cfg.num_query
             vis = 3.0 * (2 * nt_ * w_ * d_ + 2 * 2 * nt_ * d_ * d_ + 3 * 2 * nq_ * d_ * d_ + 4 * nq_ * nt_ * d_)
+            vis_tower = tower.flops_per_image(cfg.image_size) if tower is not None else 0.0      # frozen: forward only, once per pair
+            vis += vis_tower
         else:
             vis = 0.366e12 + 3 * 0.024e12
         dims = dict(d=cfg.hidden, f=cfg.ffn, V=cfg.vocab, kvd=cfg.kv_dim, vision=vis)
@@ -382,11 +393,14 @@ def main():
         fp = flops_per_pair(L, layers=args.layers, lora_r=lr_, n_tgt=plan.n_sel / (2.0 * B), **dims) - saved
         step_tflops_per_gpu = fp * (pairs_per_s / world) / 1e12
         line = {
-            "metric": "preference-pairs/sec (DPO step) " + ("OmniLMM-12B (tower excluded)" if args.omnilmm else "LLaVA-1.5-7B") + " bf16", "value": pairs_per_s, "unit": "pairs/s",
+            "metric": "preference-pairs/sec (DPO step) " + (("OmniLMM-12B" if tower is not None else "OmniLMM-12B (tower excluded)") if args.omnilmm else "LLaVA-1.5-7B") + " bf16", "value": pairs_per_s, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("OmniLMM-12B language side (Mistral-7B: 8 kv heads, f 14336) + Resampler (64 queries x 1024 "
-                                    "tower tokens); frozen EVA02-E tower NOT run (precomputed synthetic tower tokens) "
+            "config": {"workload": (("OmniLMM-12B from pixels: EVA02-E/14 tower (63 blocks, width 1792, 448 px -> 1024 tokens, frozen, "
+                                     "forward; parity UNPINNED: timm absent) -> Resampler (64 queries) -> Mistral-7B side (8 kv heads, f 14336) "
+                                     if tower is not None else
+                                     "OmniLMM-12B language side (Mistral-7B: 8 kv heads, f 14336) + Resampler (64 queries x 1024 "
+                                     "tower tokens); frozen EVA02-E tower NOT run (precomputed synthetic tower tokens) ")
                                     if args.omnilmm else "LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B) ")
                                    + (f"LoRA (r={args.lora_r}, all 7 decoder projections, dropout 0.05)" if args.lora else "full-FT")
                                    + f" DPO step, {cfg.image_size}px, seq_len={L}, {B} pairs/GPU, random-init weights",
@@ -401,6 +415,10 @@ def main():
             "shared_prefix_tokens_per_pair": sum(shared) / max(len(shared), 1),
             "tokens_per_step_per_gpu": plan.n_real_tokens,
         }
+        if tower is not None:
+            line["vision_tower"] = dict(kind="EVA02-E/14 (timm eva02_enormous_patch14_clip_224, last block dropped), frozen, forward only",
+                                        params=tower.n_params(), flops_per_image=vis_tower, blocks=tower.cfg.blocks_used,
+                                        tokens_per_image=(cfg.image_size // tower.cfg.patch) ** 2, parity="unpinned (timm absent offline)")
         if not args.no_gemm_timer:
             g = timer.summary()
             traffic, traffic_file = None, None

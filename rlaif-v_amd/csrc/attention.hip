@@ -61,7 +61,7 @@ __device__ __forceinline__ void mfma_agpr_zero(f32x16_t& acc) {
 // kernels were HBM bound).  Here the nx blocks of an (s, h) occupy consecutive slots of ONE XCD.
 __device__ __forceinline__ void attn_block_coords(int nx, int H, int S, int& x, int& h, int& s) {
   const int id = blockIdx.x, HS = H * S;
-  const int mode = nx >> 16;      // experiment switch packed into the high bits by the launcher
+  const int mode = (nx >> 16) & 15;      // experiment switch packed into the high bits by the launcher (bit 20: pair_blocks)
   nx &= 0xffff;
   int hs;
   if (mode == 1 && (HS & 7) == 0) {        // the nx blocks of an (s,h) on consecutive slots of one XCD
@@ -77,6 +77,44 @@ __device__ __forceinline__ void attn_block_coords(int nx, int H, int S, int& x, 
   }
   h = hs % H;
   s = hs / H;
+}
+
+// Which two 128-row blocks a causal workgroup processes.  The plain pairing (x, n-1-x) is balanced for a plain causal row
+// only: in a packed pair row [shared | chosen | rejected] a rejected-branch query block skips the chosen-branch key tiles
+// and a chosen-branch key block is never visited by the rejected-branch queries, so the (x, n-1-x) sums range over 36..58
+// tiles (forward / dQ) and 10..56 tiles (dK / dV) at the bench shape.  Here every lane computes the tile count of block
+// `lane` with the SAME bounds the kernels use, the blocks are ranked by descending work, and workgroup bx takes the blocks
+// of rank bx (heavy) and n-1-bx (light): the sums are equal where pairs can make them equal (forward / dQ: 36..40) and
+// otherwise DEscend with bx, i.e. the dispatcher - which issues workgroups in id order - sees the long ones first (LPT).
+// KEYS = false: query blocks (forward, dQ); true: key blocks (dK / dV).  n > 64 or bit 20 of nx clear: plain pairing.
+template <bool KEYS>
+__device__ __forceinline__ void pair_blocks(int bx, int n, int L, int sh, int e1, int lane, bool balanced, int& first,
+                                            int& second) {
+  if (!balanced || n > 64) {
+    first = bx;
+    second = (n - 1 - bx > bx) ? n - 1 - bx : -1;
+    return;
+  }
+  const int x = lane, b0 = x * 128;
+  int w;
+  if (!KEYS) {
+    const int nt = (min(L, b0 + 128) + 63) >> 6;
+    const int skip = (b0 >= e1 && e1 > sh) ? max((e1 >> 6) - ((sh + 63) >> 6), 0) : 0;
+    w = nt - skip;
+  } else {
+    const int nt = (b0 >= sh && b0 + 127 < e1) ? min((L + 63) >> 6, (e1 + 63) >> 6) : (L + 63) >> 6;
+    w = nt - (b0 >> 6);
+  }
+  if (x >= n) w = -1;
+  int rank = 0;
+  for (int y = 0; y < n; ++y) {
+    const int wy = __builtin_amdgcn_readlane(w, y);
+    rank += (wy > w || (wy == w && y < x)) ? 1 : 0;
+  }
+  const unsigned long long m1 = __ballot(x < n && rank == bx);
+  const unsigned long long m2 = __ballot(x < n && rank == n - 1 - bx);
+  first = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m1) - 1);
+  second = (n - 1 - bx > bx) ? __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m2) - 1) : -1;
 }
 
 template <int HD>
@@ -238,10 +276,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   const bf16_t* kbase = qkv + k_col0 + (h / kv_group) * HD;     // grouped-query attention: query head h -> kv head h / G
   const bf16_t* vbase = qkv + v_col0 + (h / kv_group) * HD;
 
+  int blk_first, blk_second;
+  pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), blk_first, blk_second);
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-    const int qb = (pass == 0) ? bx : (nqb - 1 - bx);
-    if (pass == 1 && qb <= bx) break;
+    const int qb = (pass == 0) ? blk_first : blk_second;
+    if (qb < 0) break;
     const int q0 = qb * 128, q0w = q0 + wave * 32;
     const int q = q0w + fr;
     QueryLaneMask<CAUSAL> qmask;
@@ -465,10 +505,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
   const bf16_t* kbase = qkv + k_col0 + (h / kv_group) * HD;
   const bf16_t* vbase = qkv + v_col0 + (h / kv_group) * HD;
 
+  int blk_first, blk_second;
+  pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), blk_first, blk_second);
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-    const int qb = (pass == 0) ? bx : (nqb - 1 - bx);
-    if (pass == 1 && qb <= bx) break;
+    const int qb = (pass == 0) ? blk_first : blk_second;
+    if (qb < 0) break;
     const int q0 = qb * 128, q0w = q0 + wave * 32;
     const int q = q0w + fr, qc = min(q, L - 1);
     QueryLaneMask<CAUSAL> qmask;
@@ -707,10 +749,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
                                    ds_tr16_b64_asm(tile_addr + toff[1][et], row0 * 256), 0, 1, 2, 3, 4, 5, 6, 7);
   };
 
+  int blk_first, blk_second;
+  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), blk_first, blk_second);
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-    const int kvb = (pass == 0) ? bx : (nkb - 1 - bx);
-    if (pass == 1 && kvb <= bx) break;
+    const int kvb = (pass == 0) ? blk_first : blk_second;
+    if (kvb < 0) break;
     const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
     const int key = kv0w + fr, keyc = min(key, L - 1);
     KeyLaneMask<CAUSAL> kmask;
@@ -943,10 +987,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
       tb[u][et] = lds0 + qtile_off(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
                   (uint32_t)((s16 & 1) * 8);
 
+  int blk_first, blk_second;
+  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), blk_first, blk_second);
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-    const int kvb = (pass == 0) ? bx : (nkb - 1 - bx);
-    if (pass == 1 && kvb <= bx) break;
+    const int kvb = (pass == 0) ? blk_first : blk_second;
+    if (kvb < 0) break;
     const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
     const int key = kv0w + fr, keyc = min(key, L - 1);
     KeyLaneMask<CAUSAL> kmask;
@@ -1202,7 +1248,9 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   hipStream_t st = (hipStream_t)stream;
   const int nb = (L + 127) / 128;
   const int nxr = causal ? (nb + 1) / 2 : nb;
-  const int nx = nxr | (map_mode << 16);
+  static int pair_mode = -1;      // RV_ATTN_PAIR=0: the plain (x, n-1-x) pairing (A/B knob); default: pair_blocks
+  if (pair_mode < 0) { const char* e = getenv("RV_ATTN_PAIR"); pair_mode = e ? atoi(e) : 1; }
+  const int nx = nxr | (map_mode << 16) | ((pair_mode ? 1 : 0) << 20);
   dim3 grid(nxr * H * S), block(256);
   static bool attr_done = false;
   if (!attr_done) {
@@ -1250,7 +1298,9 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   static int map_mode = -1;
   if (map_mode < 0) { const char* e = getenv("RV_ATTN_MAP"); map_mode = e ? atoi(e) : 1; }
   const int nxr = causal ? (nb + 1) / 2 : nb;
-  const int nx = nxr | (map_mode << 16);
+  static int pair_mode = -1;
+  if (pair_mode < 0) { const char* e = getenv("RV_ATTN_PAIR"); pair_mode = e ? atoi(e) : 1; }
+  const int nx = nxr | (map_mode << 16) | ((pair_mode ? 1 : 0) << 20);
   dim3 grid(nxr * H * S), block(256);
   hipStream_t st = (hipStream_t)stream;
   constexpr int DQ_LDS = 4 * 64 * 256;

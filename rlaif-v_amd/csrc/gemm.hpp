@@ -37,6 +37,16 @@
 #define GEMM_THREADS 256
 #define GEMM_LDS_BYTES (2 * 2 * GEMM_BM * GEMM_BK * 2)  // 2 buffers x (A,B) x 16 KiB
 
+// Tuning words set by rv_set_gemm_tuning (device globals read with volatile loads AT THE POINT OF USE - as kernel
+// arguments they would stay live in SGPRs across the main loops, which are within a few registers of spilling):
+//   [0] scheduling experiments of the 64-deep-A NN kernel (0 = off):
+//       bits 0-7 : XCD stagger - the first-round workgroup (blockIdx < 256) on XCD i sleeps i * n * s_sleep(127) (~4.6 us
+//                  each) before its prologue, so the 8 XCDs reach their epilogues at different times and the output bursts
+//                  (128-512 KB per workgroup, all 256 CUs at once) no longer hit HBM in the same 10-30 us window;
+//       bit 16   : serpentine - odd row groups walk the column tiles backwards (the turn-around round re-uses its B panel);
+//   [1] reserved.
+__device__ int rv_dev_tuning[2] = {0, 0};
+
 struct GemmShape {
   const bf16_t* A; const bf16_t* B;
   int M, N, K;
@@ -1049,7 +1059,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   const int first_m = (id / group_size) * GROUP;
   const int gsz = min(tiles_m - first_m, GROUP);
   const int tile_m = first_m + (id % group_size) % gsz;
-  const int tile_n = (id % group_size) / gsz;
+  int tile_n = (id % group_size) / gsz;
+  {
+    const int flags = __builtin_amdgcn_readfirstlane(*(volatile int*)&rv_dev_tuning[0]);
+    if (((flags >> 16) & 1) && ((first_m / GROUP) & 1)) tile_n = tiles_n - 1 - tile_n;
+    if ((flags & 0xff) && blockIdx.x < 256) {            // XCD stagger; block b runs on XCD b % 8
+      const int nsleep = (int)(blockIdx.x & 7) * (flags & 0xff);
+      for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
   const long ldb = g.ldb;
 
@@ -1291,6 +1309,29 @@ __device__ __forceinline__ uint32_t gemm_mix32(uint32_t h) {    // same mixer as
   return h;
 }
 
+// Compile-time in the shipped library (a run-time policy branch around the asm stores made hipcc spill the dominant
+// kernel: 106 SGPRs + 528 B of scratch): experiment builds pass -DRV_EPI_CPOL=1|2 (rlaif-v_amd/build.py defines/tag).
+#ifndef RV_EPI_CPOL
+#define RV_EPI_CPOL 0
+#endif
+__device__ __forceinline__ constexpr int epi_cpol_now() { return RV_EPI_CPOL; }
+// Output stores with a cache policy (rv_set_gemm_tuning key 1): 0 = plain (the line stays in the XCD's L2), 1 = sc1
+// (written through and dropped from L2: the 128-512 KB a workgroup writes per tile do not evict the operand panels the
+// next round re-reads), 2 = nt.  MI355X_MICROARCH.md "stores of each flavour".
+__device__ __forceinline__ void epi_store16(void* p, const uint4& v, int cpol) {
+  if (cpol == 0) { *(uint4*)p = v; return; }
+  const u32x4_t r = {v.x, v.y, v.z, v.w};
+  if (cpol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(r) : "memory");
+}
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ void epi_store8(void* p, const uint2& v, int cpol) {
+  if (cpol == 0) { *(uint2*)p = v; return; }
+  const u32x2_t r = {v.x, v.y};
+  if (cpol == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(r) : "memory");
+}
+
 struct EpiStore {
   bf16_t* C; long ldc;
   const bf16_t* bias;
@@ -1307,6 +1348,7 @@ struct EpiStore {
   // load) instructions - the epilogue of a 1-workgroup-per-CU kernel is store-ISSUE bound and nothing overlaps it.
   __device__ __forceinline__ void apply_wide(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
     const int half = lane >> 5;
+    const int cpol = epi_cpol_now();
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int m = mw + tm * 32 + (lane & 31);
@@ -1354,7 +1396,7 @@ struct EpiStore {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rr[j];
           }
-          *(uint4*)(C + (long)m * ldc + n) = epi_pack8(v);
+          epi_store16(C + (long)m * ldc + n, epi_pack8(v), cpol);
         }
       }
     }
@@ -1424,6 +1466,7 @@ struct EpiSwiGLU {
   bf16_t* ACT; long lda;      // activation [M][N/2]
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
     const int half = lane >> 5;
+    const int cpol = epi_cpol_now();
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int m = mw + tm * 32 + (lane & 31);
@@ -1443,7 +1486,7 @@ struct EpiSwiGLU {
           const int n = nw + tn * 32 + rgp * 16 + 8 * half;
           if (n >= N) continue;
           const uint4 pk = epi_pack8(v);
-          *(uint4*)(C + (long)m * ldc + n) = pk;
+          epi_store16(C + (long)m * ldc + n, pk, cpol);
           float r[8];
           epi_unpack8(pk, r);
           float o[4];
@@ -1452,7 +1495,7 @@ struct EpiSwiGLU {
           uint2 w;
           w.x = pack2bf(o[0], o[1]);
           w.y = pack2bf(o[2], o[3]);
-          *(uint2*)(ACT + (long)m * lda + (n >> 1)) = w;
+          epi_store8(ACT + (long)m * lda + (n >> 1), w, cpol);
         }
       }
     }
@@ -1467,6 +1510,7 @@ struct EpiSwiGLUBwd {
   bf16_t* DGU; long lddgu;
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
     const int half = lane >> 5;
+    const int cpol = epi_cpol_now();
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int m = mw + tm * 32 + (lane & 31);
@@ -1498,8 +1542,8 @@ struct EpiSwiGLUBwd {
             if (j < 4) { o0[2 * j] = dg; o0[2 * j + 1] = du; } else { o1[2 * (j - 4)] = dg; o1[2 * (j - 4) + 1] = du; }
           }
           bf16_t* dp = DGU + (long)m * lddgu + 2 * n;
-          *(uint4*)dp = epi_pack8(o0);
-          *(uint4*)(dp + 8) = epi_pack8(o1);
+          epi_store16(dp, epi_pack8(o0), cpol);
+          epi_store16(dp + 8, epi_pack8(o1), cpol);
         }
       }
     }

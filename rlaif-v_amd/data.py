@@ -154,7 +154,8 @@ class SyntheticPreferenceDataset(torch.utils.data.Dataset):
                  image_pos: int = 35, seed: int = 0, ragged: bool = False, omnilmm: Optional[dict] = None):
         """``omnilmm`` = dict(tokens=(im_patch, im_start, im_end), num_query=, tower_tokens=, width=): the OmniLMM token
         convention (<im_start> <im_patch> x num_query <im_end> inside the prompt, omnilmm.py:221-257) and, as ``image``,
-        precomputed tower tokens [tower_tokens, width] (the tower is frozen; rlaif-v_amd/omnilmm.py)."""
+        precomputed tower tokens [tower_tokens, width] (the tower is frozen; rlaif-v_amd/omnilmm.py) - or, with
+        ``pixels=True`` in the dict, a [3, image_size, image_size] pixel tensor for the model's own tower."""
         self.n, self.vocab, self.text_len, self.prompt_len = n, vocab, text_len, prompt_len
         self.image_size, self.image_pos, self.seed, self.ragged = image_size, min(image_pos, prompt_len - 2), seed, ragged
         self.omnilmm = omnilmm
@@ -179,7 +180,10 @@ class SyntheticPreferenceDataset(torch.utils.data.Dataset):
             pt, st, en = o["tokens"]
             nq, a = o["num_query"], self.image_pos
             prompt[a], prompt[a + 1:a + 1 + nq], prompt[a + 1 + nq] = st, pt, en
-            image = torch.randn(o["tower_tokens"], o["width"], generator=g).to(torch.bfloat16)
+            if o.get("pixels"):      # pixel input: the model runs its vision tower (rlaif-v_amd/eva_tower.py)
+                image = torch.randn(3, self.image_size, self.image_size, generator=g)
+            else:
+                image = torch.randn(o["tower_tokens"], o["width"], generator=g).to(torch.bfloat16)
         out = []
         for tag in ("rej", "win"):
             if self.ragged:

@@ -110,6 +110,57 @@ class EvaTower:
         w["norm.w"], w["norm.b"] = dev16(t("norm.weight")), dev16(t("norm.bias"))
         self._pos = {}
 
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        """Random weights of the full architecture drawn directly on the device (benchmarks: no checkpoint exists offline;
+        4.4 B parameters = 8.8 GB bf16 at the EVA02-E defaults), in the padded-head layout load_state_dict builds."""
+        c, dev = self.cfg, self.device
+        d, H, hd = c.width, c.heads, c.head_dim
+        g = torch.Generator(device=dev).manual_seed(seed)
+        Kp = ops.round_up(3 * c.patch * c.patch, 64)
+
+        def rn(*shape):
+            return (torch.randn(*shape, device=dev, generator=g) * std).to(BF16)
+
+        def ln():
+            return torch.ones(d, dtype=BF16, device=dev), torch.zeros(d, dtype=BF16, device=dev)
+
+        w = self.w
+        w["patch_w"] = rn(d, Kp)
+        w["patch_w"][:, 3 * c.patch * c.patch:] = 0
+        w["patch_b"], w["cls"] = rn(d), rn(d)
+        self._pos_raw = (torch.randn(1 + c.pretrain_grid ** 2, d, generator=torch.Generator().manual_seed(seed)) * std)
+        head_mask = torch.zeros(3, H, 128, 1, device=dev, dtype=BF16)
+        head_mask[:, :, :hd] = 1                                     # columns hd..127 of every head are zero padding
+        for i in range(c.blocks_used):
+            w[f"{i}.wqkv"] = (rn(3, H, 128, d) * head_mask).reshape(3 * H * 128, d)
+            bq = rn(3, H, 128) * head_mask[..., 0]
+            bq[1] = 0                                                # EvaAttention: no key bias
+            w[f"{i}.bqkv"] = bq.reshape(-1)
+            w[f"{i}.wo"] = (rn(d, H, 128) * head_mask[0, :, :, 0]).reshape(d, H * 128)
+            w[f"{i}.bo"] = rn(d)
+            for n in ("norm1", "norm2"):
+                w[f"{i}.{n}.w"], w[f"{i}.{n}.b"] = ln()
+            w[f"{i}.fc1.w"], w[f"{i}.fc1.b"] = rn(c.mlp, d), rn(c.mlp)
+            w[f"{i}.fc2.w"], w[f"{i}.fc2.b"] = rn(d, c.mlp), rn(d)
+        w["norm.w"], w["norm.b"] = ln()
+        self._pos = {}
+        return self
+
+    def n_params(self) -> int:
+        """Parameters of the un-padded architecture (accounting)."""
+        c = self.cfg
+        d = c.width
+        per_block = 3 * d * d + 2 * d + d * d + d + 4 * d + 2 * d * c.mlp + c.mlp + d
+        return c.blocks_used * per_block + d * 3 * c.patch * c.patch + 2 * d + (1 + c.pretrain_grid ** 2) * d + 2 * d
+
+    def flops_per_image(self, image_size: int) -> float:
+        """Algorithmic forward FLOPs of one image (head dim 112, no padding counted)."""
+        c = self.cfg
+        T = (image_size // c.patch) ** 2 + 1
+        d = c.width
+        per_tok = 2 * d * 3 * d + 2 * d * d + 4 * d * c.mlp + 4 * T * d
+        return c.blocks_used * T * per_tok + 2.0 * (T - 1) * d * 3 * c.patch * c.patch
+
     def pos(self, grid: int) -> torch.Tensor:
         if grid not in self._pos:
             self._pos[grid] = resample_pos_embed(self._pos_raw, self.cfg.pretrain_grid, grid).to(BF16).to(self.device).contiguous()

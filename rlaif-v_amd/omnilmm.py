@@ -10,7 +10,9 @@ the vision-to-language adapter (projector -> ``resampler.Resampler``), its param
 the splice planner.  Pinned by tests/golden/omnilmm_tiny.pt (the reference's own classes).
 
 The vision tower: timm's ``eva02_enormous_patch14_clip_224`` (omnilmm.py:31-43) is not vendored in the reference and timm is
-absent offline, so no oracle of it can be pinned; the tower is frozen in this path, its output is a pure function of the
+absent offline, so no oracle of it can be pinned; the tower is frozen in this path (``OmniLMMConfig.tune_clip = False``, the
+reference's initialize_vision_modules default; the constructor default tune_clip=True would train it - a documented
+deviation), its output is a pure function of the
 image, and ``images`` may therefore be handed over as PRECOMPUTED tower tokens [B, N, width] (3-D tensor) - which is also
 what one would cache across the 4 epochs of a run.  Pixel input goes through a tower registered with ``set_vision_tower``
 (any callable pixels -> [B, N, width]); ``rlaif-v_amd/eva_tower.py`` restates timm's EVA02-E/14 on the HIP kernels - PARITY
@@ -42,6 +44,13 @@ class OmniLMMConfig(LlavaConfig):
     im_patch_token: int = 32000
     im_start_token: int = 32001
     im_end_token: int = 32002
+    # How the reference holds its tower (omnilmm/model/omnilmm.py): ``tune_clip=False`` - the default of
+    # initialize_vision_modules (:74, :93) - keeps it in a plain list, OUT of the module's parameters: no optimizer ever
+    # sees it although, lacking a no_grad (:107-119), gradients still flow into it; ``tune_clip=True`` - the CONSTRUCTOR
+    # default (:58, :69-70; chat.py loads inference checkpoints that way) - registers it and a trainer built on
+    # model.parameters() then trains its 4.3 B weights.  This path implements tune_clip=False: the tower is frozen, its
+    # output is a pure function of the pixels (which is also what makes precomputed tower tokens legal input).
+    tune_clip: bool = False
 
     arch = "omnilmm"
 
@@ -61,6 +70,10 @@ class OmniLMMConfig(LlavaConfig):
 
 class OmniLMMDPOModel(LlavaDPOModel):
     def __init__(self, cfg: OmniLMMConfig, device="cuda:0", with_optimizer: bool = True, lora: Optional[LoraConfig] = None):
+        if cfg.tune_clip:
+            raise NotImplementedError("OmniLMMConfig.tune_clip=True (the tower as a trained submodule, omnilmm/model/omnilmm.py:58,"
+                                      "69-70) is not implemented: this path keeps the EVA02 tower frozen, i.e. the reference's "
+                                      "tune_clip=False arrangement (initialize_vision_modules default, :74,:93)")
         super().__init__(cfg, device, with_optimizer, lora)
         self.resampler = Resampler(cfg.hidden, cfg.vision_width, cfg.num_query, self.device)
         self._tower: Optional[Callable[[torch.Tensor], torch.Tensor]] = None

@@ -161,11 +161,26 @@ def main():
     losses, cw, cr = dpo_loss(pw, pr, batch["ref_win_logp"], batch["ref_rej_logp"], beta=batch["beta"])
     loss = losses.mean()
     loss.backward()
+    # What the reference does with its tower (omnilmm.py:58,69-70,107-119): under the constructor default tune_clip=True it is
+    # a registered submodule and - there being no no_grad around forward_features - RECEIVES gradients; with tune_clip=False
+    # (initialize_vision_modules' default) the same module sits in a plain list: still differentiated through, but invisible to
+    # model.parameters() and therefore to any optimizer.  The product implements the second arrangement (frozen tower); the
+    # fixture records both facts instead of silently dropping the tower's gradients.
+    tower_named = [k for k, _ in model.named_parameters() if "vision_tower" in k]
+    tower_gnorm = float(sum(float(v.grad.double().pow(2).sum()) for k, v in model.named_parameters()
+                            if "vision_tower" in k and v.grad is not None) ** 0.5)
+    frozen_style = OmniLMMForCausalLM(ocfg, tune_clip=False)
+    tower_meta = dict(tune_clip_true=dict(tower_params_registered=len(tower_named) > 0, tower_receives_grad=tower_gnorm > 0,
+                                          tower_grad_norm=tower_gnorm),
+                      tune_clip_false=dict(tower_params_registered=any("vision_tower" in k for k, _ in frozen_style.named_parameters()),
+                                           tower_is_list=isinstance(frozen_style.model.vision_tower, list)))
+    del frozen_style
     grads = compress_grads({k: v.grad for k, v in model.named_parameters() if v.grad is not None and "vision_tower" not in k})
     with torch.no_grad():
         logits = model(input_ids=batch["concatenated_input_ids"], images=cat_images).logits
     out["dpo"] = dict(batch=batch, tower_features=tf, logp=logp.detach(), loss=loss.detach(), losses=losses.detach(),
                       chosen_rewards=cw.detach(), rejected_rewards=cr.detach(), grads=grads, logits=logits[:, :, :].clone())
+    out["tower_trainability"] = tower_meta
     out["meta"] = dict(num_query=NUM_QUERY, kv_dim=KV_DIM, tokens=TOKENS, resampler_heads=cfg.hidden // 128,
                        pos_embed=model.model.resampler.pos_embed.detach().clone())
     path = os.path.join(REPO, "tests", "golden", "omnilmm_tiny.pt")

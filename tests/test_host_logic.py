@@ -459,3 +459,36 @@ def test_omnilmm_config_json_round_trip():
     # the LLaVA dictionary is untouched
     lc = importlib.import_module("rlaif-v_amd.model").LlavaConfig()
     assert ck.hf_config_dict(lc)["model_type"] == "llava_llama" and ck.config_from_hf(ck.hf_config_dict(lc)) == lc
+
+
+def test_omni_preprocess_matches_reference_golden(golden_dir):
+    """omni_preprocess (OmniLMM chat-template encoding + response-only labels, omnilmm/train/train_utils.py:50-151) and the
+    chat.py wrappers vs the reference's OWN function over the toy tokenizer (tests/golden/make_omni_preprocess_golden.py):
+    single turn with an image span, two rounds, a trailing question, and a text truncated before any assistant marker."""
+    import copy
+    import warnings
+    sys.path.insert(0, golden_dir)
+    from toy_tokenizer import OMNI_CONVERSATIONS, OmniToyTokenizer
+    from rlaif_v_amd.omni_data import expand_question_into_multimodal, omni_preprocess, wrap_question_for_omni_lmm
+    gold = torch.load(os.path.join(golden_dir, "omni_preprocess.pt"), weights_only=False)
+    tok = OmniToyTokenizer()
+    for mode, gen in (("train", False), ("generation", True)):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            d = omni_preprocess([copy.deepcopy(c) for c in OMNI_CONVERSATIONS], tok, generation=gen)
+        for got_ids, got_lab, ref in zip(d["input_ids"], d["labels"], gold[mode]):
+            assert torch.equal(got_ids, ref["input_ids"]) and torch.equal(got_lab, ref["labels"]), mode
+        assert any("Could not find key" in str(x.message) for x in w)         # the truncated sample warns, like the reference
+    # labels cover exactly the answers: sample 1 has two answers, sample 2 drops the trailing question
+    lab = d["labels"][1]
+    assert int((gold["train"][1]["labels"] != -100).sum()) == 8 + 8 and int((lab != -100).sum()) >= 16
+    # chat.py surface: <image> tag -> <im_start> + patches + <im_end>, generation prompt appended
+    q = expand_question_into_multimodal([{"role": "user", "content": "<image>\nWhat ?"}], 3, "<im_start>", "<im_end>", "<im_patch>")
+    assert q[0]["content"] == "<im_start><im_patch><im_patch><im_patch><im_end>\nWhat ?"
+    q = expand_question_into_multimodal([{"role": "user", "content": "What ?"}], 2, "<im_start>", "<im_end>", "<im_patch>")
+    assert q[0]["content"] == "<im_start><im_patch><im_patch><im_end>\nWhat ?"
+    out = wrap_question_for_omni_lmm("What is this ?", 4, tok)
+    ids = out["input_ids"].tolist()
+    assert ids.count(9) == 4 and ids[-2:] == [6, 3]                            # 4 patches; ends with "<|assistant|>\n"
+    with pytest.raises(AssertionError):
+        omni_preprocess([[{"role": "user", "content": "a"}, {"role": "user", "content": "b"}]], tok)

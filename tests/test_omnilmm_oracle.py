@@ -84,3 +84,17 @@ def test_splice_keeps_length_and_raises_like_reference():
     bad[0, p + 17] = 5                   # <im_end> missing behind the patches
     with pytest.raises(ValueError):
         OO.omnilmm_splice(bad, emb, feats, *tokens)
+
+
+def test_tower_trainability_is_recorded_not_dropped(golden_dir):
+    """The reference trains its tower under the constructor default (tune_clip=True: registered submodule, gradients flow -
+    omnilmm/model/omnilmm.py:58,69-70,107-119) and hides it from every optimizer under tune_clip=False (:74,:93).  The fixture
+    records both facts from the reference's own classes; the product implements the second and refuses the first."""
+    import os
+    import torch
+    g = torch.load(os.path.join(golden_dir, "omnilmm_tiny.pt"), weights_only=False)["tower_trainability"]
+    assert g["tune_clip_true"]["tower_params_registered"] and g["tune_clip_true"]["tower_receives_grad"]
+    assert g["tune_clip_true"]["tower_grad_norm"] > 0
+    assert g["tune_clip_false"]["tower_is_list"] and not g["tune_clip_false"]["tower_params_registered"]
+    from rlaif_v_amd.omnilmm import OmniLMMConfig
+    assert OmniLMMConfig().tune_clip is False

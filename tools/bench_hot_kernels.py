@@ -52,6 +52,32 @@ def main():
             out = torch.empty(R, N, device=dev, dtype=BF)
             ms = timeit(lambda: ops.gemm_nn(x, wT, out=out), a.iters)
             print(f"nn {name:8s} {R}x{N}x{K}: {ms:.3f} ms {2.0 * R * N * K / ms / 1e9:7.1f} TF/s", flush=True)
+        # fused-epilogue instantiations of the same NN main loop next to the plain kernel on the same shape
+        x = torch.randn(R, 4096, device=dev).to(BF)
+        wguT = (torch.randn(4096, 22016, device=dev) * 0.02).to(BF)
+        ms = timeit(lambda: ops.linear_swiglu(x, wguT), a.iters)
+        print(f"nn_swiglu     {R}x22016x4096: {ms:.3f} ms {2.0 * R * 22016 * 4096 / ms / 1e9:7.1f} TF/s", flush=True)
+        dy = torch.randn(R, 4096, device=dev).to(BF)
+        wdown = (torch.randn(4096, 11008, device=dev) * 0.02).to(BF)
+        gu = torch.randn(R, 22016, device=dev).to(BF)
+        ms = timeit(lambda: ops.linear_swiglu_bwd(dy, wdown, gu), a.iters)
+        print(f"nn_swiglu_bwd {R}x11008x4096: {ms:.3f} ms {2.0 * R * 11008 * 4096 / ms / 1e9:7.1f} TF/s", flush=True)
+        out = torch.empty(R, 11008, device=dev, dtype=BF)
+        ms = timeit(lambda: ops.gemm_nn(dy, wdown, out=out), a.iters)
+        print(f"nn plain      {R}x11008x4096: {ms:.3f} ms {2.0 * R * 11008 * 4096 / ms / 1e9:7.1f} TF/s", flush=True)
+        del x, wguT, dy, wdown, gu, out
+        n_sel, V = 22544, 32000                     # 8 pairs x 2 x 1409 target rows
+        h = torch.randn(n_sel, 4096, device=dev).to(BF)
+        wl = (torch.randn(V, 4096, device=dev) * 0.02).to(BF)
+        tgt = torch.randint(0, V, (n_sel,), device=dev, dtype=torch.int32)
+        logp, lse = ops.lmhead_logp_fwd(h, wl, tgt, n_sel)
+        ms = timeit(lambda: ops.lmhead_logp_fwd(h, wl, tgt, n_sel), a.iters)
+        print(f"lmhead_fwd {n_sel}x{V}x4096: {ms:.3f} ms {2.0 * n_sel * V * 4096 / ms / 1e9:7.1f} TF/s", flush=True)
+        coef = torch.full((n_sel,), -0.01, device=dev)
+        dl = torch.zeros(n_sel, V, dtype=BF, device=dev)
+        ms = timeit(lambda: ops.lmhead_logp_bwd(h, wl, tgt, lse, coef, n_sel, out=dl), a.iters)
+        print(f"lmhead_bwd {n_sel}x{V}x4096: {ms:.3f} ms {2.0 * n_sel * V * 4096 / ms / 1e9:7.1f} TF/s", flush=True)
+        del h, wl, dl
         for name, I, J in [("wqkv", 12288, 4096), ("wo", 4096, 4096), ("wgu", 22016, 4096), ("wdown", 4096, 11008)]:
             p = torch.randn(R, I, device=dev).to(BF)
             q = torch.randn(R, J, device=dev).to(BF)

@@ -57,6 +57,7 @@ def main():
             log(f"[{case}] HIP path: {time.time() - t0:.1f} s (first call, includes warm-up), loss {hip[case]['loss']:.6f}")
         del model, trainer
         torch.cuda.empty_cache()
+        open(os.path.join(args.out, ".hip_done"), "w").write("done\n")        # the GPU is free from here on
     report = dict(host=dict(cpus=os.cpu_count(), threads=args.threads, torch=torch.__version__), layers=args.layers)
     W0 = {k: v.clone() for k, v in W.items() if not k.startswith(O.VT)} if "cfg1_step" in cases else None
     for case in cases:
