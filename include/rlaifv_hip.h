@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 3
+#define RV_ABI_VERSION 4
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
@@ -65,20 +65,21 @@ int rv_gemm_nn_swiglu_bwd_bf16(const void* A, long lda, const void* B, long ldb,
 
 /* Fused LoRA GEMM (peft LoraLayer.forward as used by muffin/train/train_llava15_lora.py:304-318):
  *   C[m][n] = sum_{k<K} A[m][k] B[n][k] + sum_{q<K2} A2[m][c0(n)+q] B2[n][q] (+ residual[m][n]),
- *   c0(n) = group_cols ? (n / group_cols) * K2 : 0.
+ *   c0(n) = group_cols ? group(n) * K2 : 0,  group(n) = n < group0 ? 0 : 1 + (n - group0) / group_cols  (group0 = 0: = group_cols;
+ *   grouped-query attention: group0 = hidden (q), group_cols = kv_dim (k, v)).
  * The adapter contribution is two extra steps of the SAME K loop (operand tiles fetched from A2/B2), so
  * the base output is never re-read.  Forward: A = x, B = W, A2 = t = (alpha/r) x A_lora^T [M, G*r], B2 = stacked
  * lora_B [N, r], group_cols = rows of one fused projection (q|k|v, gate|up).  Input gradient: A = dy, B = W^T,
  * A2 = dt [M, G*r], B2 = stacked lora_A^T [N, G*r], group_cols = 0.  K2 multiple of 64; group_cols multiple of 128. */
 int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
-                         long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
+                         long ldb2, int K2, int group_cols, int group0, void* C, long ldc, int M, int N, int K,
                          const void* residual, long ldr, void* stream);
 
 /* NN form of rv_gemm_nt_lora_bf16: B is [K][N], B2 is [K2][N] (both row-major); A2 as there.  Forward: B = W^T copy,
  * B2 = stacked lora_B^T [r][N]; input gradient: B = W, B2 = stacked lora_A [G*r][N], group_cols = 0.  K, K2 % 32 == 0;
  * group_cols a multiple of 256. */
 int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
-                         long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
+                         long ldb2, int K2, int group_cols, int group0, void* C, long ldc, int M, int N, int K,
                          const void* residual, long ldr, void* stream);
 
 /* C = dropout_{p,seed}(alpha * A B^T) + residual: rv_gemm_nt_bf16 whose result is masked with exactly the mask

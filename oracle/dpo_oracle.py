@@ -391,7 +391,8 @@ def make_lora_weights(cfg: LlavaCfg, r: int, seed: int = 1, b_std: Optional[floa
     parity tests exercise a non-trivial adapter."""
     g = torch.Generator().manual_seed(seed)
     d, f = cfg.hidden, cfg.ffn
-    dims = {"self_attn.q_proj": (d, d), "self_attn.k_proj": (d, d), "self_attn.v_proj": (d, d), "self_attn.o_proj": (d, d),
+    kvd = cfg.n_kv_heads * cfg.head_dim                     # grouped-query attention: k / v projections are [kv_dim, hidden]
+    dims = {"self_attn.q_proj": (d, d), "self_attn.k_proj": (kvd, d), "self_attn.v_proj": (kvd, d), "self_attn.o_proj": (d, d),
             "mlp.gate_proj": (f, d), "mlp.up_proj": (f, d), "mlp.down_proj": (d, f)}
     out: Dict[str, torch.Tensor] = {}
     for i in range(cfg.layers):

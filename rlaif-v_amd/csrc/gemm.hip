@@ -133,7 +133,7 @@ template <class Epi>
 static int dispatch_ext(const GemmShape& g, const Epi& epi, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const long t256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
-  if (t256 >= 192 && g.group_cols % G2_BN == 0) {
+  if (t256 >= 192 && g.group_cols % G2_BN == 0 && g.group0 % G2_BN == 0) {
     constexpr int LDS = 4 * G2_STAGE_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
@@ -285,17 +285,18 @@ int rv_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, void* C, l
 }
 
 int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
-                         long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
+                         long ldb2, int K2, int group_cols, int group0, void* C, long ldc, int M, int N, int K,
                          const void* residual, long ldr, void* stream) {
   if (M == 0 || N == 0) return 0;
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group,
-              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols};
+              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols, group0};
   if (check_shape(g, "rv_gemm_nt_lora_bf16")) return 1;
   RV_REQUIRE(K2 > 0 && K2 % GEMM_BK == 0, "rv_gemm_nt_lora_bf16: K2 must be a positive multiple of 64");
   RV_REQUIRE(lda2 % 8 == 0 && ldb2 % 8 == 0 && ((((uintptr_t)A2 | (uintptr_t)B2) & 15) == 0),
              "rv_gemm_nt_lora_bf16: A2/B2 must be 16-byte aligned with leading dimensions multiples of 8");
-  RV_REQUIRE(group_cols == 0 || (group_cols % GEMM_BN == 0 && N % group_cols == 0),
-             "rv_gemm_nt_lora_bf16: group_cols must be 0 or a multiple of 128 that divides N");
+  RV_REQUIRE(group_cols == 0 || (group_cols % GEMM_BN == 0 && group0 % GEMM_BN == 0 && group0 >= 0 && group0 <= N &&
+                                 (N - (group0 ? group0 : group_cols)) % group_cols == 0),
+             "rv_gemm_nt_lora_bf16: group_cols / group0 must be multiples of 128 that tile N (group0 + k * group_cols = N)");
   RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_lora_bf16: ldc/ldr must be multiples of 4");
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, 1.0f};
   epi.narrow = epi_narrow();
@@ -368,7 +369,7 @@ int rv_gemm_nn_swiglu_bwd_bf16(const void* A, long lda, const void* B, long ldb,
 }
 
 int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
-                         long ldb2, int K2, int group_cols, void* C, long ldc, int M, int N, int K,
+                         long ldb2, int K2, int group_cols, int group0, void* C, long ldc, int M, int N, int K,
                          const void* residual, long ldr, void* stream) {
   if (M == 0 || N == 0) return 0;
   RV_REQUIRE(K > 0 && K % G2_BK == 0 && K2 > 0 && K2 % G2_BK == 0, "rv_gemm_nn_lora_bf16: K and K2 must be positive multiples of 32");
@@ -377,10 +378,11 @@ int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const
              "rv_gemm_nn_lora_bf16: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
   RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15) == 0,
              "rv_gemm_nn_lora_bf16: operands must be 16-byte aligned");
-  RV_REQUIRE(group_cols == 0 || (group_cols % G2_BN == 0 && N % group_cols == 0),
-             "rv_gemm_nn_lora_bf16: group_cols must be 0 or a multiple of 256 that divides N");
+  RV_REQUIRE(group_cols == 0 || (group_cols % G2_BN == 0 && group0 % G2_BN == 0 && group0 >= 0 && group0 <= N &&
+                                 (N - (group0 ? group0 : group_cols)) % group_cols == 0),
+             "rv_gemm_nn_lora_bf16: group_cols / group0 must be multiples of 256 that tile N (group0 + k * group_cols = N)");
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group,
-              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols};
+              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols, group0};
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, 1.0f};
   epi.narrow = epi_narrow();
   static bool attr_done = false;

@@ -53,13 +53,21 @@ struct GemmShape {
   long lda, ldb;
   int group;     // row tiles per scheduling group (tile order inside an XCD chunk); 0 = kernel default
   // Optional second contraction segment (kernels instantiated with EXT = true; the fused LoRA GEMM):
-  //   D[m][n] += sum_{q < K2} A2[m][c0(n) + q] * B2[n][q],   c0(n) = group_cols ? (n / group_cols) * K2 : 0
+  //   D[m][n] += sum_{q < K2} A2[m][c0(n) + q] * B2[n][q],   c0(n) = group_cols ? group(n) * K2 : 0,
+  //   group(n) = n < group0 ? 0 : 1 + (n - group0) / group_cols   (group0 = 0 means group0 = group_cols: uniform groups;
+  //   grouped-query attention: q is `hidden` wide, k and v `kv_dim` wide -> group0 = hidden, group_cols = kv_dim)
   // i.e. the K loop simply runs K2 / BK further steps whose tiles come from (A2, B2).  group_cols must be a
   // multiple of the N tile so that c0 is uniform per workgroup.
   const bf16_t* A2; const bf16_t* B2;
   long lda2, ldb2;
   int K2, group_cols;
+  int group0;
 };
+
+__device__ __forceinline__ int ext_group(int n0, int group0, int group_cols) {
+  const int g0 = group0 > 0 ? group0 : group_cols;
+  return n0 < g0 ? 0 : 1 + (n0 - g0) / group_cols;
+}
 
 __device__ __forceinline__ uint32_t gemm_lds_off(int row, int kc) {
   return (uint32_t)(row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, E
 
   const int nt1 = g.K / GEMM_BK;
   const int nt = nt1 + (EXT ? g.K2 / GEMM_BK : 0);
-  const int a2_col0 = (EXT && g.group_cols > 0) ? (n0 / g.group_cols) * g.K2 : 0;
+  const int a2_col0 = (EXT && g.group_cols > 0) ? ext_group(n0, g.group0, g.group_cols) * g.K2 : 0;
   u32x4_t ra_[4], rb_[4];
 
   auto issue = [&](int t, int buf) {
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nt_256_kernel(GemmShape g,
   const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
   const int nt1 = g.K / G2_BK;
   const int nt = nt1 + (EXT ? g.K2 / G2_BK : 0);
-  const int a2_col0 = (EXT && g.group_cols > 0) ? (n0 / g.group_cols) * g.K2 : 0;
+  const int a2_col0 = (EXT && g.group_cols > 0) ? ext_group(n0, g.group0, g.group_cols) * g.K2 : 0;
 
   auto issue_piece = [&](int t, int j) {   // j: 0 = A piece 0, 1 = B piece 0, 2 = A piece 1, 3 = B piece 1
     uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
@@ -886,7 +894,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
   const uint32_t piece0 = (uint32_t)(wave * 2) * 1024u;
   const int nt1 = g.K / G2_BK;
   const int nt = nt1 + (EXT ? g.K2 / G2_BK : 0);
-  const int a2_col0 = (EXT && g.group_cols > 0) ? (n0 / g.group_cols) * g.K2 : 0;
+  const int a2_col0 = (EXT && g.group_cols > 0) ? ext_group(n0, g.group0, g.group_cols) * g.K2 : 0;
   auto issue_piece = [&](int t, int j) {   // j: 0 = A piece 0, 1 = B piece 0, 2 = A piece 1, 3 = B piece 1
     uint8_t* st = smem + (t % NST) * G2_STAGE_BYTES;
     const int i = j >> 1;
@@ -1143,7 +1151,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   const int nt1 = g.K / G2_BK;                          // 32-deep phases of the main segment (even)
   const int nt = nt1 + (EXT ? g.K2 / G2_BK : 0);        // + the second segment
   const int ntA1 = nt1 >> 1, ntA = nt >> 1;             // 64-deep A tiles
-  const int a2_col0 = (EXT && g.group_cols > 0) ? (n0 / g.group_cols) * g.K2 : 0;
+  const int a2_col0 = (EXT && g.group_cols > 0) ? ext_group(n0, g.group0, g.group_cols) * g.K2 : 0;
   // generic sources (any tile of either segment), rebuilt per piece
   auto a_tile_src = [&](int T, int i) -> const bf16_t* {          // piece i (0..3) of A tile T
     const int row = (wave * 4 + i) * 8 + (lane >> 3);

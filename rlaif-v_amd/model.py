@@ -141,6 +141,13 @@ LORA_GROUPS = {"qkv": ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj
                "gu": ("mlp.gate_proj", "mlp.up_proj"), "down": ("mlp.down_proj",)}
 
 
+def lora_group_rows(cfg: "LlavaConfig", grp: str) -> List[Tuple[int, int]]:
+    """(first output row, rows) of every peft module inside a fused projection: q | k | v have widths hidden, kv_dim, kv_dim
+    (grouped-query attention: kv_dim < hidden), gate | up are ffn each."""
+    d, kvd, f = cfg.hidden, cfg.kv_dim, cfg.ffn
+    return {"qkv": [(0, d), (d, kvd), (d + kvd, kvd)], "o": [(0, d)], "gu": [(0, f), (f, f)], "down": [(0, d)]}[grp]
+
+
 def _is_decay(name: str) -> bool:
     return not (name.endswith("bias") or "norm" in name)
 
@@ -152,8 +159,6 @@ class ParamStore:
         d, f, V, cd, kvd = cfg.hidden, cfg.ffn, cfg.vocab_padded, cfg.clip_hidden, cfg.kv_dim
         if cfg.heads % cfg.n_kv_heads != 0:
             raise ValueError("kv_heads must divide heads")
-        if lora is not None and kvd != d:
-            raise NotImplementedError("LoRA with grouped-query attention: the fused q|k|v adapter groups assume equal widths")
         Entry = Tuple[str, Tuple[int, ...], bool]        # (key, shape, needs transposed copy); fused keys map to HF names
         self.lora = lora
         # Full fine-tune: the fused gate|up weight stores its rows INTERLEAVED (row 2j = gate_j, 2j+1 = up_j) so that the GEMM
@@ -184,7 +189,7 @@ class ParamStore:
                 decay += [(f"layers.{i}.lora_down.B", (d, rp), True), (f"layers.{i}.lora_down.A", (rp, f), True),
                           (f"layers.{i}.lora_gu.B", (2 * f, rp), True), (f"layers.{i}.lora_gu.A", (2 * rp, d), True),
                           (f"layers.{i}.lora_o.B", (d, rp), True), (f"layers.{i}.lora_o.A", (rp, d), True),
-                          (f"layers.{i}.lora_qkv.B", (3 * d, rp), True), (f"layers.{i}.lora_qkv.A", (3 * rp, d), True)]
+                          (f"layers.{i}.lora_qkv.B", (d + 2 * kvd, rp), True), (f"layers.{i}.lora_qkv.A", (3 * rp, d), True)]
             decay += proj_w
             nodecay = proj_b
         self.entries = frozen + decay + nodecay
@@ -301,14 +306,13 @@ class ParamStore:
         if self.lora is None:
             return m
         r, rp, d, f = self.lora.r, self.lora.r_pad, cfg.hidden, cfg.ffn
-        out_rows = {"qkv": d, "o": d, "gu": f, "down": d}
         in_cols = {"qkv": d, "o": d, "gu": d, "down": f}
         for i in range(cfg.layers):
             for grp, mods in LORA_GROUPS.items():
-                for gi, mod in enumerate(mods):
+                for gi, (mod, (r0, rows)) in enumerate(zip(mods, lora_group_rows(cfg, grp))):
                     p = f"model.layers.{i}.{mod}."
                     m[p + "lora_A.weight"] = (f"layers.{i}.lora_{grp}.A", gi * rp, r, in_cols[grp])
-                    m[p + "lora_B.weight"] = (f"layers.{i}.lora_{grp}.B", gi * out_rows[grp], out_rows[grp], r)
+                    m[p + "lora_B.weight"] = (f"layers.{i}.lora_{grp}.B", r0, rows, r)
         return m
 
 
@@ -499,14 +503,12 @@ class LlavaDPOModel:
         if self.lora is None:
             return
         st, cfg, rp, sc = self.store, self.cfg, self.lora.r_pad, self.lora.scaling
-        rows = {"qkv": cfg.hidden, "o": cfg.hidden, "gu": cfg.ffn, "down": cfg.hidden}
         for i in range(cfg.layers):
-            for grp, mods in LORA_GROUPS.items():
+            for grp in LORA_GROUPS:
                 W, B, AT = st.p(f"layers.{i}.w{grp}"), st.p(f"layers.{i}.lora_{grp}.B"), st.pT(f"layers.{i}.lora_{grp}.A")
-                for gi in range(len(mods)):
-                    r0 = gi * rows[grp]
-                    Wg = W[r0:r0 + rows[grp]]
-                    ops.gemm_nt(B[r0:r0 + rows[grp]], AT[:, gi * rp:(gi + 1) * rp], out=Wg, residual=Wg, alpha=sc)
+                for gi, (r0, rows) in enumerate(lora_group_rows(cfg, grp)):
+                    Wg = W[r0:r0 + rows]
+                    ops.gemm_nt(B[r0:r0 + rows], AT[:, gi * rp:(gi + 1) * rp], out=Wg, residual=Wg, alpha=sc)
                 B.zero_()
         st.sync_master_from_params()
         st.refresh_transposes()
@@ -592,7 +594,12 @@ class LlavaDPOModel:
         return None
 
     # ------------------------------------------------------------------ decoder projections (+ LoRA)
-    _GROUP_COLS = {"qkv": "hidden", "o": None, "gu": "ffn", "down": None}
+    def _lora_grouping(self, grp: str) -> Tuple[int, int]:
+        """(group_cols, group0) of the fused LoRA GEMM for a fused projection (rv_gemm_nt_lora_bf16)."""
+        cfg = self.cfg
+        if grp == "qkv":
+            return cfg.kv_dim, (cfg.hidden if cfg.kv_dim != cfg.hidden else 0)
+        return (cfg.ffn, 0) if grp == "gu" else (0, 0)
 
     def _proj_fwd(self, x: torch.Tensor, i: int, grp: str, residual: Optional[torch.Tensor] = None,
                   drop_slot: int = 0):
@@ -606,10 +613,9 @@ class LlavaDPOModel:
         if self.training and self.lora.lora_dropout > 0.0:
             xd = ops.dropout(x, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
         t = ops.gemm_nt(x if xd is None else xd, st.p(f"layers.{i}.lora_{grp}.A"), alpha=self.lora.scaling)
-        gc = self._GROUP_COLS[grp]
+        gc, g0 = self._lora_grouping(grp)
         y = ops.linear_lora(x, W, st.pT(f"layers.{i}.w{grp}"), t, st.p(f"layers.{i}.lora_{grp}.B"),
-                            st.pT(f"layers.{i}.lora_{grp}.B"), group_cols=getattr(self.cfg, gc) if gc else 0,
-                            residual=residual)
+                            st.pT(f"layers.{i}.lora_{grp}.B"), group_cols=gc, residual=residual, group0=g0)
         return y, t, (xd if self.keep_dropped_inputs else None)
 
     def _dropout_seed(self, layer: int, slot: int) -> int:
@@ -627,12 +633,12 @@ class LlavaDPOModel:
             return dx
         rp, sc = self.lora.r_pad, self.lora.scaling
         akey, bkey = f"layers.{i}.lora_{grp}.A", f"layers.{i}.lora_{grp}.B"
-        G = len(LORA_GROUPS[grp])
-        og = dy.shape[1] // G
-        BT = st.pT(bkey)                                              # [rp, G*og]
+        groups = lora_group_rows(self.cfg, grp)                       # (first output column, width) per peft module
+        G = len(groups)
+        BT = st.pT(bkey)                                              # [rp, total output width]
         dt = torch.empty(dy.shape[0], G * rp, dtype=BF16, device=self.device)
-        for g in range(G):                                            # dt_g = (alpha/r) dy_g B_g
-            ops.gemm_nt(dy[:, g * og:(g + 1) * og], BT[:, g * og:(g + 1) * og], out=dt[:, g * rp:(g + 1) * rp], alpha=sc)
+        for g, (c0, og) in enumerate(groups):                         # dt_g = (alpha/r) dy_g B_g
+            ops.gemm_nt(dy[:, c0:c0 + og], BT[:, c0:c0 + og], out=dt[:, g * rp:(g + 1) * rp], alpha=sc)
         if self.training and self.lora.lora_dropout > 0.0:
             # dropout sits on the adapter branch only: dx = dy W + mask * (dt A) / (1 - p)
             dx = ops.linear(dy, st.pT(wkey), st.p(wkey))
@@ -644,8 +650,8 @@ class LlavaDPOModel:
             dx = ops.linear_lora(dy, st.pT(wkey), st.p(wkey), dt, st.pT(akey), st.p(akey), group_cols=0)
         ops.gemm_tn_skinny(dt, xin, out=st.g(akey))
         gB = st.g(bkey)
-        for g in range(G):
-            ops.gemm_tn_skinny(dy[:, g * og:(g + 1) * og], t[:, g * rp:(g + 1) * rp], out=gB[g * og:(g + 1) * og])
+        for g, (c0, og) in enumerate(groups):
+            ops.gemm_tn_skinny(dy[:, c0:c0 + og], t[:, g * rp:(g + 1) * rp], out=gB[c0:c0 + og])
         return dx
 
     def _layer_fwd(self, i: int, x: torch.Tensor, plan: SplicePlan, cos, sin, save: bool):

@@ -90,53 +90,64 @@ def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def _lora_groups(N: int, group_cols: int, group0: int) -> int:
+    """Number of adapter column groups of an N-wide fused projection: the first group0 columns (0 = group_cols), then
+    groups of group_cols (grouped-query attention: q is hidden wide, k and v kv_dim wide)."""
+    if not group_cols:
+        return 1
+    g0 = group0 or group_cols
+    if g0 > N or (N - g0) % group_cols:
+        raise ValueError(f"fused LoRA GEMM: groups {g0} + k x {group_cols} do not tile N = {N}")
+    return 1 + (N - g0) // group_cols
+
+
 def gemm_nt_lora(a: torch.Tensor, b: torch.Tensor, a2: torch.Tensor, b2: torch.Tensor, group_cols: int = 0,
-                 out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, group0: int = 0) -> torch.Tensor:
     """out = a @ b^T + a2[:, c0(n) : c0(n)+K2] @ b2^T (+ residual): the fused LoRA GEMM (rv_gemm_nt_lora_bf16).
-    K2 = b2.shape[1]; c0(n) = (n // group_cols) * K2 when group_cols > 0 (fused q|k|v, gate|up), else 0."""
+    K2 = b2.shape[1]; c0(n) = group(n) * K2 when group_cols > 0 (fused q|k|v, gate|up; _lora_groups), else 0."""
     _chk2d(a, "a"), _chk2d(b, "b"), _chk2d(a2, "a2"), _chk2d(b2, "b2")
     M, K = a.shape
     N, K2 = b2.shape
     if b.shape != (N, K) or a2.shape[0] != M:
         raise ValueError(f"gemm_nt_lora: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} a2{tuple(a2.shape)} b2{tuple(b2.shape)}")
-    groups = N // group_cols if group_cols else 1
+    groups = _lora_groups(N, group_cols, group0)
     if a2.shape[1] != groups * K2:
         raise ValueError(f"gemm_nt_lora: a2 must have {groups} x {K2} columns, got {a2.shape[1]}")
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
     _chk2d(out, "out")
     hip.call("rv_gemm_nt_lora_bf16", a, a.stride(0), b, b.stride(0), a2, a2.stride(0), b2, b2.stride(0), K2,
-             int(group_cols), out, out.stride(0), M, N, K, residual, residual.stride(0) if residual is not None else 0)
+             int(group_cols), int(group0), out, out.stride(0), M, N, K, residual, residual.stride(0) if residual is not None else 0)
     return out
 
 
 def gemm_nn_lora(a: torch.Tensor, b: torch.Tensor, a2: torch.Tensor, b2: torch.Tensor, group_cols: int = 0,
-                 out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, group0: int = 0) -> torch.Tensor:
     """NN form of gemm_nt_lora: b [K, N] and b2 [K2, N] row-major (rv_gemm_nn_lora_bf16)."""
     _chk2d(a, "a"), _chk2d(b, "b"), _chk2d(a2, "a2"), _chk2d(b2, "b2")
     M, K = a.shape
     K2, N = b2.shape
     if b.shape != (K, N) or a2.shape[0] != M:
         raise ValueError(f"gemm_nn_lora: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} a2{tuple(a2.shape)} b2{tuple(b2.shape)}")
-    groups = N // group_cols if group_cols else 1
+    groups = _lora_groups(N, group_cols, group0)
     if a2.shape[1] != groups * K2:
         raise ValueError(f"gemm_nn_lora: a2 must have {groups} x {K2} columns, got {a2.shape[1]}")
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
     _chk2d(out, "out")
     hip.call("rv_gemm_nn_lora_bf16", a, a.stride(0), b, b.stride(0), a2, a2.stride(0), b2, b2.stride(0), K2,
-             int(group_cols), out, out.stride(0), M, N, K, residual, residual.stride(0) if residual is not None else 0)
+             int(group_cols), int(group0), out, out.stride(0), M, N, K, residual, residual.stride(0) if residual is not None else 0)
     return out
 
 
 def linear_lora(x: torch.Tensor, w: torch.Tensor, wT: torch.Tensor, a2: torch.Tensor, b2: torch.Tensor, b2T: torch.Tensor,
-                group_cols: int = 0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                group_cols: int = 0, residual: Optional[torch.Tensor] = None, group0: int = 0) -> torch.Tensor:
     """y = x @ w^T + a2[:, group block] @ b2^T (+ residual) with both weight orientations at hand (w [N, K], wT [K, N],
     b2 [N, K2], b2T [K2, N]): the NN kernel for chip-filling problems with 256-aligned groups, else the NT kernels."""
     M, N = x.shape[0], w.shape[0]
-    if ((M + 255) // 256) * ((N + 255) // 256) >= 192 and group_cols % 256 == 0 and N % 8 == 0:
-        return gemm_nn_lora(x, wT[:, :N], a2, b2T[:, :N], group_cols=group_cols, residual=residual)
-    return gemm_nt_lora(x, w, a2, b2, group_cols=group_cols, residual=residual)
+    if ((M + 255) // 256) * ((N + 255) // 256) >= 192 and group_cols % 256 == 0 and group0 % 256 == 0 and N % 8 == 0:
+        return gemm_nn_lora(x, wT[:, :N], a2, b2T[:, :N], group_cols=group_cols, residual=residual, group0=group0)
+    return gemm_nt_lora(x, w, a2, b2, group_cols=group_cols, residual=residual, group0=group0)
 
 
 def gemm_nt_dropout(a: torch.Tensor, b: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None,

@@ -54,10 +54,29 @@ def _oracle_grads(batch, W, cfg, scale, masks=None):
 @pytest.mark.parametrize("r", [16, 64])
 def test_lora_forward_backward_vs_oracle(monkeypatch, r, share_prefix):
     """r = 16 exercises the zero padding of the stored rank to the GEMM K step (64)."""
+    _lora_fwd_bwd_case(monkeypatch, O.tiny_cfg(), r, share_prefix)
+
+
+def test_lora_gqa_forward_backward_vs_oracle(monkeypatch):
+    """LoRA on a grouped-query model (OmniLMM's Zephyr / Mistral arrangement: 4 query heads on 2 key/value heads): the fused
+    q|k|v projection has adapter groups of UNEQUAL width (hidden, kv_dim, kv_dim) - rv_gemm_nt_lora_bf16 group0 / group_cols."""
+    cfg = O.tiny_gqa_cfg()
+    model = _lora_fwd_bwd_case(monkeypatch, cfg, 16, True)
+    B = model.store.p("layers.0.lora_qkv.B")
+    assert B.shape[0] == cfg.hidden + 2 * cfg.n_kv_heads * cfg.head_dim
+    # merge_and_unload on the unequal groups: merged model == adapter model
+    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=8)
+    args = (batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"])
+    a = model.eval().forward_logps(*args, save_for_backward=False).seq_logp.clone()
+    model.merge_lora()
+    b = model.forward_logps(*args, save_for_backward=False).seq_logp
+    assert bool(((a - b).abs() <= 2e-3 * a.abs()).all()), (a.tolist(), b.tolist())
+
+
+def _lora_fwd_bwd_case(monkeypatch, cfg, r, share_prefix):
     _need_gpu()
     monkeypatch.setenv("SFT_weight", "0.0")
     monkeypatch.setenv("DPO_weight", "1.0")
-    cfg = O.tiny_cfg()
     model, W = _build(cfg, r, share_prefix=share_prefix)
     model.train()
     tr = _trainer(model)
@@ -92,6 +111,7 @@ def test_lora_forward_backward_vs_oracle(monkeypatch, r, share_prefix):
         gA = model.store.g("layers.0.lora_qkv.A")
         assert gA[r:64].abs().sum() == 0 and gA[64 + r:128].abs().sum() == 0
         assert model.store.g("layers.0.lora_down.B")[:, r:].abs().sum() == 0
+    return model
 
 
 def test_lora_zero_b_is_bit_identical_to_base(monkeypatch):
