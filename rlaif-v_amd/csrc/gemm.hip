@@ -225,6 +225,16 @@ static int launch_nn_epi(const GemmShape& g, const Epi& epi, hipStream_t st) {
     attr_done = true;
   }
   const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+#ifdef RV_NN_PERSIST      // experiment build: persistent tile loop, one workgroup per CU (gemm.hpp PERSIST)
+  if (g.K % 64 == 0 && g.K >= 512 && nn_mi16()) {
+    static bool p_done = false;
+    if (!p_done) { hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<Epi, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES); p_done = true; }
+    const int nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<Epi, false, true, true>), dim3(nwg < RV_NN_PERSIST ? nwg : RV_NN_PERSIST), dim3(G2_THREADS), G4_LDS_BYTES, st, g, epi);
+    RV_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   if (g.K % 64 == 0 && g.K >= 512 && nn_mi16())
     hipLaunchKernelGGL((gemm_nn_a64_kernel<Epi, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES, st, g, epi);
   else if (g.K % 64 == 0 && g.K >= 512)
@@ -327,6 +337,17 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
     attr_done = true;
   }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
+#ifdef RV_NN_PERSIST
+  if (use_a64 && K % 64 == 0 && K >= 512 && nn_mi16()) {
+    static bool p_done = false;
+    if (!p_done) { hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES); p_done = true; }
+    const int nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, false, true, true>), dim3(nwg < RV_NN_PERSIST ? nwg : RV_NN_PERSIST), dim3(G2_THREADS),
+                       G4_LDS_BYTES, (hipStream_t)stream, g, epi);
+    RV_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   if (use_a64 && K % 64 == 0 && K >= 512 && nn_mi16())
     hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
                        (hipStream_t)stream, g, epi);

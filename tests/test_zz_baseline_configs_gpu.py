@@ -200,10 +200,20 @@ def test_full_depth_config1_step(full_depth, golden_dir):
     _record("config1_full_depth_step", m)
 
 
-@pytest.mark.parametrize("share_prefix", [False, True])
-def test_fullwidth_reference_golden(golden_dir, share_prefix, monkeypatch):
-    """Production widths through the reference classes themselves (tests/golden/make_golden.py --full-width)."""
+@pytest.mark.parametrize("share_prefix,mi16", [(False, 1), (True, 1), (True, 0)])
+def test_fullwidth_reference_golden(golden_dir, share_prefix, mi16, monkeypatch):
+    """Production widths through the reference classes themselves (tests/golden/make_golden.py --full-width).  mi16 = 0 runs the
+    whole model on the 32x32x16-MFMA main loops (rv_set_gemm_mi16(0)) so that path stays covered end to end."""
     _need_big_gpu()
+    from rlaif_v_amd import hip
+    hip.lib().call("rv_set_gemm_mi16", mi16)
+    try:
+        _fullwidth_golden_case(golden_dir, share_prefix, monkeypatch, f"_mi16_{mi16}")
+    finally:
+        hip.lib().call("rv_set_gemm_mi16", 1)
+
+
+def _fullwidth_golden_case(golden_dir, share_prefix, monkeypatch, tag):
     g = torch.load(os.path.join(golden_dir, "fullwidth_l2_b2.pt"), weights_only=False)
     monkeypatch.setenv("SFT_weight", str(g["sft_weight"]))
     monkeypatch.setenv("DPO_weight", "1.0")
@@ -232,4 +242,4 @@ def test_fullwidth_reference_golden(golden_dir, share_prefix, monkeypatch):
         assert _cos(grads[k], gr) >= 0.99, k
     assert _cos(grads["model.embed_tokens.weight"].double().sum(-1), g["grad_embed_rowsum"]) >= 0.99
     rec.update(grad_worst_norm_rel_err=worst)
-    _record(f"fullwidth_reference_golden_share{int(share_prefix)}", rec)
+    _record(f"fullwidth_reference_golden_share{int(share_prefix)}{tag}", rec)
