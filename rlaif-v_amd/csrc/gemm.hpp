@@ -1050,6 +1050,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
 // EXT: second contraction segment (A2 slices / B2 [K2][N], K2 % 64 == 0: the fused LoRA form).  The steady loop only
 // covers phases whose fetches lie in the main segment; the few phases around the seam and the adapter's own K2/32
 // phases run in the generic form (addresses rebuilt on the fly, full drain per phase).
+template <class T>
+__device__ __forceinline__ void kernarg_copy(T& dst, const __attribute__((address_space(4))) char* src) {
+  static_assert(sizeof(T) % 4 == 0, "kernel argument structs are dword multiples");
+  const __attribute__((address_space(4))) uint32_t* p = (const __attribute__((address_space(4))) uint32_t*)src;
+  uint32_t* d = (uint32_t*)&dst;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d[i] = p[i];
+}
+
 // PERSIST (experiment, -DRV_NN_PERSIST launches it with one workgroup per CU): the workgroup loops over tiles blockIdx.x,
 // blockIdx.x + gridDim.x, ... and issues the NEXT tile's prologue DMA (A0 B0 A1 B1 B2 into the idle LDS rings) before it
 // converts and stores the current accumulators, so the first fetch latency of a tile and the workgroup launch hide under
@@ -1057,21 +1066,39 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
 // retired the last phase's fragment reads.  The first wait of a later tile is vmcnt(0) (the epilogue's own loads / stores
 // and the prologue DMA do not retire in a common order).
 template <class Epi, bool EXT = false, bool MI16 = false, bool PERSIST = false>
-__global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g, Epi epi) {
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g_arg, Epi epi_arg) {
   static_assert(!(PERSIST && EXT), "the persistent tile loop exists for the plain (single-segment) form only");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const smA = smem;
   uint8_t* const smB = smem + 3 * G4_A_STAGE;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane_id = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
+  int tile_iter = blockIdx.x;
+  int m0 = 0, n0 = 0;                          // origin of the tile whose operands are being fetched (carried between tiles)
+  bool first_tile = true;
+  for (;;) {                                   // one pass per output tile (PERSIST: several; otherwise exactly one)
+  // PERSIST: the kernel arguments are re-read from the kernarg segment at the top of every tile (scalar loads through an
+  // opaque pointer) instead of living in ~40 SGPRs across the loop - carried that way hipcc spilled 70 SGPRs and, through
+  // them, VGPRs inside the main loop.
+  int lane = lane_id;
+  if constexpr (PERSIST) asm volatile("" : "+v"(lane));   // nothing lane-derived is loop invariant: hipcc otherwise hoists the
+                                                          // address / epilogue lane constants of ALL tiles above the main loop
+  GemmShape g = g_arg;
+  Epi epi = epi_arg;
+  if constexpr (PERSIST) {
+    typedef const __attribute__((address_space(4))) char* kptr_t;
+    kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    kernarg_copy(g, ka);
+    kernarg_copy(epi, ka + ((sizeof(GemmShape) + alignof(Epi) - 1) / alignof(Epi)) * alignof(Epi));
+  }
   const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
   const int nwg = tiles_m * tiles_n;
   const int GROUP = g.group > 0 ? g.group : 4;
   const int group_size = GROUP * tiles_n;
   const int flags = __builtin_amdgcn_readfirstlane(*(volatile int*)&rv_dev_tuning[0]);
-  int m0, n0;                                            // origin of the tile whose operands are being fetched
   auto set_tile = [&](int it) {                          // it = position in the launch order (blockIdx.x + k * gridDim.x)
     const int id = xcd_remap(it, nwg);
     const int first_m = (id / group_size) * GROUP;
@@ -1082,11 +1109,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
     m0 = tile_m * G2_BM;
     n0 = tile_n * G2_BN;
   };
-  int tile_iter = blockIdx.x;
-  set_tile(tile_iter);
-  if ((flags & 0xff) && blockIdx.x < 256) {              // XCD stagger; block b runs on XCD b % 8
-    const int nsleep = (int)(blockIdx.x & 7) * (flags & 0xff);
-    for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(127);
+  if (first_tile) {
+    set_tile(tile_iter);
+    if ((flags & 0xff) && blockIdx.x < 256) {            // XCD stagger; block b runs on XCD b % 8
+      const int nsleep = (int)(blockIdx.x & 7) * (flags & 0xff);
+      for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(127);
+    }
   }
   const long ldb = g.ldb;
 
@@ -1113,6 +1141,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
       b_src[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
     }
   };
+  if (PERSIST && !first_tile) asm volatile("" : "+s"(m0), "+s"(n0));     // rebuilt, not kept alive across the previous epilogue
   set_src();
   const uint32_t a_piece0 = (uint32_t)(wave * 4) * 1024u, b_piece0 = (uint32_t)(wave * 2) * 1024u;
   auto issue_a = [&](int T, int i, const bf16_t* src) {      // piece i (0..3) of A tile T
@@ -1181,9 +1210,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
 #pragma unroll
     for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt1 > 2 ? 2 : 1) * G2_BK * ldb);
   };
-  issue_prologue();
-  bool first_tile = true;
-  for (;;) {                                   // one pass per output tile (PERSIST: several; otherwise exactly one)
   if (MI16) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -1198,12 +1224,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
         for (int r = 0; r < 16; ++r) acc[MI16 ? 0 : i][j][r] = 0.f;
   }
   if (PERSIST && !first_tile) {
-    // the sources of this tile were built once already (for its prologue, before the previous tile's epilogue); they are
-    // REBUILT here from the two scalars instead of being kept alive across that epilogue (12 VGPRs hipcc had to spill)
-    asm volatile("" : "+s"(m0), "+s"(n0));
-    set_src();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's prologue was issued before the previous epilogue
   } else {
+    issue_prologue();
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
