@@ -29,10 +29,6 @@ int rv_abi_version(void);
  * (more flops per joule under the package power cap, profiles/r02_mfma_shape_power_probe.log); 0 = the 32x32x16 loops.
  * Same results to fp32 accumulation order. */
 int rv_set_gemm_mi16(int on);
-/* Tuning knob of the 256x256 GEMMs (A/B experiments; default = the shipped schedule): key 0 = scheduling flags of the
- * 64-deep-A NN kernel (bits 0-7: XCD stagger steps, bit 16: serpentine column order).  Environment: RV_GEMM_STAGGER,
- * RV_GEMM_SERP. */
-int rv_set_gemm_tuning(int key, int value);
 /* GEMM kernel selection: -1 = auto (default), 0 = 128x128x64 register-staged, 1 = 128x128x64 global_load_lds,
  * 2 = 256x256x32 ping-pong (two wave groups alternating MFMA / load segments). */
 int rv_set_gemm_variant(int variant);

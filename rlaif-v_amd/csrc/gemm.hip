@@ -20,24 +20,6 @@ static int epi_narrow() {
   if (v < 0) { const char* e = getenv("RV_EPI_WIDE"); v = (e && atoi(e) == 0) ? 1 : 0; }
   return v;
 }
-// rv_set_gemm_tuning -> device words rv_dev_tuning[key] (gemm.hpp); the environment (RV_GEMM_STAGGER, RV_GEMM_SERP,
-// is applied once, before the first NN launch; the epilogue store policy is a compile-time knob (-DRV_EPI_CPOL)
-static int push_tuning(int key, int value) {
-  if (hipMemcpyToSymbol(HIP_SYMBOL(rv_dev_tuning), &value, sizeof(int), key * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-    rv_set_error("rv_set_gemm_tuning: hipMemcpyToSymbol failed");
-    return 2;
-  }
-  return 0;
-}
-static void tuning_env_once() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  const char* a = getenv("RV_GEMM_STAGGER");
-  const char* b = getenv("RV_GEMM_SERP");
-  const int flags = ((a ? atoi(a) : 0) & 0xff) | ((b && atoi(b)) ? (1 << 16) : 0);
-  if (flags) push_tuning(0, flags);
-}
 static void read_group_env() {
   static bool env_done = false;
   if (!env_done) { const char* e = getenv("RV_GEMM_GROUP"); if (e) g_group = atoi(e); env_done = true; }
@@ -216,7 +198,6 @@ static int check_shape(const GemmShape& g, const char* who) {
 // NN GEMM with one of the SwiGLU epilogues: the 64-deep-A kernel when K allows, else the 32-deep one
 template <class Epi>
 static int launch_nn_epi(const GemmShape& g, const Epi& epi, hipStream_t st) {
-  tuning_env_once();
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_nn_256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
@@ -225,16 +206,6 @@ static int launch_nn_epi(const GemmShape& g, const Epi& epi, hipStream_t st) {
     attr_done = true;
   }
   const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
-#ifdef RV_NN_PERSIST      // experiment build: persistent tile loop, one workgroup per CU (gemm.hpp PERSIST)
-  if (g.K % 64 == 0 && g.K >= 512 && nn_mi16()) {
-    static bool p_done = false;
-    if (!p_done) { hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<Epi, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES); p_done = true; }
-    const int nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_nn_a64_kernel<Epi, false, true, true>), dim3(nwg < RV_NN_PERSIST ? nwg : RV_NN_PERSIST), dim3(G2_THREADS), G4_LDS_BYTES, st, g, epi);
-    RV_CHECK_LAUNCH();
-    return 0;
-  }
-#endif
   if (g.K % 64 == 0 && g.K >= 512 && nn_mi16())
     hipLaunchKernelGGL((gemm_nn_a64_kernel<Epi, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES, st, g, epi);
   else if (g.K % 64 == 0 && g.K >= 512)
@@ -260,13 +231,6 @@ int rv_abi_version(void) { return RV_ABI_VERSION; }
 int rv_set_gemm_mi16(int on) {
   g_mi16 = on ? 1 : 0;
   return 0;
-}
-
-int rv_set_gemm_tuning(int key, int value) {
-  RV_REQUIRE(key == 0, "rv_set_gemm_tuning: key 0 (NN scheduling flags)");
-  RV_REQUIRE(value >= 0, "rv_set_gemm_tuning: value out of range");
-  tuning_env_once();
-  return push_tuning(key, value);
 }
 
 int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
@@ -322,7 +286,6 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
              "rv_gemm_nn_bf16: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
   RV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "rv_gemm_nn_bf16: A/B must be 16-byte aligned");
   read_group_env();
-  tuning_env_once();
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
   epi.narrow = epi_narrow();
@@ -337,17 +300,6 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
     attr_done = true;
   }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
-#ifdef RV_NN_PERSIST
-  if (use_a64 && K % 64 == 0 && K >= 512 && nn_mi16()) {
-    static bool p_done = false;
-    if (!p_done) { hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES); p_done = true; }
-    const int nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, false, true, true>), dim3(nwg < RV_NN_PERSIST ? nwg : RV_NN_PERSIST), dim3(G2_THREADS),
-                       G4_LDS_BYTES, (hipStream_t)stream, g, epi);
-    RV_CHECK_LAUNCH();
-    return 0;
-  }
-#endif
   if (use_a64 && K % 64 == 0 && K >= 512 && nn_mi16())
     hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
                        (hipStream_t)stream, g, epi);

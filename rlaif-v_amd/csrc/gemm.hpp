@@ -37,16 +37,6 @@
 #define GEMM_THREADS 256
 #define GEMM_LDS_BYTES (2 * 2 * GEMM_BM * GEMM_BK * 2)  // 2 buffers x (A,B) x 16 KiB
 
-// Tuning words set by rv_set_gemm_tuning (device globals read with volatile loads AT THE POINT OF USE - as kernel
-// arguments they would stay live in SGPRs across the main loops, which are within a few registers of spilling):
-//   [0] scheduling experiments of the 64-deep-A NN kernel (0 = off):
-//       bits 0-7 : XCD stagger - the first-round workgroup (blockIdx < 256) on XCD i sleeps i * n * s_sleep(127) (~4.6 us
-//                  each) before its prologue, so the 8 XCDs reach their epilogues at different times and the output bursts
-//                  (128-512 KB per workgroup, all 256 CUs at once) no longer hit HBM in the same 10-30 us window;
-//       bit 16   : serpentine - odd row groups walk the column tiles backwards (the turn-around round re-uses its B panel);
-//   [1] reserved.
-__device__ int rv_dev_tuning[2] = {0, 0};
-
 struct GemmShape {
   const bf16_t* A; const bf16_t* B;
   int M, N, K;
@@ -1050,72 +1040,25 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
 // EXT: second contraction segment (A2 slices / B2 [K2][N], K2 % 64 == 0: the fused LoRA form).  The steady loop only
 // covers phases whose fetches lie in the main segment; the few phases around the seam and the adapter's own K2/32
 // phases run in the generic form (addresses rebuilt on the fly, full drain per phase).
-template <class T>
-__device__ __forceinline__ void kernarg_copy(T& dst, const __attribute__((address_space(4))) char* src) {
-  static_assert(sizeof(T) % 4 == 0, "kernel argument structs are dword multiples");
-  const __attribute__((address_space(4))) uint32_t* p = (const __attribute__((address_space(4))) uint32_t*)src;
-  uint32_t* d = (uint32_t*)&dst;
-#pragma unroll
-  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) d[i] = p[i];
-}
-
-// PERSIST (experiment, -DRV_NN_PERSIST launches it with one workgroup per CU): the workgroup loops over tiles blockIdx.x,
-// blockIdx.x + gridDim.x, ... and issues the NEXT tile's prologue DMA (A0 B0 A1 B1 B2 into the idle LDS rings) before it
-// converts and stores the current accumulators, so the first fetch latency of a tile and the workgroup launch hide under
-// the previous tile's epilogue.  LDS is safe to refill after the re-balancing barrier: by then both wave groups have
-// retired the last phase's fragment reads.  The first wait of a later tile is vmcnt(0) (the epilogue's own loads / stores
-// and the prologue DMA do not retire in a common order).
-template <class Epi, bool EXT = false, bool MI16 = false, bool PERSIST = false>
-__global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g_arg, Epi epi_arg) {
-  static_assert(!(PERSIST && EXT), "the persistent tile loop exists for the plain (single-segment) form only");
+template <class Epi, bool EXT = false, bool MI16 = false>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const smA = smem;
   uint8_t* const smB = smem + 3 * G4_A_STAGE;
-  const int tid = threadIdx.x, lane_id = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  int tile_iter = blockIdx.x;
-  int m0 = 0, n0 = 0;                          // origin of the tile whose operands are being fetched (carried between tiles)
-  bool first_tile = true;
-  for (;;) {                                   // one pass per output tile (PERSIST: several; otherwise exactly one)
-  // PERSIST: the kernel arguments are re-read from the kernarg segment at the top of every tile (scalar loads through an
-  // opaque pointer) instead of living in ~40 SGPRs across the loop - carried that way hipcc spilled 70 SGPRs and, through
-  // them, VGPRs inside the main loop.
-  int lane = lane_id;
-  if constexpr (PERSIST) asm volatile("" : "+v"(lane));   // nothing lane-derived is loop invariant: hipcc otherwise hoists the
-                                                          // address / epilogue lane constants of ALL tiles above the main loop
-  GemmShape g = g_arg;
-  Epi epi = epi_arg;
-  if constexpr (PERSIST) {
-    typedef const __attribute__((address_space(4))) char* kptr_t;
-    kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    kernarg_copy(g, ka);
-    kernarg_copy(epi, ka + ((sizeof(GemmShape) + alignof(Epi) - 1) / alignof(Epi)) * alignof(Epi));
-  }
   const int tiles_m = (g.M + G2_BM - 1) / G2_BM, tiles_n = (g.N + G2_BN - 1) / G2_BN;
   const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
   const int GROUP = g.group > 0 ? g.group : 4;
   const int group_size = GROUP * tiles_n;
-  const int flags = __builtin_amdgcn_readfirstlane(*(volatile int*)&rv_dev_tuning[0]);
-  auto set_tile = [&](int it) {                          // it = position in the launch order (blockIdx.x + k * gridDim.x)
-    const int id = xcd_remap(it, nwg);
-    const int first_m = (id / group_size) * GROUP;
-    const int gsz = min(tiles_m - first_m, GROUP);
-    const int tile_m = first_m + (id % group_size) % gsz;
-    int tile_n = (id % group_size) / gsz;
-    if (((flags >> 16) & 1) && ((first_m / GROUP) & 1)) tile_n = tiles_n - 1 - tile_n;
-    m0 = tile_m * G2_BM;
-    n0 = tile_n * G2_BN;
-  };
-  if (first_tile) {
-    set_tile(tile_iter);
-    if ((flags & 0xff) && blockIdx.x < 256) {            // XCD stagger; block b runs on XCD b % 8
-      const int nsleep = (int)(blockIdx.x & 7) * (flags & 0xff);
-      for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
+  const int first_m = (id / group_size) * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tile_m = first_m + (id % group_size) % gsz;
+  const int tile_n = (id % group_size) / gsz;
+  const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
   const long ldb = g.ldb;
 
   // ---- A pieces: wave w owns pieces 4w .. 4w+3 of a 64-deep tile; piece = 8 rows x 128 B, LDS image row*128 +
@@ -1123,26 +1066,22 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g_
   //      B pieces: 2 k-rows x 512 B, as gemm_nn_256_kernel.
   const bf16_t* a_src[4];
   const bf16_t* b_src[2];
-  auto set_src = [&]() {                                 // first-tile sources of the tile at (m0, n0)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave * 4 + i) * 8 + (lane >> 3);
-      const int kc = (lane & 7) ^ ((row >> 1) & 7);
-      a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8;
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((row >> 1) & 7);
+    a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+  }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wave * 2 + i) * 2 + (lane >> 5);
-      const int c = lane & 31;
-      // MI16: k rows 8..15 and 24..31 additionally swap the two 32-byte halves of every 64-byte block, so that the two
-      // 16-lane groups of a transposing read (k rows 8 apart, same 16 columns) hit disjoint banks
-      const int slot = MI16 ? ((c & 3) ^ (((r >> 3) & 1) << 1)) : (c & 3);
-      const int col = (((c >> 2) ^ (r & 3)) << 5) + (slot << 3);
-      b_src[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
-    }
-  };
-  if (PERSIST && !first_tile) asm volatile("" : "+s"(m0), "+s"(n0));     // rebuilt, not kept alive across the previous epilogue
-  set_src();
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 2 + (lane >> 5);
+    const int c = lane & 31;
+    // MI16: k rows 8..15 and 24..31 additionally swap the two 32-byte halves of every 64-byte block, so that the two
+    // 16-lane groups of a transposing read (k rows 8 apart, same 16 columns) hit disjoint banks
+    const int slot = MI16 ? ((c & 3) ^ (((r >> 3) & 1) << 1)) : (c & 3);
+    const int col = (((c >> 2) ^ (r & 3)) << 5) + (slot << 3);
+    b_src[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
+  }
   const uint32_t a_piece0 = (uint32_t)(wave * 4) * 1024u, b_piece0 = (uint32_t)(wave * 2) * 1024u;
   auto issue_a = [&](int T, int i, const bf16_t* src) {      // piece i (0..3) of A tile T
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -1177,6 +1116,19 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g_
 
   f32x16_t acc[MI16 ? 1 : 4][2];
   f32x4_t acc16[MI16 ? 8 : 1][4];
+  if (MI16) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc16[MI16 ? i : 0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[MI16 ? 0 : i][j][r] = 0.f;
+  }
 
   const int nt1 = g.K / G2_BK;                          // 32-deep phases of the main segment (even)
   const int nt = nt1 + (EXT ? g.K2 / G2_BK : 0);        // + the second segment
@@ -1198,37 +1150,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g_
     return g.B + ((long)t * G2_BK + r) * ldb + col;
   };
   // prologue: A0 B0 | A1 B1 B2  (K >= 256 is required by the launcher, so these all lie in the main segment)
-  auto issue_prologue = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_a(0, i, a_src[i]);
+  for (int i = 0; i < 4; ++i) issue_a(0, i, a_src[i]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) issue_b(0, i, b_src[i]);
+  for (int i = 0; i < 2; ++i) issue_b(0, i, b_src[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_a(1, i, a_src[i] + (ntA1 > 1 ? 64 : 0));
+  for (int i = 0; i < 4; ++i) issue_a(1, i, a_src[i] + (ntA1 > 1 ? 64 : 0));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) issue_b(1, i, b_src[i] + (long)G2_BK * ldb);
+  for (int i = 0; i < 2; ++i) issue_b(1, i, b_src[i] + (long)G2_BK * ldb);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt1 > 2 ? 2 : 1) * G2_BK * ldb);
-  };
-  if (MI16) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc16[MI16 ? i : 0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[MI16 ? 0 : i][j][r] = 0.f;
-  }
-  if (PERSIST && !first_tile) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's prologue was issued before the previous epilogue
-  } else {
-    issue_prologue();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  }
+  for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt1 > 2 ? 2 : 1) * G2_BK * ldb);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
   if (RV_GEMM_PRIO_NN == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);     // wm is wave-uniform (readfirstlane)
@@ -1330,31 +1262,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g_
   for (; p < nt; ++p) phase(p, p & 1, I0{}, I0{});
   if (wm == 0) __builtin_amdgcn_s_barrier();   // re-balance the barrier count
 
-  const int em0 = m0, en0 = n0;                // the finished tile
-  bool more = false;
-  if (PERSIST) {
-    tile_iter += (int)gridDim.x;
-    more = tile_iter < nwg;
-    if (more) {                                // both wave groups are past their last fragment reads: refill the rings
-      set_tile(tile_iter);
-      set_src();
-      issue_prologue();
-    }
-  }
   if (MI16) {
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm) {
       f32x16_t blk[2][2];
       acc16_block_to_acc32(*reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[MI16 ? 4 * hm : 0]), blk, lane);
-      epi.apply(blk, em0 + wm * 128 + hm * 64, en0 + wn * 64, lane, g.M, g.N);
+      epi.apply(blk, m0 + wm * 128 + hm * 64, n0 + wn * 64, lane, g.M, g.N);
     }
   } else {
-    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), em0 + wm * 128, en0 + wn * 64, lane, g.M, g.N);
-    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[MI16 ? 0 : 2]), em0 + wm * 128 + 64, en0 + wn * 64, lane, g.M, g.N);
+    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
+    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[MI16 ? 0 : 2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
   }
-  if (!PERSIST || !more) break;
-  first_tile = false;
-  }  // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1381,32 +1299,6 @@ __device__ __forceinline__ uint32_t gemm_mix32(uint32_t h) {    // same mixer as
   return h;
 }
 
-// Compile-time in the shipped library (a run-time policy branch around the asm stores made hipcc spill the dominant
-// kernel: 106 SGPRs + 528 B of scratch): experiment builds pass -DRV_EPI_CPOL=1|2 (rlaif-v_amd/build.py defines/tag).
-#ifndef RV_EPI_CPOL
-#define RV_EPI_CPOL 0
-#endif
-#ifndef RV_EPI_PREFETCH
-#define RV_EPI_PREFETCH 0          // 1: epilogue operand loads (gate|up of EpiSwiGLUBwd, the residual of EpiStore) batched ahead of use
-#endif
-__device__ __forceinline__ constexpr int epi_cpol_now() { return RV_EPI_CPOL; }
-// Output stores with a cache policy (rv_set_gemm_tuning key 1): 0 = plain (the line stays in the XCD's L2), 1 = sc1
-// (written through and dropped from L2: the 128-512 KB a workgroup writes per tile do not evict the operand panels the
-// next round re-reads), 2 = nt.  MI355X_MICROARCH.md "stores of each flavour".
-__device__ __forceinline__ void epi_store16(void* p, const uint4& v, int cpol) {
-  if (cpol == 0) { *(uint4*)p = v; return; }
-  const u32x4_t r = {v.x, v.y, v.z, v.w};
-  if (cpol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(r) : "memory");
-}
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-__device__ __forceinline__ void epi_store8(void* p, const uint2& v, int cpol) {
-  if (cpol == 0) { *(uint2*)p = v; return; }
-  const u32x2_t r = {v.x, v.y};
-  if (cpol == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
-  else asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(r) : "memory");
-}
-
 struct EpiStore {
   bf16_t* C; long ldc;
   const bf16_t* bias;
@@ -1423,9 +1315,11 @@ struct EpiStore {
   // load) instructions - the epilogue of a 1-workgroup-per-CU kernel is store-ISSUE bound and nothing overlaps it.
   __device__ __forceinline__ void apply_wide(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
     const int half = lane >> 5;
-    const int cpol = epi_cpol_now();
-#if RV_EPI_PREFETCH
-    uint4 rpre[2][4];                             // the block's 8 residual loads, issued ahead of the first use (clamped addresses)
+    // The block's 8 residual loads are issued BEFORE the first one is used (addresses clamped into the tensor; rows / columns
+    // beyond the edge read valid memory and are never stored).  Inside the loop they sat behind the `m >= M` / `n >= N`
+    // `continue`s - control flow hipcc does not move loads across - so every iteration paid its own load -> wait -> add ->
+    // store chain while all of the XCD's CUs were in their epilogues (round 3: +1 % on the o / down projections, bit-identical).
+    uint4 rpre[2][4];
     if (R) {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
@@ -1435,7 +1329,6 @@ struct EpiStore {
           rpre[tm][i] = *(const uint4*)(R + mc * ldr + min(nw + (i >> 1) * 32 + (i & 1) * 16 + 8 * half, N - 8));
       }
     }
-#endif
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int m = mw + tm * 32 + (lane & 31);
@@ -1479,15 +1372,11 @@ struct EpiStore {
           }
           if (R) {
             float rr[8];
-#if RV_EPI_PREFETCH
             epi_unpack8(rpre[tm][tn * 2 + rgp], rr);
-#else
-            epi_unpack8(*(const uint4*)(R + (long)m * ldr + n), rr);
-#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rr[j];
           }
-          epi_store16(C + (long)m * ldc + n, epi_pack8(v), cpol);
+          *(uint4*)(C + (long)m * ldc + n) = epi_pack8(v);
         }
       }
     }
@@ -1557,7 +1446,6 @@ struct EpiSwiGLU {
   bf16_t* ACT; long lda;      // activation [M][N/2]
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
     const int half = lane >> 5;
-    const int cpol = epi_cpol_now();
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int m = mw + tm * 32 + (lane & 31);
@@ -1577,7 +1465,7 @@ struct EpiSwiGLU {
           const int n = nw + tn * 32 + rgp * 16 + 8 * half;
           if (n >= N) continue;
           const uint4 pk = epi_pack8(v);
-          epi_store16(C + (long)m * ldc + n, pk, cpol);
+          *(uint4*)(C + (long)m * ldc + n) = pk;
           float r[8];
           epi_unpack8(pk, r);
           float o[4];
@@ -1586,7 +1474,7 @@ struct EpiSwiGLU {
           uint2 w;
           w.x = pack2bf(o[0], o[1]);
           w.y = pack2bf(o[2], o[3]);
-          epi_store8(ACT + (long)m * lda + (n >> 1), w, cpol);
+          *(uint2*)(ACT + (long)m * lda + (n >> 1)) = w;
         }
       }
     }
@@ -1599,14 +1487,13 @@ struct EpiSwiGLU {
 struct EpiSwiGLUBwd {
   const bf16_t* GU; long ldgu;
   bf16_t* DGU; long lddgu;
-#if RV_EPI_PREFETCH
   // All 16 gate|up loads of the wave's 64 x 64 block are issued BEFORE the first one is used (addresses clamped into the
   // tensor; out-of-range rows / columns are loaded from valid memory and never stored): one exposed memory latency per block
   // instead of eight.  The edge tests used to be `continue`s in front of the loads - control flow hipcc does not move loads
-  // across - so every iteration paid load -> wait -> exp -> store in sequence, with all 256 CUs in their epilogues at once.
+  // across - so every iteration paid load -> wait -> exp -> store in sequence (ISA before: LLwSS x 8; after: L x 16, w, SS x 8).
+  // Round 3: 1071 -> 1108 TF/s on the step's shape, bit-identical results (profiles/r03_gemm_lib_ab_*.log).
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
     const int half = lane >> 5;
-    const int cpol = epi_cpol_now();
     uint4 ga[2][4], gb[2][4];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -1648,55 +1535,13 @@ struct EpiSwiGLUBwd {
           }
           if (m < M && n < N) {
             bf16_t* dp = DGU + (long)m * lddgu + 2 * n;
-            epi_store16(dp, epi_pack8(o0), cpol);
-            epi_store16(dp + 8, epi_pack8(o1), cpol);
+            *(uint4*)dp = epi_pack8(o0);
+            *(uint4*)(dp + 8) = epi_pack8(o1);
           }
         }
       }
     }
   }
-#else
-  __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
-    const int half = lane >> 5;
-    const int cpol = epi_cpol_now();
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int m = mw + tm * 32 + (lane & 31);
-      if (m >= M) continue;
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-#pragma unroll
-        for (int rgp = 0; rgp < 2; ++rgp) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float a = acc[tm][tn][(2 * rgp) * 4 + j], b = acc[tm][tn][(2 * rgp + 1) * 4 + j];
-            const float recv = __shfl_xor(half ? a : b, 32);
-            v[j] = half ? recv : a;
-            v[4 + j] = half ? b : recv;
-          }
-          const int n = nw + tn * 32 + rgp * 16 + 8 * half;
-          if (n >= N) continue;
-          float da[8], gu0[8], gu1[8], o0[8], o1[8];
-          epi_unpack8(epi_pack8(v), da);
-          const bf16_t* gp = GU + (long)m * ldgu + 2 * n;
-          epi_unpack8(*(const uint4*)gp, gu0);
-          epi_unpack8(*(const uint4*)(gp + 8), gu1);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float gg = (j < 4) ? gu0[2 * j] : gu1[2 * (j - 4)], uu = (j < 4) ? gu0[2 * j + 1] : gu1[2 * (j - 4) + 1];
-            const float sg = 1.f / (1.f + __expf(-gg));
-            const float dg = da[j] * uu * sg * (1.f + gg * (1.f - sg)), du = da[j] * (gg * sg);
-            if (j < 4) { o0[2 * j] = dg; o0[2 * j + 1] = du; } else { o1[2 * (j - 4)] = dg; o1[2 * (j - 4) + 1] = du; }
-          }
-          bf16_t* dp = DGU + (long)m * lddgu + 2 * n;
-          epi_store16(dp, epi_pack8(o0), cpol);
-          epi_store16(dp + 8, epi_pack8(o1), cpol);
-        }
-      }
-    }
-  }
-#endif
 };
 
 // fp32 output (used where a downstream reduction wants full precision).

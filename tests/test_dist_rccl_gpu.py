@@ -54,6 +54,14 @@ def _two_rank_worker(rank, world, port, q):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # RCCL's own account of what it built (ranks, channels, transport) goes to a per-rank file: the first multi-GPU run shows
+    # "RCCL saw N ranks, C channels" next to the replicas-identical assertion
+    log = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                       "gpurun_out", f"rccl_debug_rank{rank}.log")
+    os.makedirs(os.path.dirname(log), exist_ok=True)
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+    os.environ.setdefault("NCCL_DEBUG_FILE", log)
     import torch.distributed as dist
     from rlaif_v_amd.dist import BucketedAllReduce, init_process_group_from_env
     from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
@@ -101,3 +109,12 @@ def test_two_rank_rccl_replicas_stay_identical():
         assert p.exitcode == 0
     for rank, same, loss, n_metrics, _ in res:
         assert same and loss == loss and n_metrics == 8, (rank, same, loss, n_metrics)
+    import re
+    root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for rank in range(2):
+        path = os.path.join(root, "gpurun_out", f"rccl_debug_rank{rank}.log")
+        if os.path.exists(path):
+            txt = open(path, errors="replace").read()
+            ch = re.findall(r"(\d+) coll channels|Channel (\d+)/(\d+)", txt)
+            nr = re.findall(r"nranks (\d+)", txt)
+            print(f"RCCL rank {rank}: nranks {sorted(set(nr))}, channel lines {len(ch)}: {ch[:4]}")
