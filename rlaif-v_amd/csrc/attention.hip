@@ -87,12 +87,14 @@ __device__ __forceinline__ void attn_block_coords(int nx, int H, int S, int& x, 
 // of rank bx (heavy) and n-1-bx (light): the sums are equal where pairs can make them equal (forward / dQ: 36..40) and
 // otherwise DEscend with bx, i.e. the dispatcher - which issues workgroups in id order - sees the long ones first (LPT).
 // KEYS = false: query blocks (forward, dQ); true: key blocks (dK / dV).  n > 64 or bit 20 of nx clear: plain pairing.
+// single = true (bit 21 of nx; the launcher then starts ONE workgroup per block): workgroup bx takes the block of rank bx
+// alone - twice as many, half as long workgroups in strict longest-first order, so the tail of the launch is one LIGHT block.
 template <bool KEYS>
-__device__ __forceinline__ void pair_blocks(int bx, int n, int L, int sh, int e1, int lane, bool balanced, int& first,
-                                            int& second) {
+__device__ __forceinline__ void pair_blocks(int bx, int n, int L, int sh, int e1, int lane, bool balanced, bool single,
+                                            int& first, int& second) {
   if (!balanced || n > 64) {
     first = bx;
-    second = (n - 1 - bx > bx) ? n - 1 - bx : -1;
+    second = (!single && n - 1 - bx > bx) ? n - 1 - bx : -1;
     return;
   }
   const int x = lane, b0 = x * 128;
@@ -114,7 +116,7 @@ __device__ __forceinline__ void pair_blocks(int bx, int n, int L, int sh, int e1
   const unsigned long long m1 = __ballot(x < n && rank == bx);
   const unsigned long long m2 = __ballot(x < n && rank == n - 1 - bx);
   first = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m1) - 1);
-  second = (n - 1 - bx > bx) ? __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m2) - 1) : -1;
+  second = (!single && n - 1 - bx > bx) ? __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m2) - 1) : -1;
 }
 
 template <int HD>
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   const bf16_t* vbase = qkv + v_col0 + (h / kv_group) * HD;
 
   int blk_first, blk_second;
-  pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), blk_first, blk_second);
+  pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const int qb = (pass == 0) ? blk_first : blk_second;
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
   const bf16_t* vbase = qkv + v_col0 + (h / kv_group) * HD;
 
   int blk_first, blk_second;
-  pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), blk_first, blk_second);
+  pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const int qb = (pass == 0) ? blk_first : blk_second;
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __r
   };
 
   int blk_first, blk_second;
-  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), blk_first, blk_second);
+  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const int kvb = (pass == 0) ? blk_first : blk_second;
@@ -988,7 +990,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
                   (uint32_t)((s16 & 1) * 8);
 
   int blk_first, blk_second;
-  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), blk_first, blk_second);
+  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const int kvb = (pass == 0) ? blk_first : blk_second;
@@ -1247,10 +1249,10 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   if (map_mode < 0) { const char* e = getenv("RV_ATTN_MAP"); map_mode = e ? atoi(e) : 1; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = (L + 127) / 128;
-  const int nxr = causal ? (nb + 1) / 2 : nb;
-  static int pair_mode = -1;      // RV_ATTN_PAIR=0: the plain (x, n-1-x) pairing (A/B knob); default: pair_blocks
+  static int pair_mode = -1;      // RV_ATTN_PAIR: 0 = the plain (x, n-1-x) pairing, 1 = pair_blocks (ranked pairs), 2 = one ranked block per workgroup
   if (pair_mode < 0) { const char* e = getenv("RV_ATTN_PAIR"); pair_mode = e ? atoi(e) : 1; }
-  const int nx = nxr | (map_mode << 16) | ((pair_mode ? 1 : 0) << 20);
+  const int nxr = (causal && pair_mode != 2) ? (nb + 1) / 2 : nb;
+  const int nx = nxr | (map_mode << 16) | ((pair_mode ? 1 : 0) << 20) | ((causal && pair_mode == 2 ? 1 : 0) << 21);
   dim3 grid(nxr * H * S), block(256);
   static bool attr_done = false;
   if (!attr_done) {
@@ -1297,10 +1299,10 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   const int nb = (L + 127) / 128;
   static int map_mode = -1;
   if (map_mode < 0) { const char* e = getenv("RV_ATTN_MAP"); map_mode = e ? atoi(e) : 1; }
-  const int nxr = causal ? (nb + 1) / 2 : nb;
   static int pair_mode = -1;
   if (pair_mode < 0) { const char* e = getenv("RV_ATTN_PAIR"); pair_mode = e ? atoi(e) : 1; }
-  const int nx = nxr | (map_mode << 16) | ((pair_mode ? 1 : 0) << 20);
+  const int nxr = (causal && pair_mode != 2) ? (nb + 1) / 2 : nb;
+  const int nx = nxr | (map_mode << 16) | ((pair_mode ? 1 : 0) << 20) | ((causal && pair_mode == 2 ? 1 : 0) << 21);
   dim3 grid(nxr * H * S), block(256);
   hipStream_t st = (hipStream_t)stream;
   constexpr int DQ_LDS = 4 * 64 * 256;

@@ -42,6 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--attn-case", default="", help="packed | plain: run only that attention case (PMC passes per case)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     R = 27664
@@ -91,6 +92,10 @@ def main():
         sh, tl = int(seg[0][0]), int(seg[1][0] - seg[0][0])
         pairs = sh * (sh + 1) / 2 + 2 * (tl * sh + tl * (tl + 1) / 2)
         fl_f = 4.0 * B * H * pairs * hd
+        if a.attn_case == "plain":
+            del qkv, do
+            qkv = do = None
+    if a.only in ("", "attn") and a.attn_case != "plain":
         o, lse = ops.attn_fwd(qkv, B, L, H, hd, True, 0, d, 2 * d, seg=seg)
         out = torch.empty_like(o)
         t_f = timeit(lambda: ops.attn_fwd(qkv, B, L, H, hd, True, 0, d, 2 * d, out=out, seg=seg), a.iters)
@@ -98,6 +103,8 @@ def main():
         t_b = timeit(lambda: ops.attn_bwd(qkv, o, do, lse, B, L, H, hd, True, 0, d, 2 * d, dqkv=dqkv, seg=seg), a.iters)
         print(f"attn packed L={L} (shared {sh}, tails {tl}): fwd {t_f:.3f} ms ({fl_f / t_f / 1e9:.0f} TF/s algorithmic)  "
               f"bwd (delta+dq+dkv) {t_b:.3f} ms ({2.5 * fl_f / t_b / 1e9:.0f} TF/s algorithmic)", flush=True)
+    if a.only in ("", "attn") and a.attn_case != "packed":
+        B, H, hd, d = 8, 32, 128, 4096
         # plain causal rows of the reference layout for comparison (16 x 2048)
         S2, L2 = 16, 2048
         qkv2 = (torch.randn(S2 * L2, 3 * d, device=dev) * 0.5).to(BF)
