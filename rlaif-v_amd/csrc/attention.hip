@@ -374,6 +374,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         if (RV_ATTN_FWD_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int e = 0; e < ET; ++e) vA[e] = tro.read(vs_addr, 0, e);
+        // (Round 3 tried the same arithmetic with the instruction-level parallelism spelled out - four independent maxima, all 32
+        // exponent arguments before the first v_exp, four partial sums instead of one 16-deep v_max3 chain, 32 dependent
+        // v_fma -> v_exp pairs and one 32-deep v_add chain: no measurable change, profiles/r03_attn_rounds_softmax_ilp.log - the
+        // second wave of the SIMD already fills those bubbles; removed.)
         float tmax = -INFINITY;                      // raw-score maximum (c > 0 keeps the order)
         if (ABL != 1)
 #pragma unroll

@@ -43,6 +43,10 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--attn-case", default="", help="packed | plain: run only that attention case (PMC passes per case)")
+    ap.add_argument("--attn-rounds", type=int, default=1,
+                    help="repeat the attention measurements this many times and print every round: the FIRST kernel measured after "
+                         "process start runs at a lower shader clock (the clock ramps up over the first ~100 ms of load) - round 3 "
+                         "found that this, not the layout, made the packed forward look 19 %% slower than the plain one")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     R = 27664
@@ -95,7 +99,14 @@ def main():
         if a.attn_case == "plain":
             del qkv, do
             qkv = do = None
+    for _round in range(a.attn_rounds):
+      _attn_round(a, dev, locals())
+
+
+def _attn_round(a, dev, env):
+    BF = torch.bfloat16
     if a.only in ("", "attn") and a.attn_case != "plain":
+        qkv, do, seg, L, d, B, H, hd, sh, tl, fl_f = (env[k] for k in ("qkv", "do", "seg", "L", "d", "B", "H", "hd", "sh", "tl", "fl_f"))
         o, lse = ops.attn_fwd(qkv, B, L, H, hd, True, 0, d, 2 * d, seg=seg)
         out = torch.empty_like(o)
         t_f = timeit(lambda: ops.attn_fwd(qkv, B, L, H, hd, True, 0, d, 2 * d, out=out, seg=seg), a.iters)
