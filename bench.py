@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--no-dp-probe", action="store_true",
                     help="skip the single-GPU data-parallel probe (steps re-timed with a concurrent reduce-copy kernel on a "
                          "side stream at every gradient bucket)")
-    ap.add_argument("--dp-probe-wgs", default="4,8,16", help="stand-in workgroup counts (= RCCL channels) to sweep")
+    ap.add_argument("--dp-probe-wgs", default="8,32", help="stand-in workgroup counts (= RCCL channels) to sweep")
     ap.add_argument("--no-gemm-timer", action="store_true")
     args = ap.parse_args()
 
