@@ -359,12 +359,6 @@ class LlavaDPOModel:
         # compute the prefix shared by the chosen and rejected sequence of a pair once (splice.build_packed_plan)
         self.share_prefix = os.environ.get("RV_SHARE_PREFIX", "1") != "0"
         self.fuse_rope_bwd = os.environ.get("RV_FUSE_ROPE_BWD", "1") != "0"
-        # weight-gradient GEMMs on a side stream (RV_WGRAD_STREAM=1): dW = dy^T x depends only on dy and a saved activation,
-        # not on the input-gradient chain, so it may run BESIDE the next layer pieces - the partly filled last round of
-        # 256-workgroup tiles of one GEMM (wgu: 5.4 rounds, wdown: 2.7) is then topped up by the other stream's workgroups
-        # instead of idling behind a kernel boundary
-        self.wgrad_stream_on = os.environ.get("RV_WGRAD_STREAM", "0") != "0"
-        self._wgrad_stream = None
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -627,32 +621,6 @@ class LlavaDPOModel:
     def _dropout_seed(self, layer: int, slot: int) -> int:
         return (self._cur_drop_step * 1000003 + self.dropout_rank * 7919 + layer * 8 + slot) & 0x7FFFFFFF
 
-    def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, out: torch.Tensor):
-        """out = dy^T @ xin (TN GEMM).  With ``wgrad_stream_on`` it is enqueued on the side stream behind everything the main
-        stream has launched so far (dy's producer included); both operands stay allocated until the side stream is done with
-        them (record_stream).  ``_wgrad_join`` orders the main stream behind the side stream."""
-        if not self.wgrad_stream_on:
-            ops.gemm_tn(dy, xin, out=out)
-            return
-        if self._wgrad_stream is None:
-            # LOW priority: the input-gradient chain on the main stream is the critical path, the weight gradients only fill
-            # the compute units it leaves idle (RV_WGRAD_PRIO overrides: HIP accepts -1 high ... 1 low on this device)
-            prio = int(os.environ.get("RV_WGRAD_PRIO", "1"))
-            try:
-                self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=prio)
-            except Exception:
-                self._wgrad_stream = torch.cuda.Stream(device=self.device)
-        side = self._wgrad_stream
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            ops.gemm_tn(dy, xin, out=out)
-        dy.record_stream(side)
-        xin.record_stream(side)
-
-    def _wgrad_join(self):
-        if self.wgrad_stream_on and self._wgrad_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._wgrad_stream)
-
     def _proj_bwd(self, dy: torch.Tensor, xin: torch.Tensor, t: Optional[torch.Tensor], i: int, grp: str,
                   drop_slot: int = 0, xd: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Input gradient of _proj_fwd; writes the weight gradients that exist (full fine-tune: dW = dy^T x by the TN
@@ -660,8 +628,8 @@ class LlavaDPOModel:
         st = self.store
         wkey = f"layers.{i}.w{grp}"
         if self.lora is None:
-            self._wgrad(dy, xin, st.g(wkey))                    # independent of the dx chain: may run beside it
             dx = ops.linear(dy, st.pT(wkey), st.p(wkey))        # dx = dy @ W: "weight" = W^T, its transpose = W itself
+            ops.gemm_tn(dy, xin, out=st.g(wkey))
             return dx
         rp, sc = self.lora.r_pad, self.lora.scaling
         akey, bkey = f"layers.{i}.lora_{grp}.A", f"layers.{i}.lora_{grp}.B"
@@ -798,7 +766,7 @@ class LlavaDPOModel:
 
         def wgrad(dy: torch.Tensor, xin: torch.Tensor, key: str):
             """dW[key] = dy^T @ xin: TN GEMM (operands transposed on the fly by ds_read_b64_tr_b16)."""
-            self._wgrad(dy, xin, st.g(key))
+            ops.gemm_tn(dy, xin, out=st.g(key))
 
         def gain_grad(key: str) -> torch.Tensor:
             return scratch_dw if lora else st.g(key)
@@ -820,7 +788,6 @@ class LlavaDPOModel:
             st.g("lm_head.weight").zero_()
             st.g("model.norm.weight").zero_()
         if hook and not lora:
-            self._wgrad_join()
             hook("lm_head", *st.buckets["lm_head"])
 
         # ---- decoder layers, last to first
@@ -832,8 +799,8 @@ class LlavaDPOModel:
             c["act"] = None
             if st.interleave_gu:
                 # d(gate|up) straight out of the down projection's input-gradient GEMM (SwiGLU backward in its epilogue)
-                self._wgrad(dx, act, st.g(f"layers.{i}.wdown"))
                 dgu = ops.linear_swiglu_bwd(dx, st.p(f"layers.{i}.wdown"), c["gu"])
+                ops.gemm_tn(dx, act, out=st.g(f"layers.{i}.wdown"))
                 del act
             else:
                 dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3, xd=c["xd_down"])
@@ -865,11 +832,9 @@ class LlavaDPOModel:
             del dxn, dx_mid
             ctx["layers"][i] = None          # free this layer's activations
             if hook:
-                self._wgrad_join()           # the bucket is final only when the side stream's weight gradients have landed
                 hook(f"layer{i}", *st.buckets[f"layer{i}"])
 
         # ---- embedding (deterministic segmented sum; frozen under LoRA) and projector
-        self._wgrad_join()
         if not lora:
             ge = st.g("model.embed_tokens.weight")
             ge.zero_()
