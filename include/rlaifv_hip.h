@@ -95,6 +95,14 @@ int rv_gemm_tn_bf16_splitk(const void* P, long ldp, const void* Q, long ldq, voi
  * e.g. dW = dY^T X (autograd of nn.Linear); operands are transposed on the fly by ds_read_b64_tr_b16. */
 int rv_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, void* C, long ldc, int R, int I, int J,
                     const void* residual, long ldr, float alpha, void* stream);
+/* rv_gemm_tn_bf16 (no residual, alpha 1) with a TAIL SPLIT: all output tiles of a weight gradient cost the same, so the last,
+ * partly filled round of 256 tiles takes as long as a full one; with a workspace the tiles of that round are split over the
+ * token axis into fp32 slabs and summed in fixed order (deterministic), e.g. wgu 1376 tiles: 6 -> 5.5 rounds.
+ * rv_gemm_tn_workspace_floats: floats the plan for (R, I, J) needs (0: no split pays - then rv_gemm_tn_bf16_ws is
+ * rv_gemm_tn_bf16).  A NULL / too small workspace also falls back to the plain launch. */
+int rv_gemm_tn_workspace_floats(int R, int I, int J);
+int rv_gemm_tn_bf16_ws(const void* P, long ldp, const void* Q, long ldq, void* C, long ldc, int R, int I, int J,
+                       float* workspace, long workspace_floats, void* stream);
 int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                            int variant, void* stream);
 

@@ -65,7 +65,7 @@ static int g_tn_dist = 3;   // prefetch distance of the TN kernel (RV_GEMM_TN_DI
 
 template <class Epi, int DIST>
 static int launch_gemm_tn_d(const bf16_t* P, long ldp, const bf16_t* Q, long ldq, int R, int I, int J, const Epi& epi,
-                            hipStream_t st, int splits, int r_chunk, long split_stride) {
+                            hipStream_t st, int splits, int r_chunk, long split_stride, int bid0, int nblocks) {
   constexpr int LDS = (DIST + 1) * G2_STAGE_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
@@ -74,24 +74,85 @@ static int launch_gemm_tn_d(const bf16_t* P, long ldp, const bf16_t* Q, long ldq
     attr_done = true;
   }
   const int tiles_i = (I + 255) / 256, tiles_j = (J + 255) / 256;
+  const int gx = nblocks > 0 ? nblocks : tiles_i * tiles_j;          // launch-order positions bid0 .. bid0 + gx - 1
   if (nn_mi16())
-    hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST, true>), dim3(tiles_i * tiles_j, splits), dim3(G2_THREADS), LDS, st, P,
-                       ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride, g_group);
+    hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST, true>), dim3(gx, splits), dim3(G2_THREADS), LDS, st, P,
+                       ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride, g_group, bid0);
   else
-    hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST>), dim3(tiles_i * tiles_j, splits), dim3(G2_THREADS), LDS, st, P,
-                       ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride, g_group);
+    hipLaunchKernelGGL((gemm_tn_256_kernel<Epi, DIST>), dim3(gx, splits), dim3(G2_THREADS), LDS, st, P,
+                       ldp, Q, ldq, R, I, J, epi, r_chunk, split_stride, g_group, bid0);
   RV_CHECK_LAUNCH();
   return 0;
 }
 
 template <class Epi>
 static int launch_gemm_tn(const bf16_t* P, long ldp, const bf16_t* Q, long ldq, int R, int I, int J, const Epi& epi,
-                          hipStream_t st, int splits = 1, int r_chunk = 0, long split_stride = 0) {
+                          hipStream_t st, int splits = 1, int r_chunk = 0, long split_stride = 0, int bid0 = 0,
+                          int nblocks = 0) {
   static bool env_done = false;
   read_group_env();
   if (!env_done) { const char* e = getenv("RV_GEMM_TN_DIST"); if (e && atoi(e) == 4) g_tn_dist = 4; env_done = true; }
-  if (g_tn_dist == 3) return launch_gemm_tn_d<Epi, 3>(P, ldp, Q, ldq, R, I, J, epi, st, splits, r_chunk, split_stride);
-  return launch_gemm_tn_d<Epi, 4>(P, ldp, Q, ldq, R, I, J, epi, st, splits, r_chunk, split_stride);
+  if (g_tn_dist == 3) return launch_gemm_tn_d<Epi, 3>(P, ldp, Q, ldq, R, I, J, epi, st, splits, r_chunk, split_stride, bid0, nblocks);
+  return launch_gemm_tn_d<Epi, 4>(P, ldp, Q, ldq, R, I, J, epi, st, splits, r_chunk, split_stride, bid0, nblocks);
+}
+
+// Tail split of a weight-gradient GEMM.  All output tiles cost the same (the contraction runs over every token), so a
+// launch of T tiles takes ceil(T / 256) rounds on 256 CUs and the last round is as long as a full one however few tiles it
+// holds (wgu: 1376 tiles = 5.375 rounds, wdown: 688 = 2.69).  Plan: the first floor(T / 256) * 256 launch-order positions
+// run as they are; the `tail` remaining tiles are split s ways over the token axis (s x tail workgroups of 1 / s length,
+// fp32 tile-dense slabs) and summed in fixed order by tn_tail_reduce_kernel.  The tail then takes ceil(tail * s / 256) / s of
+// a round instead of 1.  s = 1: no split pays (or the problem has no full round).
+struct TnTailPlan { int full_blocks, tail, splits, r_chunk; };
+static TnTailPlan tn_tail_plan(int R, int I, int J) {
+  static int enabled = -1;
+  static double penalty = 0.02;       // rounds charged per split for its fixed costs (prologue, slab store, reduce pass)
+  if (enabled < 0) {
+    const char* e = getenv("RV_TN_TAIL_SPLIT");
+    enabled = e ? atoi(e) : 1;
+    const char* q = getenv("RV_TN_TAIL_PENALTY");
+    if (q) penalty = atof(q);
+  }
+  const int T = ((I + 255) / 256) * ((J + 255) / 256);
+  TnTailPlan p{T, 0, 1, 0};
+  const int full = T / 256, tail = T % 256;
+  if (!enabled || full < 1 || tail == 0) return p;
+  double best = 1.0;
+  int best_s = 1;
+  const int cand[5] = {2, 3, 4, 6, 8};
+  for (int c = 0; c < 5; ++c) {
+    const int s = cand[c];
+    if (R / s < 2048) break;                                   // keep every split a long contraction
+    const double t = (double)((tail * s + 255) / 256) / s + penalty * s;
+    if (t < best - 1e-9) { best = t; best_s = s; }
+  }
+  if (1.0 - best < 0.15) return p;                             // not worth two more launches
+  p.full_blocks = full * 256;
+  p.tail = tail;
+  p.splits = best_s;
+  p.r_chunk = ((R + best_s - 1) / best_s + 31) / 32 * 32;
+  p.splits = (R + p.r_chunk - 1) / p.r_chunk;
+  return p;
+}
+
+// out tile = bf16(sum over splits of the fp32 slabs), fixed order; one workgroup per tail tile, same tile walk as the GEMM
+__global__ __launch_bounds__(256) void tn_tail_reduce_kernel(const float* __restrict__ ws, int splits, int tail, int bid0, int I,
+                                                              int J, int group, bf16_t* __restrict__ C, long ldc) {
+  int i0, j0;
+  tn_tile_origin((int)blockIdx.x + bid0, I, J, group, i0, j0);
+  const float* base = ws + (long)blockIdx.x * 65536;
+  for (int q = threadIdx.x; q < 256 * 64; q += 256) {          // 256 rows x 64 float4
+    const int r = q >> 6, c4 = (q & 63) * 4;
+    if (i0 + r >= I || j0 + c4 >= J) continue;
+    float4 a = *(const float4*)(base + r * 256 + c4);
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = *(const float4*)(base + (long)s * tail * 65536 + r * 256 + c4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    uint2 o;
+    o.x = pack2bf(a.x, a.y);
+    o.y = pack2bf(a.z, a.w);
+    *(uint2*)(C + (long)(i0 + r) * ldc + j0 + c4) = o;
+  }
 }
 
 template <int STAGE, class Epi>
@@ -256,6 +317,37 @@ int rv_gemm_tn_bf16(const void* P, long ldp, const void* Q, long ldq, void* C, l
   EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
   epi.narrow = epi_narrow();
   return launch_gemm_tn((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, R, I, J, epi, (hipStream_t)stream);
+}
+
+int rv_gemm_tn_workspace_floats(int R, int I, int J) {
+  if (R <= 0 || I <= 0 || J <= 0) return 0;
+  const TnTailPlan p = tn_tail_plan(R, I, J);
+  return p.splits > 1 ? p.splits * p.tail * 65536 : 0;
+}
+
+int rv_gemm_tn_bf16_ws(const void* P, long ldp, const void* Q, long ldq, void* C, long ldc, int R, int I, int J,
+                       float* workspace, long workspace_floats, void* stream) {
+  if (I == 0 || J == 0) return 0;
+  RV_REQUIRE(R > 0, "rv_gemm_tn_bf16_ws: R must be > 0");
+  RV_REQUIRE(I % 8 == 0 && J % 8 == 0 && I >= 8 && J >= 8, "rv_gemm_tn_bf16_ws: I and J must be multiples of 8");
+  RV_REQUIRE(ldp % 8 == 0 && ldq % 8 == 0 && ldc % 4 == 0, "rv_gemm_tn_bf16_ws: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
+  RV_REQUIRE((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)workspace) & 15) == 0, "rv_gemm_tn_bf16_ws: P/Q/workspace must be 16-byte aligned");
+  const TnTailPlan p = tn_tail_plan(R, I, J);
+  EpiStore epi{(bf16_t*)C, ldc, nullptr, nullptr, 0, RV_ACT_NONE, 1.0f};
+  epi.narrow = epi_narrow();
+  if (p.splits <= 1 || workspace == nullptr || workspace_floats < (long)p.splits * p.tail * 65536)
+    return launch_gemm_tn((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, R, I, J, epi, (hipStream_t)stream);
+  if (launch_gemm_tn((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, R, I, J, epi, (hipStream_t)stream, 1, 0, 0, 0, p.full_blocks))
+    return 1;
+  EpiStoreF32 epf{workspace, 256};
+  if (launch_gemm_tn((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, R, I, J, epf, (hipStream_t)stream, p.splits, p.r_chunk, -1,
+                     p.full_blocks, p.tail))
+    return 1;
+  read_group_env();
+  hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3(p.tail), dim3(256), 0, (hipStream_t)stream, workspace, p.splits, p.tail,
+                     p.full_blocks, I, J, g_group, (bf16_t*)C, ldc);
+  RV_CHECK_LAUNCH();
+  return 0;
 }
 
 int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,

@@ -621,35 +621,51 @@ __device__ __forceinline__ void acc16_block_to_acc32(const f32x4_t (&a)[4][4], f
 
 __device__ bf16_t g_zero_row[256];   // 512 zero bytes: DMA source for contraction rows beyond R
 
+// Output tile of launch-order position `bid` (XCD-aware remap + grouped order; sweep at 27.6 k tokens: GROUP 4 beats 8 by
+// 1.6-3.5 %, 16 loses another 2 %).  Shared with the tail-split reduce kernel, which must walk the same tiles.
+__device__ __forceinline__ void tn_tile_origin(int bid, int I, int J, int group, int& i0, int& j0) {
+  const int tiles_i = (I + 255) / 256, tiles_j = (J + 255) / 256;
+  const int nwg = tiles_i * tiles_j;
+  const int id = xcd_remap(bid, nwg);
+  const int GROUP = group > 0 ? group : 4;
+  const int group_size = GROUP * tiles_j;
+  const int first_i = (id / group_size) * GROUP;
+  const int gsz = min(tiles_i - first_i, GROUP);
+  i0 = (first_i + (id % group_size) % gsz) * 256;
+  j0 = ((id % group_size) / gsz) * 256;
+}
+
+struct EpiStoreF32;
+
 template <class Epi, int DIST = 3, bool MI16 = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t* __restrict__ P, long ldp,
                                                                     const bf16_t* __restrict__ Q, long ldq, int R,
                                                                     int I, int J, Epi epi, int r_chunk,
-                                                                    long split_stride, int group) {
+                                                                    long split_stride, int group, int bid0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NST = DIST + 1;
+  int i0, j0;
+  tn_tile_origin((int)blockIdx.x + bid0, I, J, group, i0, j0);
   if (gridDim.y > 1) {   // split-K: workgroup row y reduces contraction rows [y*r_chunk, (y+1)*r_chunk) into its own slab
     const long r0 = (long)blockIdx.y * r_chunk;
     P += r0 * ldp;
     Q += r0 * ldq;
     R = (int)min((long)r_chunk, (long)R - r0);
-    epi.C += (long)blockIdx.y * split_stride;
+    if constexpr (std::is_same<Epi, EpiStoreF32>::value) {
+      if (split_stride < 0) {   // tail split (rv_gemm_tn_bf16_ws): tile-dense slabs [split][tail tile][256][256]
+        epi.C += ((long)blockIdx.y * gridDim.x + blockIdx.x) * 65536 - ((long)i0 * 256 + j0);
+        epi.ldc = 256;
+      } else {
+        epi.C += (long)blockIdx.y * split_stride;
+      }
+    } else {
+      epi.C += (long)blockIdx.y * split_stride;
+    }
   }
   const bf16_t* zero_row = g_zero_row;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 2, wj = wave & 3;
-
-  const int tiles_i = (I + 255) / 256, tiles_j = (J + 255) / 256;
-  const int nwg = tiles_i * tiles_j;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  const int GROUP = group > 0 ? group : 4;   // sweep at 27.6 k tokens: 4 beats 8 by 1.6-3.5 %, 16 loses another 2 %
-  const int group_size = GROUP * tiles_j;
-  const int first_i = (id / group_size) * GROUP;
-  const int gsz = min(tiles_i - first_i, GROUP);
-  const int tile_i = first_i + (id % group_size) % gsz;
-  const int tile_j = (id % group_size) / gsz;
-  const int i0 = tile_i * 256, j0 = tile_j * 256;
 
   // ---- LDS-DMA: a stage = P tile (16 KiB) + Q tile (16 KiB); one piece = 2 rows x 512 B; 2 pieces each per wave
   int p_row[2];   // tile row filled by this lane in piece i

@@ -85,9 +85,25 @@ def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty(I, J, dtype=BF16, device=p.device)
     _chk2d(out, "out")
+    if residual is None and alpha == 1.0:
+        # weight gradients: the partly filled last round of 256 tiles is split over the token axis (rv_gemm_tn_bf16_ws)
+        need = _TN_WS_NEED.get((R, I, J))
+        if need is None:
+            need = _TN_WS_NEED[(R, I, J)] = int(hip.lib().lib.rv_gemm_tn_workspace_floats(R, I, J))
+        if need > 0:
+            key = (p.device, torch.cuda.current_stream(p.device).cuda_stream)
+            ws = _TN_WS.get(key)
+            if ws is None or ws.numel() < need:
+                ws = _TN_WS[key] = torch.empty(need, dtype=torch.float32, device=p.device)
+            hip.call("rv_gemm_tn_bf16_ws", p, p.stride(0), q, q.stride(0), out, out.stride(0), R, I, J, ws, ws.numel())
+            return out
     hip.call("rv_gemm_tn_bf16", p, p.stride(0), q, q.stride(0), out, out.stride(0), R, I, J, residual,
              residual.stride(0) if residual is not None else 0, float(alpha))
     return out
+
+
+_TN_WS = {}          # (device, stream) -> fp32 workspace of the tail split (one per stream: launches on a stream are ordered)
+_TN_WS_NEED = {}     # (R, I, J) -> floats rv_gemm_tn_workspace_floats asks for
 
 
 def _lora_groups(N: int, group_cols: int, group0: int) -> int:

@@ -722,3 +722,26 @@ def test_swiglu_fused_gemm_epilogues(ops, M, d, f):
     close(dgu[:, 1::2], da * g32 * sg, what="fused swiglu d up")
     dblocks = ops.swiglu_bwd(dact, blocks)
     assert torch.equal(torch.cat([dgu_ref[:, 0::2], dgu_ref[:, 1::2]], 1), dblocks)
+
+
+@pytest.mark.parametrize("R,I,J", [(4096, 4096, 4608), (4352, 8192, 4352), (6000, 4104, 4600)])
+def test_gemm_tn_tail_split(ops, R, I, J, monkeypatch):
+    """Weight-gradient GEMM whose last round of 256 tiles is partly filled: the tail tiles are split over the token axis into
+    fp32 slabs and summed in fixed order (rv_gemm_tn_bf16_ws).  Same result as the plain launch to fp32 summation order,
+    deterministic, edge tiles included (I, J not multiples of 256)."""
+    dev = _dev()
+    from rlaif_v_amd import hip
+    need = hip.lib().lib.rv_gemm_tn_workspace_floats(R, I, J)
+    assert need > 0, "the case must trigger the tail split"
+    p, q = rnd(R, I, seed=1, dev=dev, scale=0.5), rnd(R, J, seed=2, dev=dev, scale=0.5)
+    a = ops.gemm_tn(p, q)                                   # tail split (workspace provided by ops)
+    b = ops.gemm_tn(p, q)
+    assert torch.equal(a, b)                                # deterministic
+    plain = torch.empty(I, J, dtype=BF, device=dev)
+    hip.call("rv_gemm_tn_bf16", p, p.stride(0), q, q.stride(0), plain, plain.stride(0), R, I, J, None, 0, 1.0)
+    ref = p.float().t() @ q.float()
+    close(a, ref, what=f"gemm_tn tail split {R}x{I}x{J}")
+    close(plain, ref, what="gemm_tn plain")
+    assert (a.float() - plain.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    frac_same = (a == plain).float().mean().item()
+    assert frac_same > 0.7, frac_same                       # tiles of the full rounds are bit-identical, the tail differs in fp32 order only
