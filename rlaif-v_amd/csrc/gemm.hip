@@ -98,14 +98,16 @@ static int launch_gemm_tn(const bf16_t* P, long ldp, const bf16_t* Q, long ldq, 
 
 // Tail split of a weight-gradient GEMM.  All output tiles cost the same (the contraction runs over every token), so a
 // launch of T tiles takes ceil(T / 256) rounds on 256 CUs and the last round is as long as a full one however few tiles it
-// holds (wgu: 1376 tiles = 5.375 rounds, wdown: 688 = 2.69).  Plan: the first floor(T / 256) * 256 launch-order positions
+// holds (wgu: 1376 tiles = 5.375 rounds, wdown: 688 = 2.69).  (In practice a thin last round runs somewhat faster than a full
+// one - fewer CUs share the fabric - so the measured gain is a third of this model's: wgu 3.76 -> 3.65 ms, step -0.5 %.)  Plan: the first floor(T / 256) * 256 launch-order positions
 // run as they are; the `tail` remaining tiles are split s ways over the token axis (s x tail workgroups of 1 / s length,
 // fp32 tile-dense slabs) and summed in fixed order by tn_tail_reduce_kernel.  The tail then takes ceil(tail * s / 256) / s of
 // a round instead of 1.  s = 1: no split pays (or the problem has no full round).
 struct TnTailPlan { int full_blocks, tail, splits, r_chunk; };
 static TnTailPlan tn_tail_plan(int R, int I, int J) {
   static int enabled = -1;
-  static double penalty = 0.02;       // rounds charged per split for its fixed costs (prologue, slab store, reduce pass)
+  static double penalty = 0.04;       // rounds charged per split for its fixed costs (prologue, slab store, reduce pass); measured:
+                                      // 8 splits of the wgu tail gain nothing, 2 splits -2.7 % (profiles/r03_tn_tail_split.log)
   if (enabled < 0) {
     const char* e = getenv("RV_TN_TAIL_SPLIT");
     enabled = e ? atoi(e) : 1;
