@@ -275,6 +275,11 @@ class LLaVA15DPOTrainer:
         m = self.reducer.reduce_metrics(self._pending_metrics).tolist()
         t = self._pending_task
         self._pending_metrics = None
+        return self._metrics_dict(m, t)
+
+    @staticmethod
+    def _metrics_dict(m: List[float], t: str) -> Dict[str, float]:
+        """The reference's metric names (collect_preference_metrics, trainers.py:148-157) for task ``t`` (train | test)."""
         d = {f"rewards_{t}/chosen": m[0], f"rewards_{t}/rejected": m[1], f"logps_{t}/rejected": m[2],
              f"logps_{t}/chosen": m[3], f"logps_{t}/ref_rejected": m[4], f"logps_{t}/ref_chosen": m[5],
              f"rewards_{t}/accuracies": m[6]}
@@ -392,13 +397,9 @@ class LLaVA15DPOTrainer:
         red = self.reducer.reduce_metrics(torch.cat([tot, torch.tensor([float(cnt)], device=dev)]))
         if float(red[8]) <= 0:
             raise ValueError("evaluate(): empty evaluation set")
-        mean = red[:8] / red[8]
-        self._pending_metrics, self._pending_task = mean[:7], "test"
-        keep, self.reducer = self.reducer, GradReducer()        # already reduced: pop_metrics must not average again
-        try:
-            m = self.pop_metrics()
-        finally:
-            self.reducer = keep
+        mean = (red[:8] / red[8]).tolist()
+        self._pending_metrics = None
+        m = self._metrics_dict(mean[:7], "test")
         m["eval_loss"] = float(mean[7])
         self.log(m)
         return m
