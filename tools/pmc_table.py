@@ -15,7 +15,9 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_hot_*.txt"))):
             continue
         name = re.sub(r"\(.*", "", m.group(1)).strip()
         tab[name][m.group(2)] = (int(m.group(3)), float(m.group(5)))
-KEYS = ["gemm_nn_a64_kernel<EpiStore, false>", "gemm_nn_a64_kernel<EpiStore, false, true>", "gemm_tn_256_kernel<EpiStore, 3>",
+KEYS = ["gemm_nn_a64_kernel<EpiStore, false>", "gemm_nn_a64_kernel<EpiStore, false, true>", "gemm_nn_a64_kernel<EpiSwiGLU, false, true>",
+        "gemm_nn_a64_kernel<EpiSwiGLUBwd, false, true>", "gemm_nt_256_kernel<EpiLogpFwd, true, 0, 3, 0, false>",
+        "gemm_nt_256_kernel<EpiLogpBwd, true, 0, 3, 0, false>", "gemm_tn_256_kernel<EpiStoreF32, 3, true>", "gemm_tn_256_kernel<EpiStore, 3>",
         "gemm_tn_256_kernel<EpiStore, 3, true>", "attn_fwd2_kernel<128, true>", "attn_fwd2_kernel<128, true, 0>",
         "attn_bwd_dq2_kernel<true>", "attn_bwd_dkv3_kernel<true, 0>", "attn_bwd_dkv2_kernel<true>"]
 for k in KEYS:
