@@ -58,5 +58,5 @@ if __name__ == "__main__":
     if sys.argv[1] == "--json":
         print(traffic_json(sys.argv[2], sys.argv[3]))
         sys.exit(0)
-    for r in summarize(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)[:25]:
+    for r in summarize(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)[:80]:
         print(f"{r['kernel']:92s} {r['counter']:10s} calls {r['calls']:5d}  avg {r['avg']:14.1f}  total {r['total']:16.1f}")
