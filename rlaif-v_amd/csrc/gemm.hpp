@@ -1500,9 +1500,6 @@ struct EpiSwiGLU {
 // SwiGLU backward fused into the input-gradient GEMM of the down projection: acc = d act [M][f]; with the kept gate|up tile
 // (interleaved) it emits d(gate|up) [M][2f] directly - d act never reaches HBM.  d act is rounded to bf16 first (what the
 // unfused path stores), then the arithmetic of swiglu_bwd_kernel.
-#ifndef RV_ABL_SWIGLU_BWD
-#define RV_ABL_SWIGLU_BWD 0
-#endif
 struct EpiSwiGLUBwd {
   const bf16_t* GU; long ldgu;
   bf16_t* DGU; long lddgu;
@@ -1521,14 +1518,8 @@ struct EpiSwiGLUBwd {
       for (int i = 0; i < 4; ++i) {
         const int nc = min(nw + (i >> 1) * 32 + (i & 1) * 16 + 8 * half, N - 8);
         const bf16_t* gp = GU + mc * ldgu + 2 * nc;
-#if RV_ABL_SWIGLU_BWD == 1      // ablation (wrong results): no gate|up loads - what hiding them completely would buy
-        (void)gp;
-        ga[tm][i] = make_uint4(0x3f803f80u + (unsigned)mc, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-        gb[tm][i] = ga[tm][i];
-#else
         ga[tm][i] = *(const uint4*)gp;
         gb[tm][i] = *(const uint4*)(gp + 8);
-#endif
       }
     }
 #pragma unroll
@@ -1558,19 +1549,11 @@ struct EpiSwiGLUBwd {
             const float dg = da[j] * uu * sg * (1.f + gg * (1.f - sg)), du = da[j] * (gg * sg);
             if (j < 4) { o0[2 * j] = dg; o0[2 * j + 1] = du; } else { o1[2 * (j - 4)] = dg; o1[2 * (j - 4) + 1] = du; }
           }
-#if RV_ABL_SWIGLU_BWD == 2      // ablation (wrong results): one of the two 16-byte stores only - what halving the output would buy
-          if (m < M && n < N) {
-            bf16_t* dp = DGU + (long)m * lddgu + 2 * n;
-            const uint4 a0 = epi_pack8(o0), a1 = epi_pack8(o1);
-            *(uint4*)dp = make_uint4(a0.x ^ a1.x, a0.y ^ a1.y, a0.z ^ a1.z, a0.w ^ a1.w);
-          }
-#else
           if (m < M && n < N) {
             bf16_t* dp = DGU + (long)m * lddgu + 2 * n;
             *(uint4*)dp = epi_pack8(o0);
             *(uint4*)(dp + 8) = epi_pack8(o1);
           }
-#endif
         }
       }
     }
