@@ -617,13 +617,26 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ in, long ld_in, co
   }
 }
 
-// column sums: db[c] = sum_m dy[m][c]   (bias gradients; bf16 out)
-__global__ void colsum_kernel(const bf16_t* __restrict__ dy, long ld, bf16_t* __restrict__ db, int M, int N) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+// column sums: db[c] = sum_m dy[m][c]   (bias gradients; bf16 out).  One workgroup per 64 columns: 16 row lanes x 64 column
+// lanes (a row slice = one 128-byte line), every thread sums rows ty, ty + 16, ..., then the 16 partial sums of a column are
+// added in fixed order (deterministic).  (Round 3: the first version walked all M rows in ONE thread per column - 16
+// workgroups, 1.08 ms for the projector's 4608 x 4096 bias gradient; now ~25 us.)
+__global__ __launch_bounds__(1024) void colsum_kernel(const bf16_t* __restrict__ dy, long ld, bf16_t* __restrict__ db, int M,
+                                                       int N) {
+  __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float s = 0.f;
-  for (int m = 0; m < M; ++m) s += bf2f(dy[(long)m * ld + c]);
-  db[c] = f2bf(s);
+  if (c < N)
+    for (int m = ty; m < M; m += 16) s += bf2f(dy[(long)m * ld + c]);
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][tx];
+    db[c] = f2bf(t);
+  }
 }
 
 // ------------------------------------------------------------------ CLIP front end
@@ -1142,7 +1155,7 @@ int rv_gather_rows(const void* in, long ld_in, const int* idx, void* out, long l
 
 int rv_colsum(const void* dy, long ld, void* db, int M, int N, void* stream) {
   if (N == 0) return 0;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, ld,
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(1024), 0, STREAM(stream), (const bf16_t*)dy, ld,
                      (bf16_t*)db, M, N);
   RV_CHECK_LAUNCH();
   return 0;
