@@ -45,6 +45,39 @@ __device__ __forceinline__ void mfma_agpr_zero(f32x16_t& acc) {
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));
 }
 
+// Combine a per-lane value with the one of lane ^ 32 (the two lanes that share a query / key row of a 32x32 MFMA tile) with
+// v_permlane32_swap instead of __shfl_xor: hipcc lowers the shuffle to ds_bpermute_b32 + s_waitcnt lgkmcnt(0), and that wait
+// also drains every fragment read issued ahead of it (the V^T prefetch of the forward's softmax section).  With both operands
+// = x the swap leaves {own, partner} in lanes < 32 and {partner, own} in lanes >= 32: the combination is symmetric.
+#ifndef RV_ATTN_PERMLANE
+#define RV_ATTN_PERMLANE 1
+#endif
+__device__ __forceinline__ void xhalf_pair(float x, float& a, float& b) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const u32x2_t r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  a = __builtin_bit_cast(float, (unsigned)r[0]);
+  b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float xhalf_max(float x) {
+#if RV_ATTN_PERMLANE
+  float a, b;
+  xhalf_pair(x, a, b);
+  return fmaxf(a, b);
+#else
+  return fmaxf(x, __shfl_xor(x, 32, 64));
+#endif
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+#if RV_ATTN_PERMLANE
+  float a, b;
+  xhalf_pair(x, a, b);
+  return a + b;
+#else
+  return x + __shfl_xor(x, 32, 64);
+#endif
+}
+
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
@@ -246,6 +279,9 @@ struct TileDma {
 #ifndef RV_DKV_S2
 #define RV_DKV_S2 1            // dK/dV kernel: S^T accumulated as two independent partial sums (0: one 8-deep dependent chain)
 #endif
+#ifndef RV_ATTN_SMSPLIT
+#define RV_ATTN_SMSPLIT 0
+#endif
 #ifndef RV_ATTN_FWD_PRIO
 #define RV_ATTN_FWD_PRIO 1     // 1 = s_setprio 1 in the QK^T / PV MFMA phases (measured -0.5..-3 % vs 0, profiles/r02_attn_fwd_prio.log); 2 = in the softmax section (+1..2 %)
 #endif
@@ -384,10 +420,61 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kt][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = xhalf_max(tmax);
         const float m_new = fmaxf(m_run, tmax * c);
         const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);   // row still empty
         const float neg_m = (m_new == -INFINITY) ? 0.f : -m_new;     // a fully masked row keeps p = exp2(-inf) = 0
+#if RV_ATTN_SMSPLIT
+        // Exponentials in four slices of 16 keys, each computed UNDER the PV MFMAs of the previous slice (the matrix pipe runs
+        // asynchronously: between two MFMA issues of a wave ~5 VALU slots are free): slice kk+1's 8 v_fma / v_exp / v_add go two
+        // per MFMA of slice kk.  Only the maximum has to be complete before the first exponential.
+        float psum = 0.f;
+        m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                // the running maximum rarely moves after the first tiles
+#pragma unroll
+          for (int e = 0; e < ET; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[e][r] *= alpha;
+        }
+        auto exp_slice = [&](int kk, int j0, int j1) {      // elements j0..j1-1 (of 8) of slice kk
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j < j0 || j >= j1 || ABL == 1) continue;
+            const int r = (kk & 1) * 8 + j;
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kk >> 1][r], c, neg_m));
+            sacc[kk >> 1][r] = p;
+            psum += p;
+          }
+        };
+        exp_slice(0, 0, 8);
+        if (RV_ATTN_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (RV_ATTN_FWD_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8_t pf = pack_frag(sacc[kk >> 1], (kk & 1) * 8);
+          bf16x8_t (&vcur)[ET] = (kk & 1) ? vB : vA;
+          bf16x8_t (&vnxt)[ET] = (kk & 1) ? vA : vB;
+          if (kk < 3) {
+#pragma unroll
+            for (int e = 0; e < ET; ++e) vnxt[e] = tro.read(vs_addr, (kk + 1) * 16, e);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ET) : "memory");   // everything older than the 2*ET reads just issued
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < ET; ++e) {
+            if (ABL != 2) o[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[e], pf, o[e], 0, 0, 0);
+            if (kk < 3) {
+              exp_slice(kk + 1, (8 / ET) * e, (8 / ET) * (e + 1));
+              __builtin_amdgcn_sched_barrier(0);              // keep the slice pieces between the MFMAs
+            }
+          }
+        }
+        psum = xhalf_sum(psum);
+        l_run = l_run * alpha + psum;
+      }
+#else
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -398,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
             sacc[kt][r] = p;
             psum += p;
           }
-        psum += __shfl_xor(psum, 32, 64);
+        psum = xhalf_sum(psum);
         l_run = l_run * alpha + psum;
         m_run = m_new;
         if (!__all(alpha == 1.0f)) {                // the running maximum rarely moves after the first tiles
@@ -429,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
           }
         }
       }
+#endif
       if (RV_ATTN_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -545,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 #pragma unroll
         for (int j = 0; j < 8; ++j) delta_q = fmaf(bf2f((bf16_t)dof[ks][j]), bf2f((bf16_t)of[j]), delta_q);
       }
-      delta_q += __shfl_xor(delta_q, 32, 64);
+      delta_q = xhalf_sum(delta_q);
       if (q < L && half == 0) delta[((long)s * H + h) * L + q] = delta_q;
     }
     f32x16_t dq[ET];
