@@ -280,7 +280,7 @@ struct TileDma {
 #define RV_DKV_S2 1            // dK/dV kernel: S^T accumulated as two independent partial sums (0: one 8-deep dependent chain)
 #endif
 #ifndef RV_ATTN_SMSPLIT
-#define RV_ATTN_SMSPLIT 0
+#define RV_ATTN_SMSPLIT 1      // softmax / dS slices computed under the MFMAs of the previous slice (round 3: forward -2.7 %)
 #endif
 #ifndef RV_ATTN_FWD_PRIO
 #define RV_ATTN_FWD_PRIO 1     // 1 = s_setprio 1 in the QK^T / PV MFMA phases (measured -0.5..-3 % vs 0, profiles/r02_attn_fwd_prio.log); 2 = in the softmax section (+1..2 %)
@@ -702,6 +702,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
           const bool need_mask = (k0 + 63 >= L) || (CAUSAL && k0 + 63 > q0w) ||
                                  (q0w + 31 >= e1 && k0 + 63 >= sh && k0 < e1);
           if (need_mask) qmask.apply(sacc, k0 + kt * 32 + 4 * half);
+#if RV_ATTN_SMSPLIT
+          // dS of the second 16 keys is computed UNDER the dQ MFMAs of the first 16 (two elements per MFMA gap), see the forward
+          auto ds_elems = [&](int r0, int r1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (r < r0 || r >= r1) continue;
+              const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse_q));   // masked: exp2(-inf) = 0
+              sacc[r] = p * (pacc[r] - delta_q);
+            }
+          };
+          ds_elems(0, 8);
+          {
+            const bf16x8_t df = pack_frag(sacc, 0);
+#pragma unroll
+            for (int e = 0; e < ET; ++e) kfr1[e] = tro.read(ks_addr, kt * 32 + 16, e);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ET) : "memory");     // kfr0 landed; kfr1 may still be in flight
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < ET; ++e) {
+              dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr0[e], df, dq[e], 0, 0, 0);
+              ds_elems(8 + (8 / ET) * e, 8 + (8 / ET) * (e + 1));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#else
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse_q));   // masked: exp2(-inf) = 0
@@ -716,6 +741,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 #pragma unroll
             for (int e = 0; e < ET; ++e) dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr0[e], df, dq[e], 0, 0, 0);
           }
+#endif
           {
             const bf16x8_t df = pack_frag(sacc, 8);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
