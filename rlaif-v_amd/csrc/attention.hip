@@ -702,31 +702,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
           const bool need_mask = (k0 + 63 >= L) || (CAUSAL && k0 + 63 > q0w) ||
                                  (q0w + 31 >= e1 && k0 + 63 >= sh && k0 < e1);
           if (need_mask) qmask.apply(sacc, k0 + kt * 32 + 4 * half);
-#if RV_ATTN_SMSPLIT
-          // dS of the second 16 keys is computed UNDER the dQ MFMAs of the first 16 (two elements per MFMA gap), see the forward
-          auto ds_elems = [&](int r0, int r1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if (r < r0 || r >= r1) continue;
-              const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse_q));   // masked: exp2(-inf) = 0
-              sacc[r] = p * (pacc[r] - delta_q);
-            }
-          };
-          ds_elems(0, 8);
-          {
-            const bf16x8_t df = pack_frag(sacc, 0);
-#pragma unroll
-            for (int e = 0; e < ET; ++e) kfr1[e] = tro.read(ks_addr, kt * 32 + 16, e);
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ET) : "memory");     // kfr0 landed; kfr1 may still be in flight
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < ET; ++e) {
-              dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr0[e], df, dq[e], 0, 0, 0);
-              ds_elems(8 + (8 / ET) * e, 8 + (8 / ET) * (e + 1));
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-#else
+          // (Round 3 tried computing dS of the second 16 keys under the dQ MFMAs of the first 16, as the forward does with its
+          // softmax slices: neutral to +1 % slower here - 4 VALU per element and 246 live registers leave the gaps no room;
+          // profiles/r03_attn_smsplit_fwd_dq.log.)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lse_q));   // masked: exp2(-inf) = 0
@@ -741,7 +719,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 #pragma unroll
             for (int e = 0; e < ET; ++e) dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr0[e], df, dq[e], 0, 0, 0);
           }
-#endif
           {
             const bf16x8_t df = pack_frag(sacc, 8);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
