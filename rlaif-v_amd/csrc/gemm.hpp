@@ -1310,6 +1310,28 @@ __device__ __forceinline__ uint4 epi_pack8(const float (&f)[8]) {
   v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
   return v;
 }
+// Lanes l and l + 32 hold the two 4-column halves of the same row's 8-column groups (a: group 2g, b: group 2g + 1).  One
+// exchange gives lane l {own a | partner's a} = columns 0-7 and lane l + 32 {partner's b | own b} = columns 8-15.  Round 3:
+// v_permlane32_swap (upper half of the first operand <-> lower half of the second: exactly this exchange, one VALU op for
+// both outputs) instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32 + two v_cndmask + an lgkmcnt wait - 64 LDS round
+// trips per wave per output tile in an epilogue nothing overlaps.  Same bits.
+#ifndef RV_EPI_PERMLANE
+#define RV_EPI_PERMLANE 1
+#endif
+__device__ __forceinline__ void epi_xhalf(float a, float b, int half, float& lo, float& hi) {
+#if RV_EPI_PERMLANE
+  (void)half;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  const u32x2_t r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  lo = __builtin_bit_cast(float, (unsigned)r[0]);
+  hi = __builtin_bit_cast(float, (unsigned)r[1]);
+#else
+  const float recv = __shfl_xor(half ? a : b, 32);
+  lo = half ? recv : a;
+  hi = half ? b : recv;
+#endif
+}
+
 __device__ __forceinline__ uint32_t gemm_mix32(uint32_t h) {    // same mixer as dropout_kernel (elementwise.hip)
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
@@ -1357,9 +1379,7 @@ struct EpiStore {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float a = acc[tm][tn][(2 * rgp) * 4 + j] * alpha, b = acc[tm][tn][(2 * rgp + 1) * 4 + j] * alpha;
-            const float recv = __shfl_xor(half ? a : b, 32);
-            v[j] = half ? recv : a;
-            v[4 + j] = half ? b : recv;
+            epi_xhalf(a, b, half, v[j], v[4 + j]);
           }
           const int n = nw + tn * 32 + rgp * 16 + 8 * half;
           if (n >= N) continue;
@@ -1474,9 +1494,7 @@ struct EpiSwiGLU {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float a = acc[tm][tn][(2 * rgp) * 4 + j], b = acc[tm][tn][(2 * rgp + 1) * 4 + j];
-            const float recv = __shfl_xor(half ? a : b, 32);
-            v[j] = half ? recv : a;
-            v[4 + j] = half ? b : recv;
+            epi_xhalf(a, b, half, v[j], v[4 + j]);
           }
           const int n = nw + tn * 32 + rgp * 16 + 8 * half;
           if (n >= N) continue;
@@ -1533,9 +1551,7 @@ struct EpiSwiGLUBwd {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float a = acc[tm][tn][(2 * rgp) * 4 + j], b = acc[tm][tn][(2 * rgp + 1) * 4 + j];
-            const float recv = __shfl_xor(half ? a : b, 32);
-            v[j] = half ? recv : a;
-            v[4 + j] = half ? b : recv;
+            epi_xhalf(a, b, half, v[j], v[4 + j]);
           }
           const int n = nw + tn * 32 + rgp * 16 + 8 * half;
           float da[8], gu0[8], gu1[8], o0[8], o1[8];
