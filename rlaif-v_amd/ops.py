@@ -435,7 +435,11 @@ def lmhead_logp_bwd(h, w, tgt, lse, coef, n_rows: int, out: Optional[torch.Tenso
     V = w.shape[0]
     v_valid = V if v_valid is None else v_valid
     if out is None:
-        out = torch.zeros(h.shape[0], V, dtype=BF16, device=h.device)
+        # the kernel writes every row < n_rows completely (padding columns as zeros); only the < 64 padding ROWS need clearing -
+        # not a 1.4 GB fill of the whole tensor
+        out = torch.empty(h.shape[0], V, dtype=BF16, device=h.device)
+        if h.shape[0] > n_rows:
+            out[n_rows:].zero_()
     hip.call("rv_lmhead_logp_bwd", h, h.stride(0), w, w.stride(0), tgt, lse, coef, out, out.stride(0), n_rows, V, v_valid,
              h.shape[1], -1)
     return out
