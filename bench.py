@@ -284,6 +284,9 @@ def main():
     timer = GemmTimer()
     if not args.no_gemm_timer:
         timer.install()
+    import gc
+    gc.collect()
+    gc.disable()            # no cyclic-GC pause of the launching thread inside the timed region (single steps showed +70 ms hiccups)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -295,6 +298,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
