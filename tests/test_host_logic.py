@@ -492,3 +492,47 @@ def test_omni_preprocess_matches_reference_golden(golden_dir):
     assert ids.count(9) == 4 and ids[-2:] == [6, 3]                            # 4 patches; ends with "<|assistant|>\n"
     with pytest.raises(AssertionError):
         omni_preprocess([[{"role": "user", "content": "a"}, {"role": "user", "content": "b"}]], tok)
+
+
+def test_full_depth_harness_compare_logic():
+    """tests/full_depth.py::compare (the checker of the full-depth fixtures) on synthetic records: a HIP record equal to the
+    fixture up to bf16-level noise passes every bar; a wrong target id, a 1 % loss error, a rotated gradient or a sign-flipped
+    update each trip their own assertion.  (The real records only exist on the GPU box.)"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import copy
+    import full_depth as FD
+    g = torch.Generator().manual_seed(0)
+    S, L = 8, 40
+    labels = torch.full((S, L), -100, dtype=torch.int64)
+    labels[:, 20:36] = torch.randint(3, 500, (S, 16), generator=g)
+    mask = labels[:, 1:] != -100
+    per_tok = -11.0 + torch.randn(int(mask.sum()), generator=g)
+    seq = torch.stack([per_tok[i * 16:(i + 1) * 16].sum() for i in range(S)])
+    lr, clip = 5e-7, 1.2e-3
+    names = ["model.layers.0.mlp.down_proj.weight", "model.norm.weight"]
+    gs = {k: torch.randn(FD.N_SAMPLE, generator=g) * 1e-2 for k in names}
+    w0 = {k: torch.randn(4096, generator=g) * 0.02 for k in names}
+    post = {k: w0[k][FD.sample_index(k, 4096)] - lr * torch.sign(gs[k]) for k in names}
+    fx = dict(case="cfg1_step", layers=32, labels=labels, per_token=per_tok, log_prob=seq, loss=13.78,
+              emu_per_token=per_tok + 0.04 * torch.randn(per_tok.shape, generator=g), emu_log_prob=seq * 1.0002, emu_loss=13.79,
+              grad_norms={k: float(v.norm()) for k, v in gs.items()}, grad_samples=gs, post_samples=post,
+              grad_norm_total=811.0, clip_coef=clip, lr=lr)
+    noise = lambda t, s: t + s * torch.randn(t.shape, generator=g)                      # noqa: E731
+    hip = dict(tgt=labels[:, 1:][mask], seq_cnt=mask.sum(1).float(), log_prob=seq * (1 + 1e-4), per_token=noise(per_tok, 0.02),
+               loss=13.78 * (1 + 2e-4), grad_norms={k: v * 1.002 for k, v in fx["grad_norms"].items()},
+               grad_samples={k: noise(v, 3e-4) for k, v in gs.items()}, grad_norm_total=811.5, clip_coef=clip * 0.9995,
+               post_samples={k: v.clone() for k, v in post.items()}, m_samples={k: 0.1 * clip * v for k, v in gs.items()})
+    m = FD.compare("cfg1_step", hip, fx, W0=w0, check=True)
+    assert m["indexing_bit_exact"] and m["master_update_agree_frac"] == 1.0 and m["grad_worst_sample_cosine"] > 0.999
+    bad = copy.deepcopy(hip); bad["tgt"] = hip["tgt"].clone(); bad["tgt"][3] += 1
+    with pytest.raises(AssertionError, match="indexing"):
+        FD.compare("cfg1_step", bad, fx, W0=w0)
+    bad = copy.deepcopy(hip); bad["loss"] = 13.78 * 1.01
+    with pytest.raises(AssertionError):
+        FD.compare("cfg1_step", bad, fx, W0=w0)
+    bad = copy.deepcopy(hip); bad["grad_samples"][names[0]] = torch.randn(FD.N_SAMPLE, generator=g) * 1e-2
+    with pytest.raises(AssertionError):
+        FD.compare("cfg1_step", bad, fx, W0=w0)
+    bad = copy.deepcopy(hip); bad["post_samples"][names[0]] = w0[names[0]][FD.sample_index(names[0], 4096)] + lr * torch.sign(gs[names[0]])
+    with pytest.raises(AssertionError):
+        FD.compare("cfg1_step", bad, fx, W0=w0)
