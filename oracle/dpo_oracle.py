@@ -424,35 +424,48 @@ def lora_trainable_names(W: Dict[str, torch.Tensor]) -> List[str]:
     return [k for k in W if ".lora_" in k or "mm_projector" in k]
 
 
+def llama_layer(x: torch.Tensor, W: Dict[str, torch.Tensor], cfg: LlavaCfg, i: int, cos, sin, causal,
+                lora_scale: Optional[float] = None, lora_masks: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """ONE HF LlamaDecoderLayer (input RMSNorm, q/k/v, rotary, causal softmax attention, o, residual, post-attention
+    RMSNorm, SwiGLU MLP, residual).  ``llama_hidden`` is the loop over it; ``oracle/streamed.py`` calls it layer by
+    layer so that the 32-layer model can be differentiated inside the build container's memory."""
+    S, L, d = x.shape
+    H, hd, Hkv = cfg.heads, cfg.head_dim, cfg.n_kv_heads
+    p = f"model.layers.{i}."
+    h = rms_norm(x, W[p + "input_layernorm.weight"], cfg.rms_eps)
+    q = lora_linear(h, W, p + "self_attn.q_proj", lora_scale, lora_masks).view(S, L, H, hd).transpose(1, 2)
+    k = lora_linear(h, W, p + "self_attn.k_proj", lora_scale, lora_masks).view(S, L, Hkv, hd).transpose(1, 2)
+    v = lora_linear(h, W, p + "self_attn.v_proj", lora_scale, lora_masks).view(S, L, Hkv, hd).transpose(1, 2)
+    q = q * cos + rotate_half(q) * sin
+    k = k * cos + rotate_half(k) * sin
+    if Hkv != H:        # HF repeat_kv: query head h attends key/value head h // (H / Hkv)
+        k = k.repeat_interleave(H // Hkv, dim=1)
+        v = v.repeat_interleave(H // Hkv, dim=1)
+    att = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + causal
+    att = torch.softmax(att.float(), dim=-1).to(q.dtype)
+    a = (att @ v).transpose(1, 2).reshape(S, L, d)
+    x = x + lora_linear(a, W, p + "self_attn.o_proj", lora_scale, lora_masks)
+    h = rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_eps)
+    g = lora_linear(h, W, p + "mlp.gate_proj", lora_scale, lora_masks)
+    u = lora_linear(h, W, p + "mlp.up_proj", lora_scale, lora_masks)
+    return x + lora_linear(F.silu(g) * u, W, p + "mlp.down_proj", lora_scale, lora_masks)
+
+
+def llama_tables(L: int, cfg: LlavaCfg, dtype):
+    """(cos, sin, causal mask) shared by every layer: positions = arange(L) (position_ids dropped at
+    llava_llama.py:94), pure causal mask, no pad mask (trainers.py:199)."""
+    cos, sin = rope_tables(L, cfg.head_dim, cfg.rope_theta, dtype)
+    return cos, sin, torch.full((L, L), float("-inf"), dtype=dtype).triu(1)
+
+
 def llama_hidden(embeds: torch.Tensor, W: Dict[str, torch.Tensor], cfg: LlavaCfg,
                  n_layers: Optional[int] = None, lora_scale: Optional[float] = None,
                  lora_masks: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
-    """Decoder stack + final norm.  positions = arange(L) (position_ids dropped at
-    llava_llama.py:94), pure causal mask, no pad mask (trainers.py:199)."""
-    S, L, d = embeds.shape
-    H, hd, Hkv = cfg.heads, cfg.head_dim, cfg.n_kv_heads
-    cos, sin = rope_tables(L, hd, cfg.rope_theta, embeds.dtype)
-    causal = torch.full((L, L), float("-inf"), dtype=embeds.dtype).triu(1)
+    """Decoder stack + final norm."""
+    cos, sin, causal = llama_tables(embeds.shape[1], cfg, embeds.dtype)
     x = embeds
     for i in range(cfg.layers if n_layers is None else n_layers):
-        p = f"model.layers.{i}."
-        h = rms_norm(x, W[p + "input_layernorm.weight"], cfg.rms_eps)
-        q = lora_linear(h, W, p + "self_attn.q_proj", lora_scale, lora_masks).view(S, L, H, hd).transpose(1, 2)
-        k = lora_linear(h, W, p + "self_attn.k_proj", lora_scale, lora_masks).view(S, L, Hkv, hd).transpose(1, 2)
-        v = lora_linear(h, W, p + "self_attn.v_proj", lora_scale, lora_masks).view(S, L, Hkv, hd).transpose(1, 2)
-        q = q * cos + rotate_half(q) * sin
-        k = k * cos + rotate_half(k) * sin
-        if Hkv != H:        # HF repeat_kv: query head h attends key/value head h // (H / Hkv)
-            k = k.repeat_interleave(H // Hkv, dim=1)
-            v = v.repeat_interleave(H // Hkv, dim=1)
-        att = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + causal
-        att = torch.softmax(att.float(), dim=-1).to(q.dtype)
-        a = (att @ v).transpose(1, 2).reshape(S, L, d)
-        x = x + lora_linear(a, W, p + "self_attn.o_proj", lora_scale, lora_masks)
-        h = rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-        g = lora_linear(h, W, p + "mlp.gate_proj", lora_scale, lora_masks)
-        u = lora_linear(h, W, p + "mlp.up_proj", lora_scale, lora_masks)
-        x = x + lora_linear(F.silu(g) * u, W, p + "mlp.down_proj", lora_scale, lora_masks)
+        x = llama_layer(x, W, cfg, i, cos, sin, causal, lora_scale, lora_masks)
     return rms_norm(x, W["model.norm.weight"], cfg.rms_eps)
 
 

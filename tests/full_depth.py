@@ -36,15 +36,32 @@ CASES = {
     "cfg1_step": dict(seed=41, pairs=4, text_len=512, prompt_len=64, ragged=True, answer_lens=None, lr=5e-7, step=True),
     "cfg2_fwd": dict(seed=42, pairs=1, text_len=2048 - 575, prompt_len=64, ragged=False, answer_lens=[(1409, 704)],
                      lr=None, step=False),
+    # round 4: produced by the layer-streamed oracle inside the build container
+    # (tools/full_depth_oracle_streamed.py).  cfg2_step = BASELINE config 2's packed shape, TWO pairs at L = 2048 with ragged
+    # answers, forward + backward + clip + AdamW.  *_cond = the same batch with the reference log-probs set to the oracle's own
+    # fp32 policy log-probs shifted so that beta*z takes the listed values per pair: the regime DPO training starts in
+    # (z = 0, every pair's coefficient ~ beta/2), where the loss is NOT beta x a large log-prob difference.
+    "cfg1_cond": dict(base="cfg1_step", beta_z=[-0.5, 0.0, 0.5, 1.0], lr=5e-7, step=True),
+    "cfg2_step": dict(seed=43, pairs=2, text_len=2048 - 575, prompt_len=64, ragged=True, answer_lens=None, lr=5e-7, step=True),
+    "cfg2_cond": dict(base="cfg2_step", beta_z=[0.0, 1.0], lr=5e-7, step=True),
 }
+
+
+def base_case(case: str) -> str:
+    return CASES[case].get("base", case)
 
 
 def make_cfg(layers: int = 32) -> O.LlavaCfg:
     return O.LlavaCfg(layers=layers, model_max_length=2048)
 
 
-def make_batch(case: str, cfg: O.LlavaCfg):
-    c = CASES[case]
+def make_batch(case: str, cfg: O.LlavaCfg, fx: Optional[Dict[str, object]] = None):
+    """The case's synthetic batch; a conditioned case takes its reference log-probs from the oracle fixture ``fx``."""
+    c = CASES[base_case(case)]
+    if "beta_z" in CASES[case]:
+        batch = make_batch(base_case(case), cfg)
+        batch["ref_win_logp"], batch["ref_rej_logp"] = fx["ref_win_logp"].clone(), fx["ref_rej_logp"].clone()
+        return batch
     return O.make_synthetic_batch(cfg, c["pairs"], c["text_len"], c["prompt_len"], seed=c["seed"], ragged=c["ragged"],
                                   answer_lens=c["answer_lens"])
 
@@ -108,6 +125,82 @@ def oracle_case(case: str, W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, emulate:
     return fx
 
 
+def conditioned_refs(pw: torch.Tensor, pr: torch.Tensor, beta_z, beta: float):
+    """Reference log-probs that put pair i at beta * z_i = beta_z[i] for the policy log-probs (pw, pr):
+    z = (pw - pr) - (rw - rr)  ->  rw = pw, rr = pr + z_i   (muffin/train/trainers.py:112-116)."""
+    z = torch.tensor(beta_z, dtype=torch.float32) / beta
+    return dict(ref_win_logp=pw.detach().float().clone(), ref_rej_logp=(pr.detach().float() + z).clone())
+
+
+def oracle_streamed(base: str, W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, cond_case: Optional[str], emu_from: Optional[dict] = None,
+                    own_refs: bool = True, log=print) -> Dict[str, Dict[str, object]]:
+    """The oracle for ``base`` (own reference log-probs) and its conditioned sibling ``cond_case`` off ONE forward, evaluated
+    layer by layer (oracle/streamed.py: the same functions as dpo_oracle.dpo_train_step, chain rule by hand at the layer
+    boundaries) so that it fits the build container.  W is NOT modified: the AdamW step is applied to the sampled elements.
+    Returns {case: fixture}."""
+    from oracle import streamed as S
+    c = CASES[base]
+    batch = make_batch(base, cfg)
+    common: Dict[str, object] = dict(layers=cfg.layers, weight_seed=WEIGHT_SEED, torch=torch.__version__,
+                                     threads=torch.get_num_threads(), oracle="oracle/streamed.py (layer-streamed)")
+    if emu_from is not None:
+        common.update({k: emu_from[k] for k in ("emu_per_token", "emu_log_prob", "emu_loss")})
+    else:
+        t0 = time.time()
+        bb, Wb = O.emulate_bf16(batch, W)
+        emu = S.dpo_step_streamed(bb, Wb, cfg, backward=False, log=lambda m: log(f"[{base}] bf16 emulation {m}"))
+        e = _fwd_summary(emu)
+        common.update(emu_per_token=e["per_token"], emu_log_prob=e["log_prob"], emu_loss=e["loss"], emu_s=time.time() - t0)
+        del Wb, emu, bb
+        log(f"[{base}] bf16-emulated oracle forward: {common['emu_s']:.0f} s")
+    cases, var_of = [], {}
+
+    def variants(pw, pr):
+        vs = []
+        if own_refs:
+            cases.append(base)
+            vs.append(dict(ref_win_logp=batch["ref_win_logp"], ref_rej_logp=batch["ref_rej_logp"]))
+        if cond_case is not None:
+            cases.append(cond_case)
+            vs.append(conditioned_refs(pw, pr, CASES[cond_case]["beta_z"], batch["beta"]))
+        for cs, v in zip(cases, vs):
+            var_of[cs] = v
+        return vs
+
+    acc = [dict(gnorm={}, gsamp={}, sumsq=0.0) for _ in range(2)]
+
+    def sink(v, name, g):
+        a = acc[v]
+        ss = float(g.double().pow(2).sum())
+        a["sumsq"] += ss
+        a["gnorm"][name] = math.sqrt(ss)
+        a["gsamp"][name] = g.flatten()[sample_index(name, g.numel())].float().clone()
+
+    ph: Dict[str, float] = {}
+    res = S.dpo_step_streamed(batch, W, cfg, variants=variants, grad_sink=sink, timings=ph, log=lambda m: log(f"[{base}] {m}"))
+    out = {}
+    for v, cs in enumerate(cases):
+        cc = CASES[cs]
+        fx = dict(common, case=cs)
+        ref = dict(res, loss=res["variants"][v]["loss"])
+        fx.update(_fwd_summary(ref), losses=res["variants"][v]["losses"].detach().float().clone(), timings=dict(ph), lr=cc["lr"],
+                  n_variants=len(cases))
+        if "beta_z" in cc:
+            fx.update(beta_z=list(cc["beta_z"]), ref_win_logp=var_of[cs]["ref_win_logp"], ref_rej_logp=var_of[cs]["ref_rej_logp"])
+        a = acc[v]
+        gn = math.sqrt(a["sumsq"])
+        clip = min(1.0, 1.0 / (gn + 1e-6))
+        psamp = {}
+        for k, g in a["gsamp"].items():                                   # AdamW step 1 on the sampled elements (elementwise)
+            p = W[k].detach().flatten()[sample_index(k, W[k].numel())].float().clone()
+            O.adamw_reference({k: p}, {k: g * clip}, {}, cc["lr"], 1, max_grad_norm=None)
+            psamp[k] = p
+        fx.update(grad_norms=a["gnorm"], grad_samples=a["gsamp"], post_samples=psamp, grad_norm_total=gn, clip_coef=clip)
+        out[cs] = fx
+        log(f"[{cs}] loss {fx['loss']:.6f}, |g| {gn:.4f}, clip {clip:.3e}; fwd {ph['fwd_s']:.0f} s, bwd ({len(cases)} variants) {ph['bwd_s']:.0f} s")
+    return out
+
+
 def save_fixture(fx: Dict[str, object], path: str):
     torch.save({k: v for k, v in fx.items() if not k.startswith("_")}, path)
 
@@ -140,16 +233,34 @@ def _take(view: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return view[idx // cols, idx % cols].float().cpu()
 
 
-def hip_case(case: str, model, trainer, cfg: O.LlavaCfg, full_grads: bool = False) -> Dict[str, object]:
-    """The HIP path on the case's batch: compute_loss (+ backward + clip + AdamW for cfg1_step), through the C ABI."""
+def snapshot(model):
+    """Device copy of the bf16 parameters, so that several stepping cases can start from the same weights."""
+    return model.store.flat_p.clone()
+
+
+def restore(model, trainer, snap: torch.Tensor):
+    st = model.store
+    st.flat_p.copy_(snap)
+    st.sync_master_from_params()
+    st.refresh_transposes()
+    st.flat_m.zero_()
+    st.flat_v.zero_()
+    trainer.state["global_step"] = 0
+
+
+def hip_case(case: str, model, trainer, cfg: O.LlavaCfg, full_grads: bool = False, fx: Optional[Dict[str, object]] = None
+             ) -> Dict[str, object]:
+    """The HIP path on the case's batch: compute_loss (+ backward + clip + AdamW for the stepping cases), through the C ABI.
+    Conditioned cases read their reference log-probs from the oracle fixture ``fx``."""
     c = CASES[case]
-    batch = make_batch(case, cfg)
+    batch = make_batch(case, cfg, fx)
     model.train(c["step"])
     loss = trainer.compute_loss(model, dict(batch))
     out = model.last_out
     res: Dict[str, object] = dict(tgt=out.plan.tgt.cpu().long(), seq_cnt=out.seq_cnt.cpu(), log_prob=out.seq_logp.float().cpu(),
                                   per_token=out.per_token_logp.float().cpu(), loss=float(loss), plan_S=out.plan.S, plan_L=out.plan.L,
-                                  spliced_labels=out.plan.labels.cpu() if out.plan.labels is not None else None)
+                                  spliced_labels=out.plan.labels.cpu() if out.plan.labels is not None else None,
+                                  losses=out.per_pair[0].float().cpu() if getattr(out, "per_pair", None) is not None else None)
     if not c["step"]:
         return res
     model.backward(out, model.last_coef)
@@ -199,10 +310,42 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
         m["emu_bf16_per_token_mean_abs_err"], m["emu_bf16_per_token_max_abs_err"] = float(e.mean()), float(e.max())
         m["emu_bf16_seq_logp_max_rel_err"] = float(((fx["emu_log_prob"] - lp_ref).abs() / lp_ref.abs()).max())
         m["emu_bf16_loss_rel_err"] = abs(fx["emu_loss"] - fx["loss"]) / abs(fx["loss"])
+    sd = hip["per_token"] - fx["per_token"]
+    m["per_token_mean_signed_err"], m["per_token_rms_err"] = float(sd.mean()), float(sd.pow(2).mean().sqrt())
+    cond = "beta_z" in c
+    if cond:
+        # the quantity DPO consumes: the logit beta*z = beta*((pw - pr) - (rw - rr)) per pair.  Its error is a SUM of n
+        # per-token errors; with the bf16-emulated oracle's per-token RMS error as the yardstick an unbiased bf16
+        # implementation lands within ~ beta * rms_emu * sqrt(n) (the emulation itself does: logged next to it).
+        beta = float(fx.get("beta", 0.1))
+        B = lp.numel() // 2
+        n_pair = (mask[:B].sum(1) + mask[B:].sum(1)).float()
+        dd = beta * ((lp[:B] - lp[B:]) - (lp_ref[:B] - lp_ref[B:]))
+        m["beta_z"], m["logit"] = list(c["beta_z"]), (beta * ((lp[:B] - lp[B:]) - (fx["ref_win_logp"] - fx["ref_rej_logp"]))).tolist()
+        m["logit_abs_err"] = dd.abs().tolist()
+        m["losses"], m["losses_oracle"] = (hip["losses"].tolist() if hip.get("losses") is not None else None), fx["losses"].tolist()
+        m["loss_abs_err"] = abs(hip["loss"] - fx["loss"])
+        if "emu_per_token" in fx:
+            el = fx["emu_log_prob"].float()
+            de = beta * ((el[:B] - el[B:]) - (lp_ref[:B] - lp_ref[B:]))
+            ez = beta * ((el[:B] - el[B:]) - (fx["ref_win_logp"] - fx["ref_rej_logp"]))
+            emu_loss = float((-torch.nn.functional.logsigmoid(ez)).mean())
+            rms_emu = float((fx["emu_per_token"] - fx["per_token"]).pow(2).mean().sqrt())
+            m["emu_bf16_logit_abs_err"], m["emu_bf16_loss_abs_err"] = de.abs().tolist(), abs(emu_loss - fx["loss"])
+            m["emu_bf16_per_token_rms_err"] = rms_emu
+            m["logit_err_bar_3sigma"] = (3.0 * beta * rms_emu * n_pair.sqrt()).tolist()
+            m["logit_err_in_sigmas"] = (dd.abs() / (beta * rms_emu * n_pair.sqrt())).tolist()
+            m["emu_bf16_logit_err_in_sigmas"] = (de.abs() / (beta * rms_emu * n_pair.sqrt())).tolist()
     if check:
         assert idx_ok, "token indexing differs from the oracle's spliced labels"
         assert m["seq_logp_max_rel_err"] <= 1e-3, m["seq_logp_max_rel_err"]
-        assert m["loss_rel_err"] <= 1e-3, (m["loss"], m["loss_oracle"])
+        if not cond:
+            assert m["loss_rel_err"] <= 1e-3, (m["loss"], m["loss_oracle"])
+        elif "emu_per_token" in fx:
+            # conditioned regime: loss ~ ln 2, |d loss / d logit| <= 1: the loss error is bounded by the mean logit error
+            assert max(m["logit_err_in_sigmas"]) <= 3.0, (m["logit_abs_err"], m["logit_err_bar_3sigma"])
+            assert m["per_token_rms_err"] <= m["emu_bf16_per_token_rms_err"], (m["per_token_rms_err"], m["emu_bf16_per_token_rms_err"])
+            assert m["loss_abs_err"] <= sum(m["logit_err_bar_3sigma"]) / len(m["logit_err_bar_3sigma"]), m["loss_abs_err"]
         if "emu_per_token" in fx:
             assert m["per_token_mean_abs_err"] <= m["emu_bf16_per_token_mean_abs_err"], \
                 (m["per_token_mean_abs_err"], m["emu_bf16_per_token_mean_abs_err"])
@@ -261,7 +404,7 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
         # step 1 of Adam moves every weight by ~lr * sign(g): a mismatch is a SIGN flip of a gradient element that sits inside
         # the bf16 compute noise (per-tensor cosine 0.993-0.9999 = 1-11 % relative noise -> 1-4 % of the elements).  Measured
         # on the GPU box: 95.1 % of all sampled elements agree (profiles/r03_parity_full_depth.json).
-        assert m["master_update_agree_frac"] >= 0.93, m["master_update_agree_frac"]
+        # (logged, no bar of its own: VERDICT r3 weak 1 - a bar fitted to the measurement says nothing)
         # ... and where the gradient is NOT noise-level (|g| >= a quarter of its tensor's RMS: 70 % of the elements) the update
         # must agree almost everywhere (measured 99.90 %)
         assert m["master_update_agree_frac_large_grads"] >= 0.995, m["master_update_agree_frac_large_grads"]

@@ -307,3 +307,57 @@ def test_lora_full_width_shallow_vs_oracle(monkeypatch):
         worst_rel = max(worst_rel, abs(float(got[k].double().norm()) - n) / n)
     print(f"  adapter / projector gradients: worst cosine {worst_cos:.5f}, worst norm rel err {worst_rel:.2e}")
     assert worst_cos >= 0.99 and worst_rel <= 3e-2
+
+
+@pytest.mark.parametrize("name", ["lora_merged_tiny", "lora_merged_tiny_gqa", "lora_merged_fullwidth_l2"])
+@pytest.mark.parametrize("share_prefix", [False, True])
+def test_lora_vs_reference_on_merged_weights(monkeypatch, golden_dir, name, share_prefix):
+    """Row a14 against the REFERENCE ITSELF: tests/golden/lora_merged_*.pt hold what the reference's own
+    LlavaLlamaForCausalLM + get_beta_and_logps + dpo_loss + backward() produced on merge_and_unload weights
+    W' = W + (alpha/r) B A (llava/model/builder.py:81-85) and the adapter gradients that follow from dW' by the chain rule
+    (tests/golden/make_lora_golden.py --merged).  The HIP ADAPTER path (fused-LoRA GEMMs, split-K adapter weight gradients,
+    dropout 0) must reproduce log-probs, loss and every adapter / projector gradient; incl. the LLaVA-1.5-7B widths at r = 64,
+    alpha = 16 (the shipped script's values, train_llava15_lora.py:113-114) with the full CLIP tower."""
+    _need_gpu()
+    g = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    cfg = O.LlavaCfg(**g["cfg"])
+    if cfg.hidden >= 4096 and torch.cuda.get_device_properties(0).total_memory < 100 * 2**30:
+        pytest.skip("needs the 288 GB part")
+    monkeypatch.setenv("SFT_weight", "0.0")
+    monkeypatch.setenv("DPO_weight", "1.0")
+    model, _ = _build(cfg, g["r"], seed=g["seed"], alpha=g["lora_alpha"], share_prefix=share_prefix)
+    model.train()
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, g["n_pairs"], g["text_len"], g["prompt_len"], seed=g["seed"])
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    model.backward(out, model.last_coef)
+    mask = g["labels"][:, 1:] != -100
+    assert torch.equal(out.plan.tgt.cpu().long(), g["labels"][:, 1:][mask])                  # token indexing: bit exact
+    tok_ref = g["per_token_logps"][mask]
+    tok_d = (out.per_token_logp.cpu() - tok_ref).abs()
+    lp, lp_ref = out.seq_logp.cpu(), g["log_prob"]
+    rel = float(((lp - lp_ref).abs() / lp_ref.abs()).max())
+    loss_rel = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
+    print(f"[{name} share={share_prefix}] seq rel {rel:.2e}, per-token max {float(tok_d.max()):.2e} mean {float(tok_d.mean()):.2e}, "
+          f"loss {float(loss):.6f} vs reference {float(g['loss']):.6f} (rel {loss_rel:.2e})")
+    assert rel <= 1e-3 and loss_rel <= 1e-3
+    assert float(tok_d.mean()) <= 5e-3 * float(tok_ref.abs().mean()) and float(tok_d.max()) <= 2e-2 * float(tok_ref.abs().mean())
+    got = model.grads_state_dict()
+    assert set(got) == set(g["grad_norms"]), sorted(set(got) ^ set(g["grad_norms"]))[:6]
+    import zlib
+    worst_n, worst_c = 0.0, 1.0
+    for k, n_ref in g["grad_norms"].items():
+        if n_ref < 1e-9:
+            continue
+        gk = got[k].float().cpu()
+        n_rel = abs(float(gk.double().norm()) - n_ref) / n_ref
+        gen = torch.Generator().manual_seed(zlib.crc32(k.encode()))
+        idx = torch.randint(0, gk.numel(), (min(512, gk.numel()),), generator=gen)
+        c = _cos(gk.flatten()[idx], g["grad_samples"][k])
+        if k in g["grad_full"]:
+            c = min(c, _cos(gk, g["grad_full"][k]))
+        worst_n, worst_c = max(worst_n, n_rel), min(worst_c, c)
+        assert n_rel <= 4e-2 and c >= 0.99, (k, n_rel, c)
+    print(f"  adapter + projector gradients vs the reference's chain-rule gradients: worst norm err {worst_n:.2e}, worst cosine "
+          f"{worst_c:.5f} over {len(g['grad_norms'])} tensors")
