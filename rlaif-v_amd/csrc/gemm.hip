@@ -334,6 +334,7 @@ int rv_gemm_tn_bf16_ws(const void* P, long ldp, const void* Q, long ldq, void* C
   RV_REQUIRE(I % 8 == 0 && J % 8 == 0 && I >= 8 && J >= 8, "rv_gemm_tn_bf16_ws: I and J must be multiples of 8");
   RV_REQUIRE(ldp % 8 == 0 && ldq % 8 == 0 && ldc % 4 == 0, "rv_gemm_tn_bf16_ws: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
   RV_REQUIRE((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)workspace) & 15) == 0, "rv_gemm_tn_bf16_ws: P/Q/workspace must be 16-byte aligned");
+  RV_REQUIRE(((uintptr_t)C & 7) == 0, "rv_gemm_tn_bf16_ws: C must be 8-byte aligned (the tail reduce stores 4 bf16 at a time)");
   const TnTailPlan p = tn_tail_plan(R, I, J);
   EpiStore epi{(bf16_t*)C, ldc, nullptr, nullptr, 0, RV_ACT_NONE, 1.0f};
   epi.narrow = epi_narrow();

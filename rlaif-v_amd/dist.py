@@ -54,24 +54,51 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
 
 
 class BucketedAllReduce(GradReducer):
-    """Asynchronous bucketed SUM all-reduce over a flat gradient buffer."""
+    """Asynchronous bucketed SUM all-reduce over a flat gradient buffer.
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 400 << 20, force: bool = False):
+    mode (env RV_ALLREDUCE_MODE, default "overlap"; the first multi-GPU run can A/B all three in one command, bench.py dp_diag):
+      overlap  every bucket is all-reduced asynchronously on RCCL's own stream the moment backward finalised it;
+      serial   the same buckets, but the compute stream WAITS for each collective before backward goes on - the fallback
+               should RCCL's persistent workgroups disturb the 256-workgroup GEMMs they run beside (two LDS-filling GEMMs side
+               by side broke each other's XCD lockstep: 1.7-3.6 x, profiles/r03_wgrad_side_stream_negative_result.log);
+      skip     no collective at all (WRONG gradients for world > 1: measurement only - step time without communication).
+    ``timeline``: per-bucket (bytes, enqueue, complete) from device events, see ``last_timeline``."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 400 << 20, force: bool = False,
+                 mode: Optional[str] = None, timeline: bool = False):
         self.flat = flat_grad
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force          # issue the collectives even in a 1-rank group (exercises the RCCL path in tests)
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
+        self.mode = mode or os.environ.get("RV_ALLREDUCE_MODE", "overlap")
+        if self.mode not in ("overlap", "serial", "skip"):
+            raise ValueError(f"RV_ALLREDUCE_MODE must be overlap | serial | skip, got {self.mode!r}")
+        self.timeline = bool(timeline) and flat_grad.is_cuda
         self._pending: Optional[Tuple[int, int]] = None
         self._works: List = []
+        self._events: List = []                        # (bytes, enqueue event, completion event) per collective
         self.launched: List[Tuple[int, int]] = []      # (start, end) of every collective of the current step
+        self.last_timeline: Optional[dict] = None
 
     def _launch(self, start: int, end: int):
         if (self.world_size == 1 and not self.force) or end <= start:
             return
         self.launched.append((start, end))
-        self._works.append(dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group,
-                                           async_op=True))
+        if self.mode == "skip":
+            return
+        ev = None
+        if self.timeline:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()                              # compute stream: the bucket's gradients are final here
+            self._events.append(((end - start) * self.flat.element_size(), ev[0], ev[1]))
+        w = dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.mode == "serial":
+            w.wait()                                    # the compute stream waits: nothing of backward runs beside the collective
+            if ev is not None:
+                ev[1].record()
+        else:
+            self._works.append(w)
 
     def on_bucket_ready(self, name: str, start: int, end: int):
         """Called by backward when flat[start:end] holds final local gradients."""
@@ -89,11 +116,38 @@ class BucketedAllReduce(GradReducer):
         if self._pending is not None:
             self._launch(*self._pending)
             self._pending = None
-        for w in self._works:
-            w.wait()
+        t_end = None
+        if self.timeline and self._events:
+            t_end = torch.cuda.Event(enable_timing=True)
+            t_end.record()                              # backward has been enqueued completely at this point
+        for i, w in enumerate(self._works):
+            w.wait()                                    # collectives of one communicator complete in order
+            if self.timeline:
+                self._events[i][2].record()
         self._works = []
+        if self.timeline and self._events:
+            self._timeline_pending = (self._events, t_end)
+        self._events = []
         done, self.launched = self.launched, []
         return done
+
+    def collect_timeline(self) -> Optional[dict]:
+        """Host side of ``timeline`` (synchronises): per bucket MB, enqueue and completion in ms after the first bucket became
+        ready, and how long after the END of backward the last collective completed (the exposed communication)."""
+        pend = getattr(self, "_timeline_pending", None)
+        if pend is None:
+            return None
+        events, t_end = pend
+        self._timeline_pending = None
+        torch.cuda.synchronize()
+        t0 = events[0][1]
+        rows = [dict(mb=round(nb / 2**20, 1), enqueue_ms=round(t0.elapsed_time(a), 3), done_ms=round(t0.elapsed_time(b), 3))
+                for nb, a, b in events]
+        bw_end = t0.elapsed_time(t_end)
+        self.last_timeline = dict(mode=self.mode, buckets=rows, backward_end_ms=round(bw_end, 3),
+                                  exposed_after_backward_ms=round(max(rows[-1]["done_ms"] - bw_end, 0.0), 3),
+                                  total_mb=round(sum(r["mb"] for r in rows), 1))
+        return self.last_timeline
 
     def reduce_metrics(self, t: torch.Tensor) -> torch.Tensor:
         """Cross-rank mean of a small metric vector in ONE collective."""

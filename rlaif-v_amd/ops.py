@@ -90,11 +90,11 @@ def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None
         need = _TN_WS_NEED.get((R, I, J))
         if need is None:
             need = _TN_WS_NEED[(R, I, J)] = int(hip.lib().lib.rv_gemm_tn_workspace_floats(R, I, J))
-        if need > 0:
-            key = (p.device, torch.cuda.current_stream(p.device).cuda_stream)
-            ws = _TN_WS.get(key)
-            if ws is None or ws.numel() < need:
-                ws = _TN_WS[key] = torch.empty(need, dtype=torch.float32, device=p.device)
+        if need > 0 and out.data_ptr() % 8 == 0:
+            # scratch from the caching allocator per call: it is tied to the CURRENT stream there, freed blocks are recycled
+            # stream-correctly, and nothing outlives the launch (a per-stream-handle cache could hand a new stream that reuses
+            # a destroyed stream's handle a buffer the allocator still associates with the old one - ADVICE r3)
+            ws = torch.empty(need, dtype=torch.float32, device=p.device)
             hip.call("rv_gemm_tn_bf16_ws", p, p.stride(0), q, q.stride(0), out, out.stride(0), R, I, J, ws, ws.numel())
             return out
     hip.call("rv_gemm_tn_bf16", p, p.stride(0), q, q.stride(0), out, out.stride(0), R, I, J, residual,
@@ -102,8 +102,8 @@ def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
-_TN_WS = {}          # (device, stream) -> fp32 workspace of the tail split (one per stream: launches on a stream are ordered)
-_TN_WS_NEED = {}     # (R, I, J) -> floats rv_gemm_tn_workspace_floats asks for
+_TN_WS_NEED = {}     # (R, I, J) -> floats rv_gemm_tn_workspace_floats asks for (RV_TN_TAIL_SPLIT / RV_TN_TAIL_PENALTY are read
+                     # ONCE per process, here and in the library)
 
 
 def _lora_groups(N: int, group_cols: int, group0: int) -> int:

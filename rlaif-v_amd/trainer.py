@@ -365,7 +365,9 @@ class LLaVA15DPOTrainer:
 
     def get_eval_dataloader(self, eval_dataset=None):
         """This rank's share of the WHOLE evaluation set (rank-strided, nothing truncated; the last batch may be partial),
-        like the HF Trainer's evaluation loop."""
+        like the HF Trainer's evaluation loop.  INVARIANT: ranks may run DIFFERENT numbers of evaluation batches, which is only
+        correct because the evaluation forward issues no collective (the one [sums, count] all-reduce of evaluate() happens
+        once per rank, after the loop); a collective added to compute_loss / forward must pad the ranks to equal batch counts."""
         from torch.utils.data import DataLoader
         ds = eval_dataset if eval_dataset is not None else self.eval_dataset
         if ds is None:
@@ -382,6 +384,10 @@ class LLaVA15DPOTrainer:
         every sample of the set is evaluated once; returns the SAMPLE-weighted mean of every metric plus ``eval_loss``
         over all ranks (one fused all-reduce of [sums, count])."""
         was_training = self.model.training
+        # evaluate() overwrites model.last_out / last_coef and the pending metrics: calling it between a training compute_loss
+        # and its backward / pop_metrics would corrupt that step - saved here, restored below (ADVICE r3)
+        saved = (getattr(self.model, "last_out", None), getattr(self.model, "last_coef", None), self._pending_metrics,
+                 getattr(self, "_pending_task", None))
         self.model.eval()
         dev = self.model.device
         tot, cnt = torch.zeros(8, dtype=torch.float32, device=dev), 0
@@ -398,7 +404,7 @@ class LLaVA15DPOTrainer:
         if float(red[8]) <= 0:
             raise ValueError("evaluate(): empty evaluation set")
         mean = (red[:8] / red[8]).tolist()
-        self._pending_metrics = None
+        self.model.last_out, self.model.last_coef, self._pending_metrics, self._pending_task = saved
         m = self._metrics_dict(mean[:7], "test")
         m["eval_loss"] = float(mean[7])
         self.log(m)
@@ -478,9 +484,20 @@ class LLaVA15DPOTrainer:
         st = self.model.store
         blob = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
         want = self._optimizer_layout()
-        # blobs written before the descriptor existed used block gate|up rows and an unpadded vocabulary
-        have = blob.get("layout") or dict(version=0, interleave_gu=False, vocab_padded=int(self.model.cfg.vocab),
-                                          n_train=int(blob["master"].numel()), t0=want["t0"], entries_crc32=None)
+        have = blob.get("layout")
+        if have is None:
+            # A blob from before the descriptor existed has an UNKNOWN layout: the same revision wrote interleaved gate|up rows
+            # by default (RV_FUSE_SWIGLU=1) and block rows otherwise, with the same length - nothing in the blob tells them
+            # apart.  Never guess: the caller names the layout the blob was written under.
+            legacy = os.environ.get("RV_CKPT_LEGACY_LAYOUT", "")
+            if legacy not in ("interleaved", "block"):
+                raise ValueError(f"{path}/optimizer.pt carries no layout descriptor (written before checkpoints recorded the gate|up "
+                                 "row order and vocabulary padding), so its row order cannot be verified.  Set "
+                                 "RV_CKPT_LEGACY_LAYOUT=interleaved (written with the default RV_FUSE_SWIGLU=1) or =block "
+                                 "(RV_FUSE_SWIGLU=0) to state it, or load the HF-layout weights (from_pretrained) and restart the "
+                                 "optimizer")
+            have = dict(version=0, interleave_gu=legacy == "interleaved", vocab_padded=want["vocab_padded"],
+                        n_train=int(blob["master"].numel()), t0=want["t0"], entries_crc32=None)
         diff = [k for k in ("interleave_gu", "vocab_padded", "n_train", "t0") if have.get(k) != want[k]]
         if have.get("entries_crc32") not in (None, want["entries_crc32"]):
             diff.append("entries_crc32")

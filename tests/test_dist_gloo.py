@@ -54,6 +54,18 @@ def _worker(rank, world, port, q, lora=False):
         red.on_bucket_ready(name, a, b)
     red.finish()
     ok_again = torch.allclose(st.flat_g, expect, rtol=1e-6, atol=1e-6)
+    # RV_ALLREDUCE_MODE: "serial" gives the same sums through the same buckets, "skip" issues nothing (measurement only)
+    st.flat_g.copy_(local)
+    red_s = BucketedAllReduce(st.flat_g, bucket_bytes=1 << 20, mode="serial", timeline=True)    # timeline is a no-op on CPU tensors
+    for name, a, b in st.bucket_schedule():
+        red_s.on_bucket_ready(name, a, b)
+    ok_again = ok_again and red_s.finish() == launched and torch.allclose(st.flat_g, expect, rtol=1e-6, atol=1e-6) \
+        and red_s.collect_timeline() is None
+    st.flat_g.copy_(local)
+    red_k = BucketedAllReduce(st.flat_g, bucket_bytes=1 << 20, mode="skip")
+    for name, a, b in st.bucket_schedule():
+        red_k.on_bucket_ready(name, a, b)
+    ok_again = ok_again and red_k.finish() == launched and torch.equal(st.flat_g, local)
     # rank-strided shards of one permutation are disjoint and cover the dataset
 
     class T:

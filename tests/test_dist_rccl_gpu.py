@@ -49,6 +49,29 @@ def test_training_step_with_rccl_bucket_reduce():
         dist.destroy_process_group()
 
 
+def _cat_batches(batches):
+    """Union of collator batches: wins of all shards, then rejects of all shards (rows right-padded to a common width)."""
+    def cat(key):
+        ts = [b[key] for b in batches]
+        if ts[0].dim() == 2:
+            n = max(t.shape[1] for t in ts)
+            fill = -100 if key.endswith("labels") else 0
+            ts = [torch.nn.functional.pad(t, (0, n - t.shape[1]), value=fill) for t in ts]
+        return torch.cat(ts, 0)
+    out = {}
+    for k, v in batches[0].items():
+        if torch.is_tensor(v) and v.dim() > 0 and not k.startswith("concatenated"):
+            out[k] = cat(k)
+        elif not torch.is_tensor(v):
+            out[k] = v
+    from rlaif_v_amd.data import concate_pad
+    out["concatenated_input_ids"] = concate_pad(out["win_input_ids"], out["rej_input_ids"], 0)
+    out["concatenated_labels"] = concate_pad(out["win_labels"], out["rej_labels"], -100)
+    out["concatenated_attention_mask"] = out["concatenated_input_ids"].ne(0)
+    out["concatenated_token_weight"] = concate_pad(out["win_token_weight"], out["rej_token_weight"], 0)
+    return out
+
+
 def _two_rank_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -74,6 +97,25 @@ def _two_rank_worker(rank, world, port, q):
     red = BucketedAllReduce(model.store.flat_g, bucket_bytes=1 << 20)
     tr = LLaVA15DPOTrainer(model=model, args=TrainingArguments(learning_rate=1e-3, warmup_ratio=0.0,
                                                                lr_scheduler_type="constant"), reducer=red)
+    # (1) "2 ranks x B pairs == 1 rank x 2B pairs": the all-reduced gradient / world must equal the gradient of ONE process on the
+    # union of the shards (loss = mean over pairs; the 1/world is folded into the clip factor, flat_g holds the SUM)
+    shards = [O.make_synthetic_batch(cfg, 2, 40, 12, seed=50 + k) for k in range(w)]
+    tr.compute_loss(model, dict(shards[rank]))
+    model.backward(model.last_out, model.last_coef)
+    red.finish()
+    torch.cuda.synchronize()
+    g_dp = model.store.flat_g.float() / w
+    union = _cat_batches(shards)
+    model.grad_ready_hook = None                          # single-process reference: no exchange
+    tr.compute_loss(model, dict(union))
+    model.backward(model.last_out, model.last_coef)
+    torch.cuda.synchronize()
+    g_one = model.store.flat_g.float()
+    cos = float((g_dp.double() @ g_one.double()) / (g_dp.double().norm() * g_one.double().norm()))
+    nrel = abs(float(g_dp.norm()) - float(g_one.norm())) / float(g_one.norm())
+    model.grad_ready_hook = tr._bucket_ready
+    # (2) two optimizer steps on different shards: replicas stay bit-identical
+    start = model.store.flat_master.clone()
     for step in range(2):
         batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=100 + 10 * step + rank)       # a different shard per rank
         loss = tr.training_step(dict(batch))
@@ -83,8 +125,8 @@ def _two_rank_worker(rank, world, port, q):
     other = [torch.empty_like(mine) for _ in range(w)]
     dist.all_gather(other, mine)
     same = all(torch.equal(other[0], t) for t in other)
-    moved = bool((mine != model.store.train_p.float()).any()) or True
-    q.put((rank, same, float(loss), len(m), moved))
+    moved = float((mine != start).float().mean())        # fraction of fp32 masters the two steps moved
+    q.put((rank, same, float(loss), len(m), moved, cos, nrel))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -107,8 +149,11 @@ def test_two_rank_rccl_replicas_stay_identical():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, same, loss, n_metrics, _ in res:
+    for rank, same, loss, n_metrics, moved, cos, nrel in res:
         assert same and loss == loss and n_metrics == 8, (rank, same, loss, n_metrics)
+        assert moved > 0.5, moved                                   # the two steps really moved the weights
+        assert cos >= 0.999 and nrel <= 1e-2, (cos, nrel)           # 2 ranks x 2 pairs == 1 rank x 4 pairs
+        print(f"rank {rank}: all-reduced gradient / world vs single-process gradient on the union: cosine {cos:.6f}, norm rel err {nrel:.2e}")
     import re
     root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     for rank in range(2):

@@ -207,7 +207,7 @@ def test_evaluate_covers_the_tail_batch():
 
 def test_checkpoint_refuses_another_parameter_layout(tmp_path, monkeypatch):
     """optimizer.pt carries a layout descriptor: a blob written with interleaved gate|up rows (RV_FUSE_SWIGLU=1) must not load
-    into a block-layout store (same length, different row order), nor may an untagged legacy blob load into an interleaved one."""
+    into a block-layout store (same length, different row order), and an untagged legacy blob is of UNKNOWN layout: refused unless RV_CKPT_LEGACY_LAYOUT states it."""
     _need_gpu()
     cfg = O.tiny_cfg()
     model, _ = _model(cfg, seed=13)
@@ -226,5 +226,10 @@ def test_checkpoint_refuses_another_parameter_layout(tmp_path, monkeypatch):
     del blob["layout"]                                                          # a blob from before the descriptor existed
     os.makedirs(tmp_path / "old", exist_ok=True)
     torch.save(blob, str(tmp_path / "old" / "optimizer.pt"))
+    with pytest.raises(ValueError, match="no layout descriptor"):              # unknown layout: never guessed
+        tr.load_checkpoint(str(tmp_path / "old"))
+    monkeypatch.setenv("RV_CKPT_LEGACY_LAYOUT", "block")                        # the caller states it; it must still match
     with pytest.raises(ValueError, match="interleave_gu"):
         tr.load_checkpoint(str(tmp_path / "old"))
+    monkeypatch.setenv("RV_CKPT_LEGACY_LAYOUT", "interleaved")
+    tr.load_checkpoint(str(tmp_path / "old"))
