@@ -1328,6 +1328,262 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
   }  // pass
 }
 
+
+// =============================================================================================
+// backward, dK/dV, version 4 (round 4).  Version 3's decomposition, LDS image, operand layouts and arithmetic; what changes is
+// the ORDER of work inside a tile and the depth of the LDS ring.  PMC on version 3 (profiles/r03_pmc_attn_packed_vs_plain_final.txt):
+// matrix pipe busy 0.31, 0.37 of the wave's cycles in issue stalls, 0.22 parked - with ONE wave per SIMD every dependency of the
+// chain S^T -> exp -> dP^T -> dS -> dV / dK of a 32-query sub-tile is exposed, and the two sub-tiles of a tile run one after the
+// other.  Here both sub-tiles are in flight together and a tile is four phases of 16 MFMAs; the VALU / LDS work between two
+// MFMAs always belongs to a DIFFERENT stage than the MFMAs around it (schedule and counted waits: tools/gen_attn_dkv4.py ->
+// attn_dkv4_body.inc).  Further:
+//   * the Q row fragments of both sub-tiles are read from LDS straight into AGPRs a[192:255] (the S^T MFMAs take both operands
+//     from the accumulator file), S^T is ONE 8-deep chain per sub-tile - the two chains alternate, so no MFMA waits for its
+//     predecessor and the split partial sums of version 3 (16 extra VALU adds per sub-tile) are gone;
+//   * Q / dO tiles sit in a THREE-stage LDS ring (99.8 KB): tile t + 2 is fetched during the last phase of tile t and awaited
+//     at the end of tile t + 1 with a counted vmcnt, so the shorter tile no longer exposes the LDS-DMA latency;
+//   * -log2(e) x lse is applied once per lse value under the S^T MFMAs (as many multiplications as before, elsewhere).
+// =============================================================================================
+#define BF(x) __builtin_bit_cast(bf16x8_t, x)
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
+                                                               int k_col0, int v_col0,
+                                                               const bf16_t* __restrict__ dO, long lddo,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
+                                                               int nx, float scale, const int* __restrict__ seg_sh,
+                                                               const int* __restrict__ seg_e1, int kv_group,
+        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
+  constexpr int HD = 128, KS = 8, ET = 4;
+  constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64] = 0x8200
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, half = lane >> 5;
+  int bx, h, s;
+  attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
+  const long tok0 = (long)s * L;
+  const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
+  const int nkb = (L + 127) / 128;
+  const float c = scale * LOG2E;
+  const int HQ = H * kv_group;
+
+  int d_row[4], d_chunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d_row[i] = (wave * 4 + i) * 4 + (lane >> 4);
+    d_chunk[i] = (lane & 15) ^ (((d_row[i] & 3) << 2) | ((d_row[i] >> 2) & 3));
+  }
+  const uint32_t ldqb = (uint32_t)(ld * 2), lddob = (uint32_t)(lddo * 2);
+  // One LDS-DMA piece of tile t into ring buffer buf: j = 0..7 -> Q piece j>>1 (even j) / dO piece j>>1 (odd j); j = 8: the tile's
+  // lse (wave 0) or delta (wave 1).  Waves 0 and 1 therefore issue NP = 9 vector-memory operations per tile, waves 2 and 3 eight.
+  auto issue_piece = [&](int hq, int t, int buf, int j) {
+    uint8_t* st = smem + buf * STAGE;
+    int qs0 = t * 64;
+    asm volatile("" : "+s"(qs0));          // address arithmetic computed HERE, not hoisted to the top of the tile (spills)
+    if (j < 8) {
+      const int i = j >> 1;
+      const uint32_t r = (uint32_t)min(qs0 + d_row[i], L - 1);
+      if ((j & 1) == 0) {
+        const char* base = (const char*)(qkv + tok0 * ld + q_col0 + hq * HD);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (r * ldqb + d_chunk[i] * 16u)),
+                                         (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
+      } else {
+        const char* base = (const char*)(dO + tok0 * lddo + hq * HD);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (r * lddob + d_chunk[i] * 16u)),
+                                         (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+      }
+    } else if (wave < 2) {
+      const int qq = min(qs0 + lane, L - 1);
+      const float* src = (wave == 0 ? lse : delta) + ((long)s * HQ + hq) * L + qq;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 32768 + wave * 256), 4, 0, 0);
+    }
+  };
+  auto issue_tile = [&](int hq, int t, int buf) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) issue_piece(hq, t, buf, j);
+  };
+  // everything of this wave but the NEWEST tile's pieces has landed
+  auto wait_all_but_newest = [&]() {
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+
+  const uint32_t lds0 = lds_addr_of(smem);
+  uint32_t rb[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) rb[ks] = lds0 + qtile_off(fr, 2 * ks + half);
+  uint32_t lh = lds0 + 32768u + (uint32_t)(half * 16);
+  const int g4 = lane >> 4, s16 = lane & 15;
+  uint32_t tb[2][ET];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+      tb[u][et] = lds0 + qtile_off(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
+                  (uint32_t)((s16 & 1) * 8);
+
+  int blk_first, blk_second;
+  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
+  const int npass = CAUSAL ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int kvb = (pass == 0) ? blk_first : blk_second;
+    if (kvb < 0) break;
+    const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
+    const int key = kv0w + fr, keyc = min(key, L - 1);
+    KeyLaneMask<CAUSAL> kmask;
+    kmask.init(key, L, sh, e1);
+    {
+      const bf16_t* kp = qkv + (tok0 + keyc) * ld + h * HD + 8 * half;
+      static_for<KS>([&](auto ic) {
+        constexpr int ks = decltype(ic)::value;
+        frag_load<ks>(kp + k_col0 + 16 * ks);
+        frag_load<8 + ks>(kp + v_col0 + 16 * ks);
+      });
+      static_for<8>([&](auto ic) { acc_zero<decltype(ic)::value>(); });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    const int t_begin = CAUSAL ? (kv0 / 64) : 0;
+    const int nt = (kv0 >= sh && kv0 + 127 < e1) ? min((L + 63) / 64, (e1 + 63) / 64) : (L + 63) / 64;
+
+    // One 64-query tile out of ring buffer `buf` (the per-lane read bases already point into it; they advance at the end).
+    auto tile = [&](const int hq, const int t, const int buf) {
+      const int qs0 = t * 64;
+      const int tn = min(t + 2, nt - 1);                 // fetched meanwhile (clamped: the DMA issues stay unconditional)
+      const int bufn = buf == 0 ? 2 : buf - 1;           // (buf + 2) % 3
+      if ((CAUSAL && qs0 + 63 < kv0w) || (qs0 >= e1 && kv0w >= sh && kv0w + 31 < e1)) {
+        issue_tile(hq, tn, bufn);                        // nothing of this tile is visible to this wave's 32 keys
+      } else {
+        const bool need_mask_a = (qs0 + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qs0) ||
+                                 (qs0 + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
+        const bool need_mask_b = (qs0 + 63 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qs0 + 32) ||
+                                 (qs0 + 63 >= e1 && kv0w + 31 >= sh && kv0w < e1);
+        f32x16_t sA, sB, pA, pB;
+        bf16x8_t foA[KS], foB[KS], tr[2][ET];
+        f32x4_t lsA[4], lsB[4], deA[4], deB[4];
+        u32x4_t pfA0, pfA1, pfB0, pfB1, dsA0, dsA1, dsB0, dsB1;
+        // Each helper PINS what it produced with an empty volatile asm: pure VALU values have no ordering against the volatile asm
+        // MFMAs / reads around them, and without the pin hipcc sinks whole stages to their first use (seen in the ISA: all 16
+        // exponentials of sub-tile A in one lump behind the mask branch of sub-tile B instead of two per MFMA gap).
+        auto prescale = [&](f32x4_t (&ls)[4], int j0, int j1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j >= j0 && j < j1) { ls[j] = ls[j] * (-LOG2E); asm volatile("" : "+v"(ls[j])); }
+        };
+        auto exps = [&](f32x16_t& sx, const f32x4_t (&ls)[4], int r0, int r1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (r >= r0 && r < r1) {
+              float p = __builtin_amdgcn_exp2f(fmaf(sx[r], c, ls[r >> 2][r & 3]));     // masked: exp2(-inf) = 0
+              asm volatile("" : "+v"(p));
+              sx[r] = p;
+            }
+        };
+        auto dsmul = [&](f32x16_t& px, const f32x16_t& sx, const f32x4_t (&de)[4], int r0, int r1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (r >= r0 && r < r1) {
+              float d = sx[r] * (px[r] - de[r >> 2][r & 3]);
+              asm volatile("" : "+v"(d));
+              px[r] = d;
+            }
+        };
+        auto pack2 = [&](u32x4_t& pf, const f32x16_t& a, int base, int d0) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            if (d >= d0 && d < d0 + 2) {
+              uint32_t w = pack2bf(a[base + 2 * d], a[base + 2 * d + 1]);
+              asm volatile("" : "+v"(w));
+              pf[d] = w;
+            }
+        };
+        auto pack4 = [&](u32x4_t& pf, const f32x16_t& a, int base) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            uint32_t w = pack2bf(a[base + 2 * d], a[base + 2 * d + 1]);
+            asm volatile("" : "+v"(w));
+            pf[d] = w;
+          }
+        };
+#include "attn_dkv4_body.inc"
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this tile is complete: its buffer is the next DMA target
+      wait_all_but_newest();                             // tile t + 1 has landed (this wave's pieces) ...
+      __syncthreads();                                   // ... and everybody's
+      const uint32_t flip = buf == 2 ? (uint32_t)(-2 * STAGE) : (uint32_t)STAGE;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) rb[ks] += flip;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int et = 0; et < ET; ++et) tb[u][et] += flip;
+      lh += flip;
+    };
+
+    for (int gq = 0; gq < kv_group; ++gq) {
+      const int hq = h * kv_group + gq;
+      issue_tile(hq, t_begin, 0);
+      issue_tile(hq, min(t_begin + 1, nt - 1), 1);
+      wait_all_but_newest();
+      __syncthreads();
+      int buf = 0;
+      for (int t = t_begin; t < nt; ++t) {
+        tile(hq, t, buf);
+        buf = buf == 2 ? 0 : buf + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped re-fetches of the last tiles: nothing may land later
+      __syncthreads();
+      const uint32_t back = (uint32_t)(buf * STAGE);       // the bases point into ring buffer `buf`: back to buffer 0
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) rb[ks] -= back;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int et = 0; et < ET; ++et) tb[u][et] -= back;
+      lh -= back;
+    }  // query heads of the group
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
+
+    bf16_t* kp_out = dqkv + (tok0 + keyc) * lddq + h * HD;
+    if (rope_cos) {       // dK leaves through the inverse rotation (pairs = tiles e, e + 2)
+      const long pos = rope_pos ? rope_pos[tok0 + keyc] : keyc;
+      static_for<2>([&](auto ic) {
+        constexpr int e = decltype(ic)::value;
+        f32x16_t lo, hi;
+        acc_read<e>(lo);
+        acc_read<e + 2>(hi);
+        if (key < L) store_rope_bwd_pair(lo, hi, scale, rope_cos + pos * 64, rope_sin + pos * 64, e, half, kp_out + k_col0);
+      });
+    }
+    static_for<ET>([&](auto ic) {
+      constexpr int e = decltype(ic)::value;
+      f32x16_t dk_e, dv_e;
+      if (!rope_cos) acc_read<e>(dk_e);
+      acc_read<4 + e>(dv_e);
+      if (key < L) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          uint2 w;
+          if (!rope_cos) {
+            w.x = pack2bf(dk_e[rg * 4 + 0] * scale, dk_e[rg * 4 + 1] * scale);
+            w.y = pack2bf(dk_e[rg * 4 + 2] * scale, dk_e[rg * 4 + 3] * scale);
+            *(uint2*)(kp_out + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
+          }
+          w.x = pack2bf(dv_e[rg * 4 + 0], dv_e[rg * 4 + 1]);
+          w.y = pack2bf(dv_e[rg * 4 + 2], dv_e[rg * 4 + 3]);
+          *(uint2*)(kp_out + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
+        }
+      }
+    });
+  }  // pass
+}
+#undef BF
+
 }  // namespace
 
 extern "C" {
@@ -1402,6 +1658,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   hipStream_t st = (hipStream_t)stream;
   constexpr int DQ_LDS = 4 * 64 * 256;
   constexpr int DKV_LDS = 2 * (2 * 64 * 256 + 512);
+  constexpr int DKV4_LDS = 3 * (2 * 64 * 256 + 512);     // version 4: three-stage ring
   static bool attr_done = false;
   static int dkv_version = 3;
   static int dkv_ablate = 0;
@@ -1421,8 +1678,10 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
     hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     { const char* a = getenv("RV_DKV_ABLATE"); if (a) dkv_ablate = atoi(a); }
 #endif
-    const char* e = getenv("RV_ATTN_DKV");        // A/B knob: 2 = the compiler-scheduled version-2 kernel
-    if (e && atoi(e) == 2) dkv_version = 2;
+    hipFuncSetAttribute((const void*)attn_bwd_dkv4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV4_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV4_LDS);
+    const char* e = getenv("RV_ATTN_DKV");        // A/B knob: 2 = the compiler-scheduled version-2 kernel, 3 = version 3, 4 = version 4
+    if (e && atoi(e) >= 2 && atoi(e) <= 4) dkv_version = atoi(e);
     attr_done = true;
   }
   // dQ: one workgroup per (query head, query block); dK/dV: per (KEY/VALUE head, key block), looping over its query heads
@@ -1435,6 +1694,8 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
     RV_CHECK_LAUNCH();
     if (dkv_version == 2)
       hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+    else if (dkv_version == 4)
+      hipLaunchKernelGGL((attn_bwd_dkv4_kernel<true>), grid_kv, block, DKV4_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
 #ifdef RV_ATTN_EXPERIMENTS
 #define RV_ABL_LAUNCH(N) else if (dkv_ablate == N) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, N>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
     RV_ABL_LAUNCH(1) RV_ABL_LAUNCH(2) RV_ABL_LAUNCH(3) RV_ABL_LAUNCH(5) RV_ABL_LAUNCH(6)
@@ -1447,6 +1708,8 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
     RV_CHECK_LAUNCH();
     if (dkv_version == 2)
       hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+    else if (dkv_version == 4)
+      hipLaunchKernelGGL((attn_bwd_dkv4_kernel<false>), grid_kv, block, DKV4_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
     else
       hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
   }
