@@ -1345,6 +1345,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
 //   * -log2(e) x lse is applied once per lse value under the S^T MFMAs (as many multiplications as before, elsewhere).
 // =============================================================================================
 #define BF(x) __builtin_bit_cast(bf16x8_t, x)
+// RV_DKV4_PROF (experiment builds): s_memtime stamps at the phase boundaries of a tile, accumulated per wave 0 of every workgroup
+// into rv_dkv4_prof[] (ticks): 0 skipped-tile / loop glue, 1 P1, 2 P2, 3 P3, 4 P4, 5 end-of-tile waits, 6 barrier, 7 prologue +
+// epilogue of a pass, 14 whole kernel per workgroup, 15 workgroups.  Each stamp drains lgkmcnt (s_memtime is an SMEM read).
+#ifdef RV_DKV4_PROF
+__device__ unsigned long long rv_dkv4_prof[16];
+#define PROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += (unsigned)(t_ - pr_last); pr_last = t_; }
+#else
+#define PROF(i)
+#endif
+#define RV_CAT2(a, b) a##b
+#define RV_CAT(a, b) RV_CAT2(a, b)
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                                int k_col0, int v_col0,
@@ -1429,6 +1440,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __r
 
   int blk_first, blk_second;
   pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
+#ifdef RV_DKV4_PROF
+  unsigned pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long pr_last = pr_t0;
+#endif
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const int kvb = (pass == 0) ? blk_first : blk_second;
@@ -1463,10 +1479,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __r
                                  (qs0 + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
         const bool need_mask_b = (qs0 + 63 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qs0 + 32) ||
                                  (qs0 + 63 >= e1 && kv0w + 31 >= sh && kv0w < e1);
+#ifdef RV_DKV4_ABL          // ablation bodies leave some of these unwritten: defined values, opaque to the optimiser
+        f32x16_t sA = {}, sB = {}, pA = {}, pB = {};
+        bf16x8_t foA[KS] = {}, foB[KS] = {}, tr[2][ET] = {};
+        f32x4_t lsA[4] = {}, lsB[4] = {}, deA[4] = {}, deB[4] = {};
+        u32x4_t pfA0 = {}, pfA1 = {}, pfB0 = {}, pfB1 = {}, dsA0 = {}, dsA1 = {}, dsB0 = {}, dsB1 = {};
+        asm volatile("" : "+v"(sA), "+v"(sB), "+v"(pA), "+v"(pB));
+        asm volatile("" : "+v"(pfA0), "+v"(pfA1), "+v"(pfB0), "+v"(pfB1), "+v"(dsA0), "+v"(dsA1), "+v"(dsB0), "+v"(dsB1));
+#pragma unroll
+        for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(foA[i]), "+v"(foB[i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(lsA[i]), "+v"(lsB[i]), "+v"(deA[i]), "+v"(deB[i]), "+v"(tr[0][i]), "+v"(tr[1][i]));
+#else
         f32x16_t sA, sB, pA, pB;
         bf16x8_t foA[KS], foB[KS], tr[2][ET];
         f32x4_t lsA[4], lsB[4], deA[4], deB[4];
         u32x4_t pfA0, pfA1, pfB0, pfB1, dsA0, dsA1, dsB0, dsB1;
+#endif
         // Each helper PINS what it produced with an empty volatile asm: pure VALU values have no ordering against the volatile asm
         // MFMAs / reads around them, and without the pin hipcc sinks whole stages to their first use (seen in the ISA: all 16
         // exponentials of sub-tile A in one lump behind the mask branch of sub-tile B instead of two per MFMA gap).
@@ -1510,11 +1539,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __r
             pf[d] = w;
           }
         };
+#ifndef RV_DKV4_ABL
 #include "attn_dkv4_body.inc"
+#else                       // experiment builds: ablation bodies (tools/gen_attn_dkv4.py --ablations), results wrong by construction
+#define RV_STR2(x) #x
+#define RV_STR(x) RV_STR2(x)
+#include RV_STR(RV_CAT(attn_dkv4_body_abl, RV_DKV4_ABL).inc)
+#endif
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this tile is complete: its buffer is the next DMA target
       wait_all_but_newest();                             // tile t + 1 has landed (this wave's pieces) ...
+      PROF(5);
       __syncthreads();                                   // ... and everybody's
+      PROF(6);
       const uint32_t flip = buf == 2 ? (uint32_t)(-2 * STAGE) : (uint32_t)STAGE;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) rb[ks] += flip;
@@ -1531,6 +1568,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __r
       issue_tile(hq, min(t_begin + 1, nt - 1), 1);
       wait_all_but_newest();
       __syncthreads();
+      PROF(7);
       int buf = 0;
       for (int t = t_begin; t < nt; ++t) {
         tile(hq, t, buf);
@@ -1580,13 +1618,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __r
         }
       }
     });
+    PROF(7);
   }  // pass
+#ifdef RV_DKV4_PROF
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&rv_dkv4_prof[i], (unsigned long long)pr[i]);
+    atomicAdd(&rv_dkv4_prof[14], __builtin_amdgcn_s_memtime() - pr_t0);
+    atomicAdd(&rv_dkv4_prof[15], 1ull);
+  }
+#endif
 }
 #undef BF
 
 }  // namespace
 
 extern "C" {
+
+#ifdef RV_DKV4_PROF
+// experiment builds only: read and clear the phase counters of attn_bwd_dkv4_kernel (16 x u64)
+int rv_debug_dkv4_prof(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rv_dkv4_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(rv_dkv4_prof), z, sizeof(z)) != hipSuccess;
+}
+#endif
 
 int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
                 int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group, void* stream) {

@@ -1,0 +1,55 @@
+"""Phase profile of attn_bwd_dkv4_kernel from its s_memtime stamps (experiment builds -DRV_DKV4_PROF, tools/build_dkv4_ablations.py
+--prof): ticks per tile and phase at the bench shape.  Usage: RV_ATTN_DKV=4 RV_HIP_LIB=.../librlaifv_hip_prof<n>.so python tools/exp_dkv4_prof.py"""
+import ctypes
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rlaif_v_amd import ops, hip  # noqa: E402
+
+BF = torch.bfloat16
+dev = torch.device("cuda:0")
+B, H, hd, shared, tail = 8, 32, 128, 638, 1410
+L, d = shared + 2 * tail, H * hd
+qkv = (torch.randn(B * L, 3 * d, device=dev) * 0.5).to(BF)
+do = (torch.randn(B * L, d, device=dev) * 0.5).to(BF)
+seg = (torch.full((B,), shared, dtype=torch.int32, device=dev), torch.full((B,), shared + tail, dtype=torch.int32, device=dev))
+o, lse = ops.attn_fwd(qkv, B, L, H, hd, True, 0, d, 2 * d, seg=seg)
+dqkv = torch.empty_like(qkv)
+lib = hip.lib().lib
+lib.rv_debug_dkv4_prof.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+buf = (ctypes.c_ulonglong * 16)()
+for _ in range(3):
+    ops.attn_bwd(qkv, o, do, lse, B, L, H, hd, True, 0, d, 2 * d, dqkv=dqkv, seg=seg)
+torch.cuda.synchronize()
+lib.rv_debug_dkv4_prof(buf)
+iters = 10
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(iters):
+    ops.attn_bwd(qkv, o, do, lse, B, L, H, hd, True, 0, d, 2 * d, dqkv=dqkv, seg=seg)
+e.record()
+torch.cuda.synchronize()
+ms = s.elapsed_time(e) / iters
+lib.rv_debug_dkv4_prof(buf)
+v = [int(x) for x in buf]
+# tiles a workgroup processes: sum over key blocks of (nt - t_begin)
+nkb = (L + 127) // 128
+e1 = shared + tail
+tiles = 0
+for kb in range(nkb):
+    kv0 = kb * 128
+    nt = min((L + 63) // 64, (e1 + 63) // 64) if (kv0 >= shared and kv0 + 127 < e1) else (L + 63) // 64
+    tiles += nt - kv0 // 64
+tiles_total = tiles * B * H
+wgs = v[15] / iters
+names = ["glue", "P1 S^T", "P2 dP^T+exp", "P3 dV_A dK_A", "P4 dV_B dK_B+DMA", "tile-end waits", "barrier", "pass prologue/epilogue"]
+tot = sum(v[:8])
+print(f"lib {os.environ.get('RV_HIP_LIB', 'default')}: dq + dkv {ms:.3f} ms; {wgs:.0f} workgroups, {tiles_total} tiles per launch, "
+      f"{v[14] / v[15]:.0f} ticks per workgroup, stamped {tot / v[15]:.0f}")
+for n, x in zip(names, v[:8]):
+    print(f"  {n:26s} {100.0 * x / tot:5.1f} %   {x / iters / tiles_total:8.2f} ticks per tile")
+print(f"  total per tile {tot / iters / tiles_total:.2f} ticks (wave 0 of every workgroup)")

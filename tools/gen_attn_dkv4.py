@@ -21,11 +21,20 @@ in flight behind a read one waits for - asserted here).  Usage: python tools/gen
 """
 import os
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rlaif-v_amd", "csrc", "attn_dkv4_body.inc")
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rlaif-v_amd", "csrc")
+OUT = os.path.join(CSRC, "attn_dkv4_body.inc")
+# Ablation bodies (experiment builds -DRV_DKV4_ABL=n, results WRONG by construction; timing deltas price the stages):
+#   1 no transposing reads, 2 no row / lse / delta reads, 3 no VALU, 4 no MFMAs, 5 no LDS reads at all, 6 MFMAs only (+ DMA),
+#   7 no LDS-DMA of the following tiles, 8 nothing but DMA + barrier
+ABL = {0: set(), 1: {"tr"}, 2: {"row"}, 3: {"valu"}, 4: {"mfma"}, 5: {"tr", "row"}, 6: {"tr", "row", "valu"}, 7: {"dma"},
+       8: {"tr", "row", "valu", "mfma"}}
 
 
 class Sched:
-    def __init__(self):
+    def __init__(self, skip=()):
+        self.skip = set(skip)
         self.lines = []
         self.issued = 0            # LDS reads issued so far
         self.last = {}             # read name -> index (1-based) of its last read
@@ -35,7 +44,10 @@ class Sched:
     def emit(self, s):
         self.lines.append("          " + s)
 
-    def read(self, name, stmt, n=1):
+    def read(self, name, stmt, n=1, kind="row"):
+        if kind in self.skip:
+            self.last[name] = self.issued        # never issued: any wait for it is already satisfied
+            return
         self.emit(stmt)
         self.issued += n
         self.last[name] = self.issued
@@ -52,9 +64,12 @@ class Sched:
         self.done = idx
 
     def mfma(self, stmt):
-        self.emit(stmt)
+        if "mfma" not in self.skip:
+            self.emit(stmt)
 
-    def valu(self, stmt):
+    def valu(self, stmt, kind="valu"):
+        if kind in self.skip:
+            return
         self.emit(stmt)
         self.emit("__builtin_amdgcn_sched_barrier(0);")
 
@@ -62,8 +77,8 @@ class Sched:
         self.emit("__builtin_amdgcn_sched_barrier(0);")
 
 
-def main():
-    s = Sched()
+def generate(abl=0):
+    s = Sched(ABL[abl])
     X = "AB"
 
     def rq(x, ks):      # Q row fragment ks of sub-tile x -> AGPR slot x*8 + ks
@@ -85,9 +100,10 @@ def main():
         x, isdo, h = groups[g]
         off = x * 32 * 256 + isdo * 16384 + h * 16 * 256
         s.read(f"T{g}_{e}", f"tr[{g & 1}][{e}] = __builtin_shufflevector(ds_tr16_b64_asm(tb[0][{e}], {off}), "
-                            f"ds_tr16_b64_asm(tb[1][{e}], {off}), 0, 1, 2, 3, 4, 5, 6, 7);", n=2)
+                            f"ds_tr16_b64_asm(tb[1][{e}], {off}), 0, 1, 2, 3, 4, 5, 6, 7);", n=2, kind="tr")
 
     s.emit("// ---- GENERATED by tools/gen_attn_dkv4.py: do not edit; the waits are counted against THIS issue order ----")
+    s.emit("PROF(0);")
     # prologue: first half of the Q row fragments of both sub-tiles, lse of both
     for ks in range(4):
         rq(0, ks)
@@ -113,6 +129,7 @@ def main():
         if j in (6, 7):
             s.need("LB3")
             s.valu(f"prescale(lsB, {2 * (j - 6)}, {2 * (j - 6) + 2});")
+    s.emit("PROF(1);")
     # ---- P2: dP^T_A / dP^T_B with the exponentials
     s.emit("// ---- P2: dP^T of both sub-tiles, interleaved; exponentials of S^T underneath")
     # (the last S^T_A MFMA is P1 slot 14: VALU may read sA from three MFMAs later on = after P2 slot 1)
@@ -140,6 +157,7 @@ def main():
         if 10 <= j <= 13:
             q = j - 10         # two of the eight cvt_pk of P_A per slot: fragment q >> 1, dwords 2 (q & 1), 2 (q & 1) + 1
             s.valu(f"pack2(pfA{q >> 1}, sA, {(q >> 1) * 8}, {(q & 1) * 2});")
+    s.emit("PROF(2);")
     # ---- P3 / P4: dV, dK
     s.emit("// ---- P3: dV_A, dK_A; dS of both sub-tiles underneath.  P4: dV_B, dK_B; the LDS-DMA of tile t + 2 underneath")
     dsA = {2: (0, 3), 3: (3, 6), 4: (6, 9), 5: (9, 12), 6: (12, 15), 7: (15, 16)}
@@ -181,11 +199,20 @@ def main():
         if j == 16:
             s.valu("pack4(dsB1, pB, 8);")
         if 19 <= j <= 27:
-            s.valu(f"issue_piece(hq, tn, bufn, {j - 19});")
+            s.valu(f"issue_piece(hq, tn, bufn, {j - 19});", kind="dma")
+        if j == 15:
+            s.emit("PROF(3);")
+        if j == 31:
+            s.emit("PROF(4);")
     s.emit(f"// ---- end of the generated tile body: {s.issued} LDS reads, deepest counted wait lgkmcnt({s.max_wait}) ----")
-    open(OUT, "w").write("\n".join(s.lines) + "\n")
-    print(OUT, s.issued, "reads, max wait", s.max_wait)
+    out = OUT if abl == 0 else OUT.replace(".inc", f"_abl{abl}.inc")
+    open(out, "w").write("\n".join(s.lines) + "\n")
+    print(out, s.issued, "reads, max wait", s.max_wait)
 
 
 if __name__ == "__main__":
-    main()
+    generate(0)
+    if "--ablations" in sys.argv:
+        for a in sorted(ABL):
+            if a:
+                generate(a)
