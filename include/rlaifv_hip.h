@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 4
+#define RV_ABI_VERSION 5
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
@@ -147,8 +147,9 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
                 void* stream);
 /* kv_group (both calls): grouped-query attention as in HF Mistral / Llama-3 (`repeat_kv`): H query heads share
  * H / kv_group key/value heads, query head h reads kv head h / kv_group (K at k_col0 + (h / kv_group) * hd); 1 = MHA.
- * backward (hd = 128): O = the forward output (rv_attn_fwd's `out`), delta = [S, H, L] fp32 WORKSPACE: the dQ kernel fills
- * it with rowsum(dO * O) (what rv_attn_delta computes) on the fly and the dK/dV kernel reads it.  Writes dQ, dK, dV into
+ * backward (hd = 128): O = the forward output (rv_attn_fwd's `out`), delta = [3][S, H, L] fp32 WORKSPACE (ABI 5; it was [S, H, L]): the dQ
+ * kernel fills it with rowsum(dO * O) (what rv_attn_delta computes), its negative and -lse / scale on the fly and the dK/dV kernel
+ * reads them.  Writes dQ, dK, dV into
  * dqkv at the column offsets of qkv.  Deterministic (no atomics): one kernel per 128-query block for dQ, one per 128-key
  * block for dK/dV.  Packed rows: key tiles / query tiles that a whole block cannot see are never fetched.
  * rope_cos / rope_sin (fp32 [positions][64], both NULL = off) + rope_pos (int32 [S * L] position of every row, NULL = row

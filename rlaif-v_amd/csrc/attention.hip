@@ -634,7 +634,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
         for (int j = 0; j < 8; ++j) delta_q = fmaf(bf2f((bf16_t)dof[ks][j]), bf2f((bf16_t)of[j]), delta_q);
       }
       delta_q = xhalf_sum(delta_q);
-      if (q < L && half == 0) delta[((long)s * H + h) * L + q] = delta_q;
+      if (q < L && half == 0) {
+        // workspace planes [3][S, H, L]: delta (versions 2-4 of the dK/dV kernel), -delta and -lse / scale (version 5 reads them
+        // straight into its MFMA accumulator inputs)
+        const long idx = ((long)s * H + h) * L + q, plane = (long)((int)gridDim.x / ((nx & 0xffff) * H)) * H * L;
+        delta[idx] = delta_q;
+        delta[plane + idx] = -delta_q;
+        delta[2 * plane + idx] = -lse[idx] / scale;
+      }
     }
     f32x16_t dq[ET];
 #pragma unroll
@@ -1630,17 +1637,317 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __r
 #endif
 }
 #undef BF
+#undef PROF
+
+// =============================================================================================
+// backward, dK/dV, version 5 (round 4): version 4's layouts and arithmetic under the schedule its phase stamps asked for
+// (tools/gen_attn_dkv5.py has the analysis and generates the three straight-line bodies included below): sub-tile A runs one
+// phase ahead of sub-tile B so every phase has VALU work of its own, the row terms enter through the MFMA accumulator inputs
+// (S^T starts from -lse / scale, dP^T from -delta), ONE barrier per tile in front of the last phase with the next tile's first
+// operands read behind it, a FOUR-stage LDS ring (133 KB) fetched two tiles ahead, transposed fragments two groups ahead.
+// =============================================================================================
+#define BF(x) __builtin_bit_cast(bf16x8_t, x)
+// RV_DKV5_PROF (experiment builds; same slots as RV_DKV4_PROF): s_memtime stamps at the phase boundaries of a tile, accumulated per wave 0 of every workgroup
+// into rv_dkv5_prof[] (ticks): 0 skipped-tile / loop glue, 1 P1, 2 P2, 3 P3, 4 P4, 5 end-of-tile waits, 6 barrier, 7 prologue +
+// epilogue of a pass, 14 whole kernel per workgroup, 15 workgroups.  Each stamp drains lgkmcnt (s_memtime is an SMEM read).
+#ifdef RV_DKV5_PROF
+__device__ unsigned long long rv_dkv5_prof[16];
+#define PROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += (unsigned)(t_ - pr_last); pr_last = t_; }
+#else
+#define PROF(i)
+#endif
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
+                                                               int k_col0, int v_col0,
+                                                               const bf16_t* __restrict__ dO, long lddo,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
+                                                               int nx, float scale, const int* __restrict__ seg_sh,
+                                                               const int* __restrict__ seg_e1, int kv_group,
+        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
+  constexpr int HD = 128, KS = 8, ET = 4;
+  constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64] = 0x8200
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, half = lane >> 5;
+  int bx, h, s;
+  attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
+  const long tok0 = (long)s * L;
+  const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
+  const int nkb = (L + 127) / 128;
+  const float c = scale * LOG2E;
+  const int HQ = H * kv_group;
+  const long ws_plane = (long)((int)gridDim.x / ((nx & 0xffff) * H)) * HQ * L;       // one [S, HQ, L] plane of the delta workspace
+
+  int d_row[4], d_chunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d_row[i] = (wave * 4 + i) * 4 + (lane >> 4);
+    d_chunk[i] = (lane & 15) ^ (((d_row[i] & 3) << 2) | ((d_row[i] >> 2) & 3));
+  }
+  const uint32_t ldqb = (uint32_t)(ld * 2), lddob = (uint32_t)(lddo * 2);
+  // One LDS-DMA piece of tile t into ring buffer buf: j = 0..7 -> Q piece j>>1 (even j) / dO piece j>>1 (odd j); j = 8: the tile's
+  // lse (wave 0) or delta (wave 1).  Waves 0 and 1 therefore issue NP = 9 vector-memory operations per tile, waves 2 and 3 eight.
+  auto issue_piece = [&](int hq, int t, int buf, int j) {
+    uint8_t* st = smem + buf * STAGE;
+    int qs0 = t * 64;
+    asm volatile("" : "+s"(qs0));          // address arithmetic computed HERE, not hoisted to the top of the tile (spills)
+    if (j < 8) {
+      const int i = j >> 1;
+      const uint32_t r = (uint32_t)min(qs0 + d_row[i], L - 1);
+      if ((j & 1) == 0) {
+        const char* base = (const char*)(qkv + tok0 * ld + q_col0 + hq * HD);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (__umul24(r, ldqb) + d_chunk[i] * 16u)),
+                                         (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
+      } else {
+        const char* base = (const char*)(dO + tok0 * lddo + hq * HD);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (__umul24(r, lddob) + d_chunk[i] * 16u)),
+                                         (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+      }
+    } else if (wave < 2) {         // plane 2 of the workspace = -lse / scale (wave 0), plane 1 = -delta (wave 1): written by the dQ kernel
+      const int qq = min(qs0 + lane, L - 1);
+      const float* src = delta + (wave == 0 ? 2 : 1) * ws_plane + ((long)s * HQ + hq) * L + qq;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 32768 + wave * 256), 4, 0, 0);
+    }
+  };
+  auto issue_tile = [&](int hq, int t, int buf) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) issue_piece(hq, t, buf, j);
+  };
+  // everything of this wave but the NEWEST tile's pieces has landed
+  auto wait_all_but_newest = [&]() {
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+
+  const uint32_t lds0 = lds_addr_of(smem);
+  uint32_t rb[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) rb[ks] = lds0 + qtile_off(fr, 2 * ks + half);
+  uint32_t lh = lds0 + 32768u + (uint32_t)(half * 16);
+  const int g4 = lane >> 4, s16 = lane & 15;
+  uint32_t tb[2][ET];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+      tb[u][et] = lds0 + qtile_off(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
+                  (uint32_t)((s16 & 1) * 8);
+
+  int blk_first, blk_second;
+  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
+#ifdef RV_DKV5_PROF
+  unsigned pr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long pr_last = pr_t0;
+#endif
+  // Per-pass state (a causal workgroup owns TWO key blocks: blk_first, then blk_second).  The set-up of a pass - first two tiles
+  // of its LDS ring, K / V fragments of its 32 keys per wave - is issued BEFORE the epilogue of the previous pass (accumulator
+  // read-out, inverse rotation, stores), so the two memory latencies and the ~600 epilogue instructions overlap; version 3 / 4
+  // spend 18 % of the kernel in these prologues and epilogues (phase stamps, profiles/r04_attn_dkv4_phase_profile.log).
+  int kvb = blk_first, kv0 = 0, kv0w = 0, key = 0, keyc = 0, t_begin = 0, nt = 0;
+  KeyLaneMask<CAUSAL> kmask;
+  auto pass_begin = [&](int blk) {        // geometry of the pass + its K / V fragments -> AGPRs + the first two tiles of query head 0
+    kvb = blk;
+    kv0 = kvb * 128;
+    kv0w = kv0 + wave * 32;
+    key = kv0w + fr;
+    keyc = min(key, L - 1);
+    kmask.init(key, L, sh, e1);
+    t_begin = CAUSAL ? (kv0 / 64) : 0;
+    nt = (kv0 >= sh && kv0 + 127 < e1) ? min((L + 63) / 64, (e1 + 63) / 64) : (L + 63) / 64;
+    issue_tile(h * kv_group, t_begin, 0);
+    issue_tile(h * kv_group, min(t_begin + 1, nt - 1), 1);
+    const bf16_t* kp = qkv + (tok0 + keyc) * ld + h * HD + 8 * half;
+    static_for<KS>([&](auto ic) {
+      constexpr int ks = decltype(ic)::value;
+      frag_load<ks>(kp + k_col0 + 16 * ks);
+      frag_load<8 + ks>(kp + v_col0 + 16 * ks);
+    });
+  };
+  PROF(11);
+  pass_begin(blk_first);
+  static_for<8>([&](auto ic) { acc_zero<decltype(ic)::value>(); });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int npass = CAUSAL ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    for (int gq = 0; gq < kv_group; ++gq) {
+      const int hq = h * kv_group + gq;
+      if (gq > 0) {                     // (query head 0: issued by pass_begin, landed and published before this point)
+        issue_tile(hq, t_begin, 0);
+        issue_tile(hq, min(t_begin + 1, nt - 1), 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      PROF(7);
+      // carried from tile to tile: sub-tile A's accumulators (pre-loaded with -lse / scale and -delta), its first dO row
+      // fragments (the matching Q fragments sit in AGPRs a[192:207])
+      f32x16_t sA, pA;
+      bf16x8_t foA[KS];
+      // quarter j (rows 4 j .. 4 j + 3) of an accumulator input <- four consecutive floats of the tile's -lse / scale or -delta
+      auto acc_quarter = [&](f32x16_t& ax, int j, const f32x4_t v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ax[4 * j + i] = v[i];
+      };
+      {
+#include "attn_dkv5_prefetch.inc"
+      }
+      int buf = 0;
+      for (int t = t_begin; t < nt; ++t) {
+        const int qs0 = t * 64;
+        const int tn = min(t + 2, nt - 1);               // fetched meanwhile (clamped: the DMA issues stay unconditional)
+        const int bufn = (buf + 2) & 3;
+        const uint32_t flip = buf == 3 ? (uint32_t)(-3 * STAGE) : (uint32_t)STAGE;
+        auto flip_rows = [&]() {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) rb[ks] += flip;
+          lh += flip;
+        };
+        auto flip_tr = [&]() {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int et = 0; et < ET; ++et) tb[u][et] += flip;
+        };
+        if ((CAUSAL && qs0 + 63 < kv0w) || (qs0 >= e1 && kv0w >= sh && kv0w + 31 < e1)) {
+#include "attn_dkv5_skip.inc"
+        } else {
+          bool need_mask_a, need_mask_b;
+          auto mask_flags = [&]() {            // computed under the first MFMAs (an opaque copy of qs0 keeps the SALU chain here)
+            int q2 = qs0;
+            asm volatile("" : "+s"(q2));
+            need_mask_a = (q2 + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > q2) ||
+                          (q2 + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
+            need_mask_b = (q2 + 63 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > q2 + 32) ||
+                          (q2 + 63 >= e1 && kv0w + 31 >= sh && kv0w < e1);
+          };
+          f32x16_t sB, pB;
+          bf16x8_t foB[KS], tr[3][ET];
+          u32x4_t pfA0, pfA1, pfB0, pfB1, dsA0, dsA1, dsB0, dsB1;
+          // Each helper PINS what it produced with an empty volatile asm (pure VALU values have no ordering against the
+          // volatile asm MFMAs / reads around them: hipcc otherwise sinks whole stages to their first use).
+          auto exps = [&](f32x16_t& sx, int r0, int r1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (r >= r0 && r < r1) {
+                float p = __builtin_amdgcn_exp2f(sx[r] * c);          // masked: exp2(-inf) = 0
+                asm volatile("" : "+v"(p));
+                sx[r] = p;
+              }
+          };
+          auto dsmul = [&](f32x16_t& px, const f32x16_t& sx, int r0, int r1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (r >= r0 && r < r1) {
+                float d = sx[r] * px[r];
+                asm volatile("" : "+v"(d));
+                px[r] = d;
+              }
+          };
+          auto pack4 = [&](u32x4_t& pf, const f32x16_t& a, int base) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              uint32_t w = pack2bf(a[base + 2 * d], a[base + 2 * d + 1]);
+              asm volatile("" : "+v"(w));
+              pf[d] = w;
+            }
+          };
+#include "attn_dkv5_body.inc"
+        }
+        buf = (buf + 1) & 3;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped re-fetches of the last tiles: nothing may land later
+      __syncthreads();
+      PROF(8);
+      const uint32_t back = (uint32_t)(buf * STAGE);       // the bases point into ring buffer `buf`: back to buffer 0
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) rb[ks] -= back;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int et = 0; et < ET; ++et) tb[u][et] -= back;
+      lh -= back;
+    }  // query heads of the group
+    // the finished pass's output rows, then the NEXT pass's set-up (its LDS ring is free: barrier above; its K / V AGPRs were last
+    // read by MFMAs issued a whole phase ago), then the read-out of this pass underneath those loads
+    const bool key_ok = key < L;
+    const long pos_row = tok0 + keyc;
+    bf16_t* kp_out = dqkv + (tok0 + keyc) * lddq + h * HD;
+    const int next_blk = (pass + 1 < npass) ? blk_second : -1;
+    if (next_blk >= 0) pass_begin(next_blk);
+    PROF(9);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
+    if (rope_cos) {       // dK leaves through the inverse rotation (pairs = tiles e, e + 2)
+      const long pos = rope_pos ? rope_pos[pos_row] : (long)(pos_row - tok0);
+      static_for<2>([&](auto ic) {
+        constexpr int e = decltype(ic)::value;
+        f32x16_t lo, hi;
+        acc_read<e>(lo);
+        acc_read<e + 2>(hi);
+        if (key_ok) store_rope_bwd_pair(lo, hi, scale, rope_cos + pos * 64, rope_sin + pos * 64, e, half, kp_out + k_col0);
+      });
+    }
+    static_for<ET>([&](auto ic) {
+      constexpr int e = decltype(ic)::value;
+      f32x16_t dk_e, dv_e;
+      if (!rope_cos) acc_read<e>(dk_e);
+      acc_read<4 + e>(dv_e);
+      if (key_ok) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          uint2 w;
+          if (!rope_cos) {
+            w.x = pack2bf(dk_e[rg * 4 + 0] * scale, dk_e[rg * 4 + 1] * scale);
+            w.y = pack2bf(dk_e[rg * 4 + 2] * scale, dk_e[rg * 4 + 3] * scale);
+            *(uint2*)(kp_out + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
+          }
+          w.x = pack2bf(dv_e[rg * 4 + 0], dv_e[rg * 4 + 1]);
+          w.y = pack2bf(dv_e[rg * 4 + 2], dv_e[rg * 4 + 3]);
+          *(uint2*)(kp_out + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
+        }
+      }
+    });
+    PROF(10);
+    if (next_blk < 0) break;
+    static_for<8>([&](auto ic) { acc_zero<decltype(ic)::value>(); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next pass's K / V fragments and first tiles (and this pass's stores)
+    __syncthreads();
+    PROF(7);
+  }  // pass
+#ifdef RV_DKV5_PROF
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) atomicAdd(&rv_dkv5_prof[i], (unsigned long long)pr[i]);
+    atomicAdd(&rv_dkv5_prof[14], __builtin_amdgcn_s_memtime() - pr_t0);
+    atomicAdd(&rv_dkv5_prof[15], 1ull);
+  }
+#endif
+}
+#undef BF
+#undef PROF
 
 }  // namespace
 
 extern "C" {
 
-#ifdef RV_DKV4_PROF
-// experiment builds only: read and clear the phase counters of attn_bwd_dkv4_kernel (16 x u64)
+#if defined(RV_DKV4_PROF) || defined(RV_DKV5_PROF)
+// experiment builds only: read and clear the phase counters of the profiled dK/dV kernel (16 x u64)
 int rv_debug_dkv4_prof(unsigned long long* out16) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rv_dkv4_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+#ifdef RV_DKV5_PROF
+#define RV_PROF_SYM rv_dkv5_prof
+#else
+#define RV_PROF_SYM rv_dkv4_prof
+#endif
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(RV_PROF_SYM), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
   unsigned long long z[16] = {0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(rv_dkv4_prof), z, sizeof(z)) != hipSuccess;
+  return hipMemcpyToSymbol(HIP_SYMBOL(RV_PROF_SYM), z, sizeof(z)) != hipSuccess;
+#undef RV_PROF_SYM
 }
 #endif
 
@@ -1715,6 +2022,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   constexpr int DQ_LDS = 4 * 64 * 256;
   constexpr int DKV_LDS = 2 * (2 * 64 * 256 + 512);
   constexpr int DKV4_LDS = 3 * (2 * 64 * 256 + 512);     // version 4: three-stage ring
+  constexpr int DKV5_LDS = 4 * (2 * 64 * 256 + 512);     // version 5: four-stage ring
   static bool attr_done = false;
   static int dkv_version = 3;
   static int dkv_ablate = 0;
@@ -1736,8 +2044,10 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
 #endif
     hipFuncSetAttribute((const void*)attn_bwd_dkv4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV4_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV4_LDS);
-    const char* e = getenv("RV_ATTN_DKV");        // A/B knob: 2 = the compiler-scheduled version-2 kernel, 3 = version 3, 4 = version 4
-    if (e && atoi(e) >= 2 && atoi(e) <= 4) dkv_version = atoi(e);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV5_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV5_LDS);
+    const char* e = getenv("RV_ATTN_DKV");        // A/B knob: 2 = the compiler-scheduled version-2 kernel, 3 / 4 / 5 = the hand-scheduled versions
+    if (e && atoi(e) >= 2 && atoi(e) <= 5) dkv_version = atoi(e);
     attr_done = true;
   }
   // dQ: one workgroup per (query head, query block); dK/dV: per (KEY/VALUE head, key block), looping over its query heads
@@ -1752,6 +2062,8 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
       hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
     else if (dkv_version == 4)
       hipLaunchKernelGGL((attn_bwd_dkv4_kernel<true>), grid_kv, block, DKV4_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+    else if (dkv_version == 5)
+      hipLaunchKernelGGL((attn_bwd_dkv5_kernel<true>), grid_kv, block, DKV5_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
 #ifdef RV_ATTN_EXPERIMENTS
 #define RV_ABL_LAUNCH(N) else if (dkv_ablate == N) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, N>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
     RV_ABL_LAUNCH(1) RV_ABL_LAUNCH(2) RV_ABL_LAUNCH(3) RV_ABL_LAUNCH(5) RV_ABL_LAUNCH(6)
@@ -1766,6 +2078,8 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
       hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
     else if (dkv_version == 4)
       hipLaunchKernelGGL((attn_bwd_dkv4_kernel<false>), grid_kv, block, DKV4_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
+    else if (dkv_version == 5)
+      hipLaunchKernelGGL((attn_bwd_dkv5_kernel<false>), grid_kv, block, DKV5_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
     else
       hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
   }

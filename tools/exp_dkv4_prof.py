@@ -46,10 +46,11 @@ for kb in range(nkb):
     tiles += nt - kv0 // 64
 tiles_total = tiles * B * H
 wgs = v[15] / iters
-names = ["glue", "P1 S^T", "P2 dP^T+exp", "P3 dV_A dK_A", "P4 dV_B dK_B+DMA", "tile-end waits", "barrier", "pass prologue/epilogue"]
-tot = sum(v[:8])
+names = ["glue", "P1 S^T", "P2 dP^T+exp", "P3 dV_A dK_A", "P4 dV_B dK_B+DMA", "tile-end waits", "barrier", "pass prologue/epilogue",
+         "v5: loop-end vmcnt(0) + barrier", "v5: next pass issue (DMA, K/V loads)", "v5: read-out + stores", "v5: kernel prologue"]
+tot = sum(v[:12])
 print(f"lib {os.environ.get('RV_HIP_LIB', 'default')}: dq + dkv {ms:.3f} ms; {wgs:.0f} workgroups, {tiles_total} tiles per launch, "
       f"{v[14] / v[15]:.0f} ticks per workgroup, stamped {tot / v[15]:.0f}")
-for n, x in zip(names, v[:8]):
-    print(f"  {n:26s} {100.0 * x / tot:5.1f} %   {x / iters / tiles_total:8.2f} ticks per tile")
+for n, x in zip(names, v[:12]):
+    print(f"  {n:38s} {100.0 * x / tot:5.1f} %   {x / iters / tiles_total:8.2f} ticks per tile")
 print(f"  total per tile {tot / iters / tiles_total:.2f} ticks (wave 0 of every workgroup)")
