@@ -1876,21 +1876,46 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
     }  // query heads of the group
     // the finished pass's output rows, then the NEXT pass's set-up (its LDS ring is free: barrier above; its K / V AGPRs were last
     // read by MFMAs issued a whole phase ago), then the read-out of this pass underneath those loads
-    const bool key_ok = key < L;
     const long pos_row = tok0 + keyc;
-    bf16_t* kp_out = dqkv + (tok0 + keyc) * lddq + h * HD;
+    const int out_row0 = kv0w;                  // first key row of this wave's finished tile
     const int next_blk = (pass + 1 < npass) ? blk_second : -1;
     if (next_blk >= 0) pass_begin(next_blk);
     PROF(9);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
-    if (rope_cos) {       // dK leaves through the inverse rotation (pairs = tiles e, e + 2)
+    // Read-out through LDS.  A lane owns ONE key row and 4 consecutive columns per accumulator row group: storing from registers
+    // is 32 eight-byte stores per wave instruction into 32 different 24 KB-strided rows (phase stamps: 10 % of the kernel).  Each
+    // wave stages its [32 keys][128] dK and dV tiles (bf16, 16-byte chunks XOR-swizzled by the row) in ring buffers 2 / 3 - the
+    // next pass's first tiles go to buffers 0 / 1 - and writes them out as whole 256-byte rows, 16 bytes per lane.
+    uint8_t* stg = smem + 2 * STAGE + wave * 16384;
+    auto stage = [&](int m, int e, int rg, uint32_t w0, uint32_t w1) {       // 4 columns e*32 + rg*8 + 4*half .. of key row fr
+      uint2 w;
+      w.x = w0;
+      w.y = w1;
+      *(uint2*)(stg + m * 8192 + fr * 256 + (((e * 4 + rg) ^ (fr & 15)) << 4) + half * 8) = w;
+    };
+    if (rope_cos) {       // dK leaves through the inverse rotation (pairs = tiles e, e + 2): dx1 = dy1 cos + dy2 sin, dx2 = dy2 cos - dy1 sin
       const long pos = rope_pos ? rope_pos[pos_row] : (long)(pos_row - tok0);
+      const float* cr = rope_cos + pos * 64;
+      const float* sr = rope_sin + pos * 64;
       static_for<2>([&](auto ic) {
         constexpr int e = decltype(ic)::value;
         f32x16_t lo, hi;
         acc_read<e>(lo);
         acc_read<e + 2>(hi);
-        if (key_ok) store_rope_bwd_pair(lo, hi, scale, rope_cos + pos * 64, rope_sin + pos * 64, e, half, kp_out + k_col0);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int i0 = e * 32 + rg * 8 + 4 * half;
+          const f32x4_t cc = *(const f32x4_t*)(cr + i0), ss = *(const f32x4_t*)(sr + i0);
+          float o1[4], o2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x = bf2f(f2bf(lo[rg * 4 + j] * scale)), y = bf2f(f2bf(hi[rg * 4 + j] * scale));
+            o1[j] = x * cc[j] + y * ss[j];
+            o2[j] = y * cc[j] - x * ss[j];
+          }
+          stage(0, e, rg, pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
+          stage(0, e + 2, rg, pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]));
+        }
       });
     }
     static_for<ET>([&](auto ic) {
@@ -1898,26 +1923,43 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
       f32x16_t dk_e, dv_e;
       if (!rope_cos) acc_read<e>(dk_e);
       acc_read<4 + e>(dv_e);
-      if (key_ok) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          uint2 w;
-          if (!rope_cos) {
-            w.x = pack2bf(dk_e[rg * 4 + 0] * scale, dk_e[rg * 4 + 1] * scale);
-            w.y = pack2bf(dk_e[rg * 4 + 2] * scale, dk_e[rg * 4 + 3] * scale);
-            *(uint2*)(kp_out + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
-          }
-          w.x = pack2bf(dv_e[rg * 4 + 0], dv_e[rg * 4 + 1]);
-          w.y = pack2bf(dv_e[rg * 4 + 2], dv_e[rg * 4 + 3]);
-          *(uint2*)(kp_out + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
-        }
+      for (int rg = 0; rg < 4; ++rg) {
+        if (!rope_cos)
+          stage(0, e, rg, pack2bf(dk_e[rg * 4 + 0] * scale, dk_e[rg * 4 + 1] * scale), pack2bf(dk_e[rg * 4 + 2] * scale, dk_e[rg * 4 + 3] * scale));
+        stage(1, e, rg, pack2bf(dv_e[rg * 4 + 0], dv_e[rg * 4 + 1]), pack2bf(dv_e[rg * 4 + 2], dv_e[rg * 4 + 3]));
       }
     });
+    const bool all_rows = out_row0 + 31 < L;      // wave-uniform: every row of the tile exists -> exactly 16 store instructions
+    {
+      bf16_t* out0 = dqkv + (tok0 + out_row0) * lddq + h * HD;
+      const int pc = lane & 15;
+      auto write_rows = [&](auto pred) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + (lane >> 4);
+            const u32x4_t v = *(const u32x4_t*)(stg + m * 8192 + row * 256 + (pc << 4));
+            bf16_t* dst = out0 + (long)row * lddq + (m ? v_col0 : k_col0) + ((pc ^ (row & 15)) << 3);
+            if constexpr (decltype(pred)::value) {
+              if (out_row0 + row < L) *(u32x4_t*)dst = v;
+            } else {      // asm: EXACTLY one store instruction each - the counted vmcnt(16) at the end of the pass relies on it
+              asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            }
+          }
+      };
+      if (all_rows) write_rows(std::false_type{});
+      else write_rows(std::true_type{});
+    }
     PROF(10);
     if (next_blk < 0) break;
     static_for<8>([&](auto ic) { acc_zero<decltype(ic)::value>(); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next pass's K / V fragments and first tiles (and this pass's stores)
-    __syncthreads();
+    // the next pass's K / V fragments and first tiles have landed; this pass's 16 row stores - the NEWEST vector-memory operations -
+    // may stay in flight (a wave with a ragged last tile issued an unknown number of them: it waits for everything)
+    if (all_rows) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     PROF(7);
   }  // pass
 #ifdef RV_DKV5_PROF
@@ -2024,7 +2066,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   constexpr int DKV4_LDS = 3 * (2 * 64 * 256 + 512);     // version 4: three-stage ring
   constexpr int DKV5_LDS = 4 * (2 * 64 * 256 + 512);     // version 5: four-stage ring
   static bool attr_done = false;
-  static int dkv_version = 3;
+  static int dkv_version = 5;        // round 4: version 5 (tools/gen_attn_dkv5.py); RV_ATTN_DKV=3 selects the round-2/3 kernel
   static int dkv_ablate = 0;
   (void)dkv_ablate;
   if (!attr_done) {
