@@ -1935,17 +1935,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
       bf16_t* out0 = dqkv + (tok0 + out_row0) * lddq + h * HD;
       const int pc = lane & 15;
       auto write_rows = [&](auto pred) {
+        u32x4_t v[2][8];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[m][i] = *(const u32x4_t*)(stg + m * 8192 + (4 * i + (lane >> 4)) * 256 + (pc << 4));
+        // hipcc's waitcnt insertion does not look at inline-asm operands: without this wait the asm stores below sent registers
+        // whose LDS read had not landed yet (seen as garbage in the last rows of dK, non-deterministically)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int row = 4 * i + (lane >> 4);
-            const u32x4_t v = *(const u32x4_t*)(stg + m * 8192 + row * 256 + (pc << 4));
             bf16_t* dst = out0 + (long)row * lddq + (m ? v_col0 : k_col0) + ((pc ^ (row & 15)) << 3);
             if constexpr (decltype(pred)::value) {
-              if (out_row0 + row < L) *(u32x4_t*)dst = v;
+              if (out_row0 + row < L) *(u32x4_t*)dst = v[m][i];
             } else {      // asm: EXACTLY one store instruction each - the counted vmcnt(16) at the end of the pass relies on it
-              asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+              // (s_nop: a store of more than 8 bytes reads its data registers late - they must not be rewritten in the next
+              // cycle; hipcc pads its own stores, not inline asm: the address arithmetic of the following store reused them)
+              asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v[m][i]) : "memory");
             }
           }
       };

@@ -263,7 +263,20 @@ def hip_case(case: str, model, trainer, cfg: O.LlavaCfg, full_grads: bool = Fals
                                   losses=out.per_pair[0].float().cpu() if getattr(out, "per_pair", None) is not None else None)
     if not c["step"]:
         return res
-    model.backward(out, model.last_coef)
+    coef = model.last_coef
+    if "beta_z" in c:
+        # Conditioned regime: d loss / d logp = -+ beta sigma(-beta z) / B depends on the FORWARD's logit, and a bf16 forward moves
+        # beta z by ~0.2 (compare(): logit_abs_err; the bf16-emulated oracle by ~0.4), i.e. the coefficient - and with it every
+        # gradient norm - by ~10 %.  That is forward noise, asserted on its own; the BACKWARD is compared at the strict bars by
+        # handing it the oracle's coefficients (model.backward takes them as an argument), so that a gradient mismatch cannot hide
+        # behind, or be blamed on, the coefficient.  Both coefficient vectors are recorded.
+        B = coef.numel() // 2
+        sig = torch.sigmoid(-torch.tensor(c["beta_z"], dtype=torch.float32))
+        beta = float(batch["beta"])
+        coef_ref = torch.cat([-beta * sig / B, beta * sig / B]).to(coef.device)
+        res["coef_hip"], res["coef_oracle"] = coef.float().cpu(), coef_ref.cpu()
+        coef = coef_ref
+    model.backward(out, coef)
     st = model.store
     gnorm, gsamp = {}, {}
     for name, v in _trainable_views(model, st.flat_g):
@@ -285,6 +298,8 @@ def hip_case(case: str, model, trainer, cfg: O.LlavaCfg, full_grads: bool = Fals
 def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Optional[Dict[str, torch.Tensor]] = None,
             check: bool = True) -> Dict[str, object]:
     """Metrics of HIP vs oracle fixture; with ``check`` the bars below are asserted.
+    Conditioned cases (beta_z): the backward ran on the ORACLE's coefficients (hip_case), the forward's logit error and the
+    coefficients the HIP loss kernel derived from it are asserted separately.
     Bars: token indexing bit exact; sequence log-prob sums and loss 1e-3 relative (north_star); per-token log-probs no
     further from the fp32 oracle than the bf16-EMULATED oracle is (mean; worst token within 1.5 x the emulation's worst);
     gradients: every tensor's norm within 3 %, direction cosine >= 0.99; total norm / clip factor within 1 %; post-step
@@ -344,6 +359,11 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
         elif "emu_per_token" in fx:
             # conditioned regime: loss ~ ln 2, |d loss / d logit| <= 1: the loss error is bounded by the mean logit error
             assert max(m["logit_err_in_sigmas"]) <= 3.0, (m["logit_abs_err"], m["logit_err_bar_3sigma"])
+            if "coef_hip" in hip:   # the coefficients the HIP loss kernel derived from ITS logits: beta sigma(-beta z) / B, |sigma'| <= 1/4
+                B = lp.numel() // 2
+                dc = (hip["coef_hip"] - hip["coef_oracle"]).abs() * B / beta
+                m["coef_sigma_abs_err"] = dc.tolist()
+                assert bool((dc[:B] <= 0.25 * dd.abs() + 1e-4).all()) and bool((dc[B:] <= 0.25 * dd.abs() + 1e-4).all()), (dc.tolist(), dd.tolist())
             assert m["per_token_rms_err"] <= m["emu_bf16_per_token_rms_err"], (m["per_token_rms_err"], m["emu_bf16_per_token_rms_err"])
             assert m["loss_abs_err"] <= sum(m["logit_err_bar_3sigma"]) / len(m["logit_err_bar_3sigma"]), m["loss_abs_err"]
         if "emu_per_token" in fx:

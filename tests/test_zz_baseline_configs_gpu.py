@@ -259,7 +259,7 @@ def test_full_depth_step0_self_consistency(full_depth, golden_dir, case):
     b = dict(batch)
     b["ref_win_logp"], b["ref_rej_logp"] = torch.tensor(win_lp), torch.tensor(rej_lp)
     model.train(True)
-    loss = trainer.compute_loss(model, b)
+    loss = trainer.compute_loss(model, dict(b))          # (get_beta_and_logps pops the keys it consumes, like the reference)
     out = model.last_out
     metrics = trainer.pop_metrics()
     pol = out.seq_logp.float().cpu()
