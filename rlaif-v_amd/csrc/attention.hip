@@ -761,230 +761,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 }
 
 // =============================================================================================
-// backward, dK/dV, version 2: no pre-transposed copies.
-//   * Q / dO tiles (64 queries x 128, row-major as in HBM) are double-buffered in LDS by global_load_lds
-//     (no staging registers; next tile in flight while the current one is consumed; one barrier per tile);
+// backward, dK/dV: no pre-transposed copies.
+//   * Q / dO tiles (64 queries x 128, row-major as in HBM) are ring-buffered in LDS by global_load_lds;
 //   * the operands whose contraction index is the query (Q^T for dK, dO^T for dV) are read from the SAME tiles
 //     with ds_read_b64_tr_b16, in the order in which P / dS leave the accumulators;
 //   * chunk swizzle c ^ (((row&3)<<2) | ((row>>2)&3)): the 32-row ds_read_b128 pattern sees 16 distinct chunks and
 //     the 4 rows of a transposing read fall into 4 different quarters of the 256-byte bank row;
 //   * lse / delta of the tile arrive through 4-byte LDS-DMA.
+// (Version 2 of the kernel - the compiler-scheduled one - lives in history: commit 5e465f4 and before.)
 // =============================================================================================
 __device__ __forceinline__ uint32_t qtile_off(int row, int c) {
   return (uint32_t)(row * 256 + ((c ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4));
 }
-
-template <bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
-                                                               int k_col0, int v_col0,
-                                                               const bf16_t* __restrict__ dO, long lddo,
-                                                               const float* __restrict__ lse,
-                                                               const float* __restrict__ delta,
-                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
-                                                               int nx, float scale, const int* __restrict__ seg_sh,
-                                                               const int* __restrict__ seg_e1, int kv_group,
-        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
-  // H = number of KEY/VALUE heads (the grid walks kv heads); the kv_group query heads h*G .. h*G+G-1 that share kv head h
-  // are accumulated into the same dK / dV tile (grouped-query attention; kv_group = 1: plain multi-head attention)
-  constexpr int HD = 128, KS = 8, ET = 4;
-  constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64]
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 31, half = lane >> 5;
-  int bx, h, s;
-  attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
-  const long tok0 = (long)s * L;
-  // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
-  const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
-  const int nkb = (L + 127) / 128;
-  const float c = scale * LOG2E;
-  const int HQ = H * kv_group;
-
-  // LDS-DMA assignment: each wave fills 4 pieces (4 rows x 256 B) of Q and of dO per tile; wave 0 also lse/delta
-  int d_row[4], d_chunk[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    d_row[i] = (wave * 4 + i) * 4 + (lane >> 4);
-    d_chunk[i] = (lane & 15) ^ (((d_row[i] & 3) << 2) | ((d_row[i] >> 2) & 3));
-  }
-  auto issue_tile = [&](int hq, int t, int buf) {          // hq = query head
-    uint8_t* st = smem + buf * STAGE;
-    const int qs0 = t * 64;
-    const float* lse_base = lse + ((long)s * HQ + hq) * L;
-    const float* delta_base = delta + ((long)s * HQ + hq) * L;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long tk = tok0 + min(qs0 + d_row[i], L - 1);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(qkv + tk * ld + q_col0 + hq * HD + d_chunk[i] * 8),
-          (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(dO + tk * lddo + hq * HD + d_chunk[i] * 8),
-          (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
-    }
-    if (wave == 0) {
-      const int qq = min(qs0 + lane, L - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse_base + qq),
-                                       (__attribute__((address_space(3))) void*)(st + 32768), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta_base + qq),
-                                       (__attribute__((address_space(3))) void*)(st + 32768 + 256), 4, 0, 0);
-    }
-  };
-
-  // ---- per-lane LDS offsets, hoisted so the loops only add compile-time constants (the XOR swizzle defeats
-  // the compiler's immediate-offset folding and it would otherwise keep ~100 address VGPRs alive)
-  // row-operand reads (ds_read_b128): row = qt*32 + fr (+8192 per qt), chunk 2*ks + half
-  uint32_t boff[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) boff[ks] = qtile_off(fr, 2 * ks + half);
-  // transposing reads: row = qt*32 + 16*k2 + 8u + 4*(g4>>1) + (s16>>2); column e = et*32 + 16*(g4&1) + 4*(s16&3)
-  const int g4 = lane >> 4, s16 = lane & 15;
-  uint32_t toff[2][ET];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int et = 0; et < ET; ++et)
-      toff[u][et] = qtile_off(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
-                    (uint32_t)((s16 & 1) * 8);
-  auto tr8 = [&](uint32_t tile_addr, int row0, int et) -> bf16x8_t {   // row0 = qt*32 + k2*16; asm reads: caller waits
-    return __builtin_shufflevector(ds_tr16_b64_asm(tile_addr + toff[0][et], row0 * 256),
-                                   ds_tr16_b64_asm(tile_addr + toff[1][et], row0 * 256), 0, 1, 2, 3, 4, 5, 6, 7);
-  };
-
-  int blk_first, blk_second;
-  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
-  const int npass = CAUSAL ? 2 : 1;
-  for (int pass = 0; pass < npass; ++pass) {
-    const int kvb = (pass == 0) ? blk_first : blk_second;
-    if (kvb < 0) break;
-    const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
-    const int key = kv0w + fr, keyc = min(key, L - 1);
-    KeyLaneMask<CAUSAL> kmask;
-    kmask.init(key, L, sh, e1);
-
-    bf16x8_t kf[KS], vf[KS];
-    {
-      const bf16_t* kp = qkv + (tok0 + keyc) * ld + h * HD + 8 * half;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = *(const bf16x8_t*)(kp + k_col0 + 16 * ks);
-        vf[ks] = *(const bf16x8_t*)(kp + v_col0 + 16 * ks);
-      }
-    }
-    f32x16_t dk[ET], dv[ET];
-#pragma unroll
-    for (int e = 0; e < ET; ++e) { mfma_agpr_zero(dk[e]); mfma_agpr_zero(dv[e]); }
-
-    const int t_begin = CAUSAL ? (kv0 / 64) : 0;
-    // a key block that lies entirely in the chosen branch [sh, e1) is invisible to every rejected-branch query (>= e1):
-    // its query loop ends at e1 instead of L (no DMA, no barrier for the tiles behind it)
-    const int nt = (kv0 >= sh && kv0 + 127 < e1) ? min((L + 63) / 64, (e1 + 63) / 64) : (L + 63) / 64;
-    for (int gq = 0; gq < kv_group; ++gq) {
-    const int hq = h * kv_group + gq;
-    issue_tile(hq, t_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int t = t_begin; t < nt; ++t) {
-      const int buf = (t - t_begin) & 1;
-      const uint8_t* Qs = smem + buf * STAGE;
-      const uint8_t* dOs = Qs + 16384;
-      const float* lse_s = (const float*)(Qs + 32768);
-      const float* delta_s = lse_s + 64;
-      const int qs0 = t * 64;
-      if (t + 1 < nt) issue_tile(hq, t + 1, buf ^ 1);
-
-      if (!(CAUSAL && qs0 + 63 < kv0w) && !(qs0 >= e1 && kv0w >= sh && kv0w + 31 < e1)) {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          f32x16_t sacc, pacc;
-          zero16(sacc);
-          zero16(pacc);
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t qf = *(const bf16x8_t*)(Qs + boff[ks] + qt * 8192);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sacc, 0, 0, 0);
-            const bf16x8_t df = *(const bf16x8_t*)(dOs + boff[ks] + qt * 8192);
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], pacc, 0, 0, 0);
-          }
-          // transposed fragments of the FIRST 16 queries are requested now: they do not depend on P / dS, so their
-          // LDS latency hides under the exp / mask VALU work below (one wave per SIMD: nothing else would hide it)
-          const uint32_t dos_addr = lds_addr_of(dOs), qs_addr = lds_addr_of(Qs);
-          bf16x8_t dotf0[ET], qtf0[ET], dotf1[ET], qtf1[ET];
-#pragma unroll
-          for (int e = 0; e < ET; ++e) {
-            dotf0[e] = tr8(dos_addr, qt * 32, e);
-            qtf0[e] = tr8(qs_addr, qt * 32, e);
-          }
-          const int qsub = qs0 + qt * 32;                      // first query of this 32-row sub-tile
-          const bool need_mask = (qsub + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qsub) ||
-                                 (qsub + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
-          if (need_mask) kmask.apply(sacc, qsub + 4 * half);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -LOG2E * lse_s[ql]));
-            sacc[r] = p;
-            pacc[r] = p * (pacc[r] - delta_s[ql]);
-          }
-          const bf16x8_t pf0 = pack_frag(sacc, 0), dsf0 = pack_frag(pacc, 0);
-          const bf16x8_t pf1 = pack_frag(sacc, 8), dsf1 = pack_frag(pacc, 8);
-          // second 16 queries, in two batches of 8 asm reads (lgkmcnt is a 4-bit counter: at most 15 can be counted)
-#pragma unroll
-          for (int e = 0; e < ET; ++e) dotf1[e] = tr8(dos_addr, qt * 32 + 16, e);
-          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // everything older than the 8 reads just issued
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < ET; ++e) {
-            mfma_agpr(dv[e], dotf0[e], pf0);
-            mfma_agpr(dk[e], qtf0[e], dsf0);
-          }
-#pragma unroll
-          for (int e = 0; e < ET; ++e) qtf1[e] = tr8(qs_addr, qt * 32 + 16, e);
-          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // dotf1 landed
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < ET; ++e) mfma_agpr(dv[e], dotf1[e], pf1);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < ET; ++e) mfma_agpr(dk[e], qtf1[e], dsf1);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    }  // query heads of the group
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
-
-    if (key < L && rope_cos) {
-      const long pos = rope_pos ? rope_pos[tok0 + key] : key;
-      bf16_t* kb = dqkv + (tok0 + key) * lddq + h * HD + k_col0;
-      store_rope_bwd_pair(dk[0], dk[2], scale, rope_cos + pos * 64, rope_sin + pos * 64, 0, half, kb);
-      store_rope_bwd_pair(dk[1], dk[3], scale, rope_cos + pos * 64, rope_sin + pos * 64, 1, half, kb);
-    }
-    if (key < L) {
-      bf16_t* kp = dqkv + (tok0 + key) * lddq + h * HD;
-#pragma unroll
-      for (int e = 0; e < ET; ++e)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          uint2 w;
-          if (!rope_cos) {
-            w.x = pack2bf(dk[e][rg * 4 + 0] * scale, dk[e][rg * 4 + 1] * scale);
-            w.y = pack2bf(dk[e][rg * 4 + 2] * scale, dk[e][rg * 4 + 3] * scale);
-            *(uint2*)(kp + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
-          }
-          w.x = pack2bf(dv[e][rg * 4 + 0], dv[e][rg * 4 + 1]);
-          w.y = pack2bf(dv[e][rg * 4 + 2], dv[e][rg * 4 + 3]);
-          *(uint2*)(kp + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
-        }
-    }
-  }  // pass
-}
-
 
 // =============================================================================================
 // backward, dK/dV, version 3.  Same decomposition, tiles, LDS image and arithmetic as version 2 (bit-identical results);
@@ -1337,309 +1125,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
 
 
 // =============================================================================================
-// backward, dK/dV, version 4 (round 4).  Version 3's decomposition, LDS image, operand layouts and arithmetic; what changes is
-// the ORDER of work inside a tile and the depth of the LDS ring.  PMC on version 3 (profiles/r03_pmc_attn_packed_vs_plain_final.txt):
-// matrix pipe busy 0.31, 0.37 of the wave's cycles in issue stalls, 0.22 parked - with ONE wave per SIMD every dependency of the
-// chain S^T -> exp -> dP^T -> dS -> dV / dK of a 32-query sub-tile is exposed, and the two sub-tiles of a tile run one after the
-// other.  Here both sub-tiles are in flight together and a tile is four phases of 16 MFMAs; the VALU / LDS work between two
-// MFMAs always belongs to a DIFFERENT stage than the MFMAs around it (schedule and counted waits: tools/gen_attn_dkv4.py ->
-// attn_dkv4_body.inc).  Further:
-//   * the Q row fragments of both sub-tiles are read from LDS straight into AGPRs a[192:255] (the S^T MFMAs take both operands
-//     from the accumulator file), S^T is ONE 8-deep chain per sub-tile - the two chains alternate, so no MFMA waits for its
-//     predecessor and the split partial sums of version 3 (16 extra VALU adds per sub-tile) are gone;
-//   * Q / dO tiles sit in a THREE-stage LDS ring (99.8 KB): tile t + 2 is fetched during the last phase of tile t and awaited
-//     at the end of tile t + 1 with a counted vmcnt, so the shorter tile no longer exposes the LDS-DMA latency;
-//   * -log2(e) x lse is applied once per lse value under the S^T MFMAs (as many multiplications as before, elsewhere).
-// =============================================================================================
-#define BF(x) __builtin_bit_cast(bf16x8_t, x)
-// RV_DKV4_PROF (experiment builds): s_memtime stamps at the phase boundaries of a tile, accumulated per wave 0 of every workgroup
-// into rv_dkv4_prof[] (ticks): 0 skipped-tile / loop glue, 1 P1, 2 P2, 3 P3, 4 P4, 5 end-of-tile waits, 6 barrier, 7 prologue +
-// epilogue of a pass, 14 whole kernel per workgroup, 15 workgroups.  Each stamp drains lgkmcnt (s_memtime is an SMEM read).
-#ifdef RV_DKV4_PROF
-__device__ unsigned long long rv_dkv4_prof[16];
-#define PROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += (unsigned)(t_ - pr_last); pr_last = t_; }
-#else
-#define PROF(i)
-#endif
-#define RV_CAT2(a, b) a##b
-#define RV_CAT(a, b) RV_CAT2(a, b)
-template <bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
-                                                               int k_col0, int v_col0,
-                                                               const bf16_t* __restrict__ dO, long lddo,
-                                                               const float* __restrict__ lse,
-                                                               const float* __restrict__ delta,
-                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
-                                                               int nx, float scale, const int* __restrict__ seg_sh,
-                                                               const int* __restrict__ seg_e1, int kv_group,
-        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
-  constexpr int HD = 128, KS = 8, ET = 4;
-  constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64] = 0x8200
-  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 31, half = lane >> 5;
-  int bx, h, s;
-  attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
-  const long tok0 = (long)s * L;
-  const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
-  const int nkb = (L + 127) / 128;
-  const float c = scale * LOG2E;
-  const int HQ = H * kv_group;
-
-  int d_row[4], d_chunk[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    d_row[i] = (wave * 4 + i) * 4 + (lane >> 4);
-    d_chunk[i] = (lane & 15) ^ (((d_row[i] & 3) << 2) | ((d_row[i] >> 2) & 3));
-  }
-  const uint32_t ldqb = (uint32_t)(ld * 2), lddob = (uint32_t)(lddo * 2);
-  // One LDS-DMA piece of tile t into ring buffer buf: j = 0..7 -> Q piece j>>1 (even j) / dO piece j>>1 (odd j); j = 8: the tile's
-  // lse (wave 0) or delta (wave 1).  Waves 0 and 1 therefore issue NP = 9 vector-memory operations per tile, waves 2 and 3 eight.
-  auto issue_piece = [&](int hq, int t, int buf, int j) {
-    uint8_t* st = smem + buf * STAGE;
-    int qs0 = t * 64;
-    asm volatile("" : "+s"(qs0));          // address arithmetic computed HERE, not hoisted to the top of the tile (spills)
-    if (j < 8) {
-      const int i = j >> 1;
-      const uint32_t r = (uint32_t)min(qs0 + d_row[i], L - 1);
-      if ((j & 1) == 0) {
-        const char* base = (const char*)(qkv + tok0 * ld + q_col0 + hq * HD);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (r * ldqb + d_chunk[i] * 16u)),
-                                         (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, 0, 0);
-      } else {
-        const char* base = (const char*)(dO + tok0 * lddo + hq * HD);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (r * lddob + d_chunk[i] * 16u)),
-                                         (__attribute__((address_space(3))) void*)(st + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
-      }
-    } else if (wave < 2) {
-      const int qq = min(qs0 + lane, L - 1);
-      const float* src = (wave == 0 ? lse : delta) + ((long)s * HQ + hq) * L + qq;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(st + 32768 + wave * 256), 4, 0, 0);
-    }
-  };
-  auto issue_tile = [&](int hq, int t, int buf) {
-#pragma unroll
-    for (int j = 0; j < 9; ++j) issue_piece(hq, t, buf, j);
-  };
-  // everything of this wave but the NEWEST tile's pieces has landed
-  auto wait_all_but_newest = [&]() {
-    if (wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  };
-
-  const uint32_t lds0 = lds_addr_of(smem);
-  uint32_t rb[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) rb[ks] = lds0 + qtile_off(fr, 2 * ks + half);
-  uint32_t lh = lds0 + 32768u + (uint32_t)(half * 16);
-  const int g4 = lane >> 4, s16 = lane & 15;
-  uint32_t tb[2][ET];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int et = 0; et < ET; ++et)
-      tb[u][et] = lds0 + qtile_off(8 * u + 4 * (g4 >> 1) + (s16 >> 2), et * 4 + 2 * (g4 & 1) + ((s16 & 3) >> 1)) +
-                  (uint32_t)((s16 & 1) * 8);
-
-  int blk_first, blk_second;
-  pair_blocks<true>(bx, nkb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
-#ifdef RV_DKV4_PROF
-  unsigned pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
-  unsigned long long pr_last = pr_t0;
-#endif
-  const int npass = CAUSAL ? 2 : 1;
-  for (int pass = 0; pass < npass; ++pass) {
-    const int kvb = (pass == 0) ? blk_first : blk_second;
-    if (kvb < 0) break;
-    const int kv0 = kvb * 128, kv0w = kv0 + wave * 32;
-    const int key = kv0w + fr, keyc = min(key, L - 1);
-    KeyLaneMask<CAUSAL> kmask;
-    kmask.init(key, L, sh, e1);
-    {
-      const bf16_t* kp = qkv + (tok0 + keyc) * ld + h * HD + 8 * half;
-      static_for<KS>([&](auto ic) {
-        constexpr int ks = decltype(ic)::value;
-        frag_load<ks>(kp + k_col0 + 16 * ks);
-        frag_load<8 + ks>(kp + v_col0 + 16 * ks);
-      });
-      static_for<8>([&](auto ic) { acc_zero<decltype(ic)::value>(); });
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-
-    const int t_begin = CAUSAL ? (kv0 / 64) : 0;
-    const int nt = (kv0 >= sh && kv0 + 127 < e1) ? min((L + 63) / 64, (e1 + 63) / 64) : (L + 63) / 64;
-
-    // One 64-query tile out of ring buffer `buf` (the per-lane read bases already point into it; they advance at the end).
-    auto tile = [&](const int hq, const int t, const int buf) {
-      const int qs0 = t * 64;
-      const int tn = min(t + 2, nt - 1);                 // fetched meanwhile (clamped: the DMA issues stay unconditional)
-      const int bufn = buf == 0 ? 2 : buf - 1;           // (buf + 2) % 3
-      if ((CAUSAL && qs0 + 63 < kv0w) || (qs0 >= e1 && kv0w >= sh && kv0w + 31 < e1)) {
-        issue_tile(hq, tn, bufn);                        // nothing of this tile is visible to this wave's 32 keys
-      } else {
-        const bool need_mask_a = (qs0 + 31 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qs0) ||
-                                 (qs0 + 31 >= e1 && kv0w + 31 >= sh && kv0w < e1);
-        const bool need_mask_b = (qs0 + 63 >= L) || (kv0w + 31 >= L) || (CAUSAL && kv0w + 31 > qs0 + 32) ||
-                                 (qs0 + 63 >= e1 && kv0w + 31 >= sh && kv0w < e1);
-#ifdef RV_DKV4_ABL          // ablation bodies leave some of these unwritten: defined values, opaque to the optimiser
-        f32x16_t sA = {}, sB = {}, pA = {}, pB = {};
-        bf16x8_t foA[KS] = {}, foB[KS] = {}, tr[2][ET] = {};
-        f32x4_t lsA[4] = {}, lsB[4] = {}, deA[4] = {}, deB[4] = {};
-        u32x4_t pfA0 = {}, pfA1 = {}, pfB0 = {}, pfB1 = {}, dsA0 = {}, dsA1 = {}, dsB0 = {}, dsB1 = {};
-        asm volatile("" : "+v"(sA), "+v"(sB), "+v"(pA), "+v"(pB));
-        asm volatile("" : "+v"(pfA0), "+v"(pfA1), "+v"(pfB0), "+v"(pfB1), "+v"(dsA0), "+v"(dsA1), "+v"(dsB0), "+v"(dsB1));
-#pragma unroll
-        for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(foA[i]), "+v"(foB[i]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(lsA[i]), "+v"(lsB[i]), "+v"(deA[i]), "+v"(deB[i]), "+v"(tr[0][i]), "+v"(tr[1][i]));
-#else
-        f32x16_t sA, sB, pA, pB;
-        bf16x8_t foA[KS], foB[KS], tr[2][ET];
-        f32x4_t lsA[4], lsB[4], deA[4], deB[4];
-        u32x4_t pfA0, pfA1, pfB0, pfB1, dsA0, dsA1, dsB0, dsB1;
-#endif
-        // Each helper PINS what it produced with an empty volatile asm: pure VALU values have no ordering against the volatile asm
-        // MFMAs / reads around them, and without the pin hipcc sinks whole stages to their first use (seen in the ISA: all 16
-        // exponentials of sub-tile A in one lump behind the mask branch of sub-tile B instead of two per MFMA gap).
-        auto prescale = [&](f32x4_t (&ls)[4], int j0, int j1) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j >= j0 && j < j1) { ls[j] = ls[j] * (-LOG2E); asm volatile("" : "+v"(ls[j])); }
-        };
-        auto exps = [&](f32x16_t& sx, const f32x4_t (&ls)[4], int r0, int r1) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (r >= r0 && r < r1) {
-              float p = __builtin_amdgcn_exp2f(fmaf(sx[r], c, ls[r >> 2][r & 3]));     // masked: exp2(-inf) = 0
-              asm volatile("" : "+v"(p));
-              sx[r] = p;
-            }
-        };
-        auto dsmul = [&](f32x16_t& px, const f32x16_t& sx, const f32x4_t (&de)[4], int r0, int r1) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (r >= r0 && r < r1) {
-              float d = sx[r] * (px[r] - de[r >> 2][r & 3]);
-              asm volatile("" : "+v"(d));
-              px[r] = d;
-            }
-        };
-        auto pack2 = [&](u32x4_t& pf, const f32x16_t& a, int base, int d0) {
-#pragma unroll
-          for (int d = 0; d < 4; ++d)
-            if (d >= d0 && d < d0 + 2) {
-              uint32_t w = pack2bf(a[base + 2 * d], a[base + 2 * d + 1]);
-              asm volatile("" : "+v"(w));
-              pf[d] = w;
-            }
-        };
-        auto pack4 = [&](u32x4_t& pf, const f32x16_t& a, int base) {
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            uint32_t w = pack2bf(a[base + 2 * d], a[base + 2 * d + 1]);
-            asm volatile("" : "+v"(w));
-            pf[d] = w;
-          }
-        };
-#ifndef RV_DKV4_ABL
-#include "attn_dkv4_body.inc"
-#else                       // experiment builds: ablation bodies (tools/gen_attn_dkv4.py --ablations), results wrong by construction
-#define RV_STR2(x) #x
-#define RV_STR(x) RV_STR2(x)
-#include RV_STR(RV_CAT(attn_dkv4_body_abl, RV_DKV4_ABL).inc)
-#endif
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this tile is complete: its buffer is the next DMA target
-      wait_all_but_newest();                             // tile t + 1 has landed (this wave's pieces) ...
-      PROF(5);
-      __syncthreads();                                   // ... and everybody's
-      PROF(6);
-      const uint32_t flip = buf == 2 ? (uint32_t)(-2 * STAGE) : (uint32_t)STAGE;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) rb[ks] += flip;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int et = 0; et < ET; ++et) tb[u][et] += flip;
-      lh += flip;
-    };
-
-    for (int gq = 0; gq < kv_group; ++gq) {
-      const int hq = h * kv_group + gq;
-      issue_tile(hq, t_begin, 0);
-      issue_tile(hq, min(t_begin + 1, nt - 1), 1);
-      wait_all_but_newest();
-      __syncthreads();
-      PROF(7);
-      int buf = 0;
-      for (int t = t_begin; t < nt; ++t) {
-        tile(hq, t, buf);
-        buf = buf == 2 ? 0 : buf + 1;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped re-fetches of the last tiles: nothing may land later
-      __syncthreads();
-      const uint32_t back = (uint32_t)(buf * STAGE);       // the bases point into ring buffer `buf`: back to buffer 0
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) rb[ks] -= back;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int et = 0; et < ET; ++et) tb[u][et] -= back;
-      lh -= back;
-    }  // query heads of the group
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last asm MFMA -> v_accvgpr_read (hipcc pads nothing for asm)
-
-    bf16_t* kp_out = dqkv + (tok0 + keyc) * lddq + h * HD;
-    if (rope_cos) {       // dK leaves through the inverse rotation (pairs = tiles e, e + 2)
-      const long pos = rope_pos ? rope_pos[tok0 + keyc] : keyc;
-      static_for<2>([&](auto ic) {
-        constexpr int e = decltype(ic)::value;
-        f32x16_t lo, hi;
-        acc_read<e>(lo);
-        acc_read<e + 2>(hi);
-        if (key < L) store_rope_bwd_pair(lo, hi, scale, rope_cos + pos * 64, rope_sin + pos * 64, e, half, kp_out + k_col0);
-      });
-    }
-    static_for<ET>([&](auto ic) {
-      constexpr int e = decltype(ic)::value;
-      f32x16_t dk_e, dv_e;
-      if (!rope_cos) acc_read<e>(dk_e);
-      acc_read<4 + e>(dv_e);
-      if (key < L) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          uint2 w;
-          if (!rope_cos) {
-            w.x = pack2bf(dk_e[rg * 4 + 0] * scale, dk_e[rg * 4 + 1] * scale);
-            w.y = pack2bf(dk_e[rg * 4 + 2] * scale, dk_e[rg * 4 + 3] * scale);
-            *(uint2*)(kp_out + k_col0 + e * 32 + rg * 8 + 4 * half) = w;
-          }
-          w.x = pack2bf(dv_e[rg * 4 + 0], dv_e[rg * 4 + 1]);
-          w.y = pack2bf(dv_e[rg * 4 + 2], dv_e[rg * 4 + 3]);
-          *(uint2*)(kp_out + v_col0 + e * 32 + rg * 8 + 4 * half) = w;
-        }
-      }
-    });
-    PROF(7);
-  }  // pass
-#ifdef RV_DKV4_PROF
-  if (tid == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&rv_dkv4_prof[i], (unsigned long long)pr[i]);
-    atomicAdd(&rv_dkv4_prof[14], __builtin_amdgcn_s_memtime() - pr_t0);
-    atomicAdd(&rv_dkv4_prof[15], 1ull);
-  }
-#endif
-}
-#undef BF
-#undef PROF
-
-// =============================================================================================
 // backward, dK/dV, version 5 (round 4): version 4's layouts and arithmetic under the schedule its phase stamps asked for
 // (tools/gen_attn_dkv5.py has the analysis and generates the three straight-line bodies included below): sub-tile A runs one
 // phase ahead of sub-tile B so every phase has VALU work of its own, the row terms enter through the MFMA accumulator inputs
@@ -1647,7 +1132,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(const bf16_t* __r
 // operands read behind it, a FOUR-stage LDS ring (133 KB) fetched two tiles ahead, transposed fragments two groups ahead.
 // =============================================================================================
 #define BF(x) __builtin_bit_cast(bf16x8_t, x)
-// RV_DKV5_PROF (experiment builds; same slots as RV_DKV4_PROF): s_memtime stamps at the phase boundaries of a tile, accumulated per wave 0 of every workgroup
+// RV_DKV5_PROF (experiment builds): s_memtime stamps at the phase boundaries of a tile, accumulated per wave 0 of every workgroup
 // into rv_dkv5_prof[] (ticks): 0 skipped-tile / loop glue, 1 P1, 2 P2, 3 P3, 4 P4, 5 end-of-tile waits, 6 barrier, 7 prologue +
 // epilogue of a pass, 14 whole kernel per workgroup, 15 workgroups.  Each stamp drains lgkmcnt (s_memtime is an SMEM read).
 #ifdef RV_DKV5_PROF
@@ -1987,18 +1472,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
 
 extern "C" {
 
-#if defined(RV_DKV4_PROF) || defined(RV_DKV5_PROF)
-// experiment builds only: read and clear the phase counters of the profiled dK/dV kernel (16 x u64)
-int rv_debug_dkv4_prof(unsigned long long* out16) {
 #ifdef RV_DKV5_PROF
-#define RV_PROF_SYM rv_dkv5_prof
-#else
-#define RV_PROF_SYM rv_dkv4_prof
-#endif
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(RV_PROF_SYM), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+// experiment builds only: read and clear the phase counters of attn_bwd_dkv5_kernel (16 x u64)
+int rv_debug_dkv5_prof(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rv_dkv5_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
   unsigned long long z[16] = {0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(RV_PROF_SYM), z, sizeof(z)) != hipSuccess;
-#undef RV_PROF_SYM
+  return hipMemcpyToSymbol(HIP_SYMBOL(rv_dkv5_prof), z, sizeof(z)) != hipSuccess;
 }
 #endif
 
@@ -2072,7 +1551,6 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   hipStream_t st = (hipStream_t)stream;
   constexpr int DQ_LDS = 4 * 64 * 256;
   constexpr int DKV_LDS = 2 * (2 * 64 * 256 + 512);
-  constexpr int DKV4_LDS = 3 * (2 * 64 * 256 + 512);     // version 4: three-stage ring
   constexpr int DKV5_LDS = 4 * (2 * 64 * 256 + 512);     // version 5: four-stage ring
   static bool attr_done = false;
   static int dkv_version = 5;        // round 4: version 5 (tools/gen_attn_dkv5.py); RV_ATTN_DKV=3 selects the round-2/3 kernel
@@ -2081,8 +1559,6 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   if (!attr_done) {
     hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
 #ifdef RV_ATTN_EXPERIMENTS
@@ -2093,12 +1569,10 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
     hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     { const char* a = getenv("RV_DKV_ABLATE"); if (a) dkv_ablate = atoi(a); }
 #endif
-    hipFuncSetAttribute((const void*)attn_bwd_dkv4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV4_LDS);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV4_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV5_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV5_LDS);
-    const char* e = getenv("RV_ATTN_DKV");        // A/B knob: 2 = the compiler-scheduled version-2 kernel, 3 / 4 / 5 = the hand-scheduled versions
-    if (e && atoi(e) >= 2 && atoi(e) <= 5) dkv_version = atoi(e);
+    const char* e = getenv("RV_ATTN_DKV");        // A/B knob: 3 = the round-2/3 kernel, 5 = the round-4 kernel (versions 2 and 4: history)
+    if (e && (atoi(e) == 3 || atoi(e) == 5)) dkv_version = atoi(e);
     attr_done = true;
   }
   // dQ: one workgroup per (query head, query block); dK/dV: per (KEY/VALUE head, key block), looping over its query heads
@@ -2109,11 +1583,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_HEAD, (const bf16_t*)O, ldo, lse, delta, BWD_TAIL(H));
     RV_CHECK_LAUNCH();
-    if (dkv_version == 2)
-      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
-    else if (dkv_version == 4)
-      hipLaunchKernelGGL((attn_bwd_dkv4_kernel<true>), grid_kv, block, DKV4_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
-    else if (dkv_version == 5)
+    if (dkv_version == 5)
       hipLaunchKernelGGL((attn_bwd_dkv5_kernel<true>), grid_kv, block, DKV5_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
 #ifdef RV_ATTN_EXPERIMENTS
 #define RV_ABL_LAUNCH(N) else if (dkv_ablate == N) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, N>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
@@ -2125,11 +1595,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   } else {
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<false>), grid, block, DQ_LDS, st, BWD_HEAD, (const bf16_t*)O, ldo, lse, delta, BWD_TAIL(H));
     RV_CHECK_LAUNCH();
-    if (dkv_version == 2)
-      hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
-    else if (dkv_version == 4)
-      hipLaunchKernelGGL((attn_bwd_dkv4_kernel<false>), grid_kv, block, DKV4_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
-    else if (dkv_version == 5)
+    if (dkv_version == 5)
       hipLaunchKernelGGL((attn_bwd_dkv5_kernel<false>), grid_kv, block, DKV5_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));
     else
       hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false>), grid_kv, block, DKV_LDS, st, BWD_HEAD, lse, (const float*)delta, BWD_TAIL(Hkv));

@@ -406,16 +406,37 @@ def test_lr_schedules_and_rejected_flags():
         LLaVA15DPOTrainer(model=_M(), args=TrainingArguments(gradient_accumulation_steps=0))
 
 
-def test_dkv3_isa_has_no_compiler_agpr_traffic():
-    """attn_bwd_dkv3_kernel addresses the accumulator file by hard register numbers (csrc/attn_agpr.inc).  That is only
-    sound while hipcc itself never touches AGPRs in that kernel (no spill-to-AGPR, no scratch): audit the generated ISA."""
+def test_dkv_isa_has_no_compiler_agpr_traffic():
+    """attn_bwd_dkv3_kernel / attn_bwd_dkv5_kernel address the accumulator file by hard register numbers (csrc/attn_agpr.inc).
+    That is only sound while hipcc itself never touches AGPRs in those kernels (no spill-to-AGPR, no scratch): audit the generated
+    ISA.  Version 5 additionally relies on counted lgkmcnt waits: no scalar memory load may sit inside its tile body."""
     import shutil
     import subprocess
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("hipcc not available")
     out = subprocess.run(["bash", os.path.join(REPO, "tools", "check_agpr_isa.sh")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-500:]
-    assert "instructions in dkv3: 0" in out.stdout
+    assert "instructions in dkv3: 0" in out.stdout and "instructions in dkv5: 0" in out.stdout
+    assert "SMEM loads inside the dkv5 tile body: 0" in out.stdout
+
+
+def test_dkv5_generated_bodies_are_current():
+    """csrc/attn_dkv5_*.inc are generated (tools/gen_attn_dkv5.py): the committed files must be what the generator emits."""
+    import subprocess
+    import sys
+    import tempfile
+    import shutil
+    csrc = os.path.join(REPO, "rlaif-v_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        keep = {n: open(os.path.join(csrc, n)).read() for n in os.listdir(csrc) if n.startswith("attn_dkv5_")}
+        try:
+            subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_attn_dkv5.py")], check=True, capture_output=True)
+            for n, txt in keep.items():
+                assert open(os.path.join(csrc, n)).read() == txt, f"{n} is stale: run python tools/gen_attn_dkv5.py"
+        finally:
+            for n, txt in keep.items():
+                open(os.path.join(csrc, n), "w").write(txt)
+    assert len(keep) == 3
 
 
 def test_omnilmm_splice_plan_matches_oracle_bit_exact():

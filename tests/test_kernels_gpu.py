@@ -438,8 +438,8 @@ def test_attn_gqa_fwd_bwd(ops, H, G, causal, L):
     assert torch.equal(ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, causal, 0, kc, vc, kv_group=G), dqkv)
 
 
-@pytest.mark.parametrize("G,use_pos,dkv", [(1, False, 3), (1, True, 3), (2, True, 3), (1, True, 2)])
-def test_attn_bwd_fused_inverse_rope(ops, G, use_pos, dkv, monkeypatch):
+@pytest.mark.parametrize("G,use_pos", [(1, False), (1, True), (2, True)])
+def test_attn_bwd_fused_inverse_rope(ops, G, use_pos):
     """rv_attn_bwd with rope tables writes dQ / dK already rotated back: identical (to bf16 rounding of the fp32 rotation)
     to the unfused rv_attn_bwd followed by rv_rope_inplace(backward); dV untouched.  Packed rows + position table + GQA."""
     dev = _dev()
@@ -454,7 +454,7 @@ def test_attn_bwd_fused_inverse_rope(ops, G, use_pos, dkv, monkeypatch):
     cos, sin = ops.rope_tables(512, hd, 10000.0, dev)
     pos = (torch.randint(0, 512, (S * L,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(dev)) if use_pos else None
     out, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, kc, vc, seg=(sh, e1), kv_group=G)
-    # RV_ATTN_DKV is read once per process: the version-2 dK/dV kernel is covered when the whole file runs with it set
+    # (RV_ATTN_DKV is read once per process: the round-2/3 dK/dV kernel is covered when the whole file runs with RV_ATTN_DKV=3)
     ref = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, True, 0, kc, vc, seg=(sh, e1), kv_group=G)
     ops.rope_inplace(ref, cos, sin, L, H + Hkv, hd, backward=True, pos=pos)
     got = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, True, 0, kc, vc, seg=(sh, e1), kv_group=G, rope=(cos, sin, pos))

@@ -1,7 +1,14 @@
 #!/bin/bash
-# Audit of the hard-register AGPR kernel: compiles attention.hip to ISA and lists every v_accvgpr_* that hipcc itself emitted
-# (outside ;;#ASMSTART .. ;;#ASMEND) inside attn_bwd_dkv3_kernel - there must be none (attn_agpr.inc).  Exit 1 otherwise.
+# Audit of the hard-register AGPR kernels: compiles attention.hip to ISA and lists every v_accvgpr_* / scratch_* that hipcc itself
+# emitted (outside ;;#ASMSTART .. ;;#ASMEND) inside attn_bwd_dkv3_kernel and attn_bwd_dkv5_kernel - there must be none
+# (attn_agpr.inc: the kernels address a[0:255] by number).  Also: s_load inside the tile body of version 5 would break its
+# counted lgkmcnt waits (SMEM shares the counter and returns out of order): none allowed between the first and the last MFMA.
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -I$R/rlaif-v_amd/csrc -S --cuda-device-only -o $T/attn.s $R/rlaif-v_amd/csrc/attention.hip 2>/dev/null || exit 2
-awk '/^_ZN12_GLOBAL__N_120attn_bwd_dkv3_kernel.*:$/{k=1} k&&/s_endpgm/{k=0} k&&/#ASMSTART/{a=1} k&&/#ASMEND/{a=0} k&&!a&&/v_accvgpr|scratch_/{print; bad++} END{print "compiler-emitted accvgpr/scratch instructions in dkv3:", bad+0; exit bad>0}' $T/attn.s
+rc=0
+for K in dkv3 dkv5; do
+  awk -v K=$K '$0 ~ "^_ZN12_GLOBAL__N_120attn_bwd_" K "_kernel.*:$"{k=1} k&&/s_endpgm/{k=0} k&&/#ASMSTART/{a=1} k&&/#ASMEND/{a=0} k&&!a&&/v_accvgpr|scratch_/{print; bad++} END{print "compiler-emitted accvgpr/scratch instructions in " K ":", bad+0; exit bad>0}' $T/attn.s || rc=1
+done
+awk '/^_ZN12_GLOBAL__N_120attn_bwd_dkv5_kernelILb1E.*:$/{k=1} k&&/s_endpgm/{k=0} k&&/v_mfma/{n++} k&&n>=1&&n<64&&/s_load_|s_buffer_load/{print; bad++} END{print "SMEM loads inside the dkv5 tile body:", bad+0; exit bad>0}' $T/attn.s || rc=1
+exit $rc

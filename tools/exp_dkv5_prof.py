@@ -1,5 +1,11 @@
-"""Phase profile of attn_bwd_dkv4_kernel from its s_memtime stamps (experiment builds -DRV_DKV4_PROF, tools/build_dkv4_ablations.py
---prof): ticks per tile and phase at the bench shape.  Usage: RV_ATTN_DKV=4 RV_HIP_LIB=.../librlaifv_hip_prof<n>.so python tools/exp_dkv4_prof.py"""
+"""Phase profile of attn_bwd_dkv5_kernel from its s_memtime stamps: ticks (shader clocks) per 64-query tile and phase at the bench
+shape, wave 0 of every workgroup.  Needs the experiment build -DRV_DKV5_PROF:
+
+    python tools/exp_dkv5_prof.py --build        (here: writes rlaif-v_amd/librlaifv_hip_prof5.so)
+    RV_HIP_LIB=$PWD/rlaif-v_amd/librlaifv_hip_prof5.so python tools/exp_dkv5_prof.py      (on the GPU box)
+
+(The same stamps on version 4 of the kernel and its ablation bodies - profiles/r04_attn_dkv4_*.log - are what version 5's schedule
+was derived from; that kernel and its generator live in history, commit 5e465f4.)"""
 import ctypes
 import math
 import os
@@ -7,7 +13,17 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+if "--build" in sys.argv:
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("b", os.path.join(REPO, "rlaif-v_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    os.environ["RV_BUILD_ONLY"] = "attention.hip"
+    b.build_extension()
+    print(b.build_extension(force=True, verbose=False, defines=("RV_DKV5_PROF",), tag="_prof5"))
+    sys.exit(0)
 from rlaif_v_amd import ops, hip  # noqa: E402
 
 BF = torch.bfloat16
@@ -20,12 +36,12 @@ seg = (torch.full((B,), shared, dtype=torch.int32, device=dev), torch.full((B,),
 o, lse = ops.attn_fwd(qkv, B, L, H, hd, True, 0, d, 2 * d, seg=seg)
 dqkv = torch.empty_like(qkv)
 lib = hip.lib().lib
-lib.rv_debug_dkv4_prof.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+lib.rv_debug_dkv5_prof.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 buf = (ctypes.c_ulonglong * 16)()
 for _ in range(3):
     ops.attn_bwd(qkv, o, do, lse, B, L, H, hd, True, 0, d, 2 * d, dqkv=dqkv, seg=seg)
 torch.cuda.synchronize()
-lib.rv_debug_dkv4_prof(buf)
+lib.rv_debug_dkv5_prof(buf)
 iters = 10
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
@@ -34,7 +50,7 @@ for _ in range(iters):
 e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / iters
-lib.rv_debug_dkv4_prof(buf)
+lib.rv_debug_dkv5_prof(buf)
 v = [int(x) for x in buf]
 # tiles a workgroup processes: sum over key blocks of (nt - t_begin)
 nkb = (L + 127) // 128
@@ -46,8 +62,8 @@ for kb in range(nkb):
     tiles += nt - kv0 // 64
 tiles_total = tiles * B * H
 wgs = v[15] / iters
-names = ["glue", "P1 S^T", "P2 dP^T+exp", "P3 dV_A dK_A", "P4 dV_B dK_B+DMA", "tile-end waits", "barrier", "pass prologue/epilogue",
-         "v5: loop-end vmcnt(0) + barrier", "v5: next pass issue (DMA, K/V loads)", "v5: read-out + stores", "v5: kernel prologue"]
+names = ["glue", "I  S^T_A dP^T_A (+DMA)", "II S^T_B dP^T_B (+exp A)", "III dV_A dK_A (+exp)", "IV dV_B dK_B (+next tile)", "wait for tile t+1", "barrier", "pass-end wait + barrier",
+         "loop-end vmcnt(0) + barrier", "next pass issue (DMA, K/V loads)", "read-out + stores", "kernel prologue"]
 tot = sum(v[:12])
 print(f"lib {os.environ.get('RV_HIP_LIB', 'default')}: dq + dkv {ms:.3f} ms; {wgs:.0f} workgroups, {tiles_total} tiles per launch, "
       f"{v[14] / v[15]:.0f} ticks per workgroup, stamped {tot / v[15]:.0f}")

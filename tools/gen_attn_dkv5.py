@@ -18,7 +18,9 @@ phases), 325 cycles of exposed LDS latency at the head of every tile, 530 of loo
     the barrier of tile t - 1, which is what guarantees that nobody still reads that buffer (tile t - 2);
   * transposed fragments are requested two groups (8 MFMAs) ahead.
 
-Counted waits as in gen_attn_dkv4.py.  Emits attn_dkv5_body.inc (a tile this wave computes), attn_dkv5_skip.inc (a tile that is
+Every LDS read is an explicit asm read and every wait a COUNTED s_waitcnt lgkmcnt(n): this script tracks the issue order of all
+reads of the tile and computes n for each use (LDS returns in order; the field is 4 bits: at most 15 younger reads may be in flight
+behind a read one waits for - asserted here).  Emits attn_dkv5_body.inc (a tile this wave computes), attn_dkv5_skip.inc (a tile that is
 invisible to this wave's 32 keys: DMA, barrier and the pre-loads only) and attn_dkv5_prefetch.inc (loop prologue).
 Usage: python tools/gen_attn_dkv5.py
 """
