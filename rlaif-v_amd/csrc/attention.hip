@@ -78,6 +78,21 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 #endif
 }
 
+// RV_ATTN_PROF (experiment builds): s_memtime stamps in the tile loops of the forward (slots 0..7) and dQ (slots 8..15) kernels,
+// accumulated per wave 0 of every workgroup into rv_attn_prof[]: +0 DMA issue, +1 first MFMA phase (S^T [and dP^T]),
+// +2 softmax / dS + second MFMA phase, +3 wait for the next tile's DMA, +4 barrier, +5 per-pass prologue / epilogue, +6 whole
+// kernel, +7 workgroups.  tools/exp_attn_prof.py reads them.  Each stamp drains lgkmcnt (s_memtime is an SMEM read).
+#ifdef RV_ATTN_PROF
+__device__ unsigned long long rv_attn_prof[16];
+#define APROF_DECL unsigned apr[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long apr_t0 = __builtin_amdgcn_s_memtime(); unsigned long long apr_last = apr_t0;
+#define APROF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); apr[i] += (unsigned)(t_ - apr_last); apr_last = t_; }
+#define APROF_END(base) if (threadIdx.x == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&rv_attn_prof[(base) + i_], (unsigned long long)apr[i_]); \
+    atomicAdd(&rv_attn_prof[(base) + 6], __builtin_amdgcn_s_memtime() - apr_t0); atomicAdd(&rv_attn_prof[(base) + 7], 1ull); }
+#else
+#define APROF_DECL
+#define APROF(i)
+#define APROF_END(base)
+#endif
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
@@ -316,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 
   int blk_first, blk_second;
   pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
+  APROF_DECL
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const int qb = (pass == 0) ? blk_first : blk_second;
@@ -352,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    APROF(5);
     for (int i = 0; i < nte; ++i) {
       const int t = i < skip_lo ? i : i + skip_n;
       const int k0 = t * 64;
@@ -362,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         dma.issue(kbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE, wave);
         dma.issue(vbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE + TILE, wave);
       }
+      APROF(0);
       if (!(CAUSAL && k0 > q0w + 31) && !(q0w >= e1 && k0 >= sh && k0 + 63 < e1)) {
         // S^T = K Q^T.  The K fragments are fetched in groups of four explicit ds_read_b128, group g+1 in flight while
         // group g multiplies (the compiler's own schedule was read / wait / MFMA sixteen times per tile).  Fragment ks of
@@ -396,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
         }
         // The tile needs element masks only when it touches the sequence end, the causal diagonal of this wave
         // or the chosen-branch window of a packed pair; interior tiles (the vast majority) skip ~200 VALU ops.
+        APROF(1);
         const bool need_mask = (k0 + 63 >= L) || (CAUSAL && k0 + 63 > q0w) ||
                                (q0w + 31 >= e1 && k0 + 63 >= sh && k0 < e1);
         if (need_mask) {
@@ -518,8 +537,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
       }
 #endif
       if (RV_ATTN_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+      APROF(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      APROF(3);
       __syncthreads();
+      APROF(4);
     }
 
     if (q < L) {
@@ -537,6 +559,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
       if (half == 0) lse[((long)s * H + h) * L + q] = (m_run + log2f(l_run)) * LN2;
     }
   }  // pass
+  APROF(5);
+  APROF_END(0)
 }
 
 // Inverse RoPE fused into the stores of dQ / dK (apply_rotary_pos_emb's autograd, HF modeling_llama: the half-split pairs
@@ -601,6 +625,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 
   int blk_first, blk_second;
   pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
+  APROF_DECL
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const int qb = (pass == 0) ? blk_first : blk_second;
@@ -660,6 +685,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    APROF(5);
     for (int i = 0; i < nte; ++i) {
       const int t = i < skip_lo ? i : i + skip_n;
       const int k0 = t * 64;
@@ -670,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
         dma.issue(kbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE, wave);
         dma.issue(vbase, ld, tok0, kn, L, smem + ((i + 1) & 1) * STAGE + TILE, wave);
       }
+      APROF(0);
       if (!(CAUSAL && k0 > q0w + 31) && !(q0w >= e1 && k0 >= sh && k0 + 63 < e1)) {
         const uint32_t ka0 = lds_addr_of(Ks) + boff[0];       // fragment ks: ka0 ^ (ks << 5); V tile = K tile + TILE
 #pragma unroll
@@ -735,8 +762,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
           }
         }
       }
+      APROF(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      APROF(3);
       __syncthreads();
+      APROF(4);
     }
 
     if (q < L) {
@@ -758,6 +788,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
       }
     }
   }  // pass
+  APROF(5);
+  APROF_END(8)
 }
 
 // =============================================================================================
@@ -1472,6 +1504,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
 
 extern "C" {
 
+#ifdef RV_ATTN_PROF
+// experiment builds only: read and clear the phase counters of the forward / dQ kernels (16 x u64)
+int rv_debug_attn_prof(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rv_attn_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(rv_attn_prof), z, sizeof(z)) != hipSuccess;
+}
+#endif
 #ifdef RV_DKV5_PROF
 // experiment builds only: read and clear the phase counters of attn_bwd_dkv5_kernel (16 x u64)
 int rv_debug_dkv5_prof(unsigned long long* out16) {
