@@ -495,7 +495,7 @@ def main():
         if not args.no_gemm_timer:
             g = timer.summary()
             traffic, traffic_file = None, None
-            for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # newest committed PMC passes first
+            for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # newest committed PMC passes first
                 try:   # HBM bytes per GEMM launch (profiles/, separate rocprofv3 --pmc runs of this same command)
                     with open(os.path.join(REPO, "profiles", name)) as fh:
                         traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
