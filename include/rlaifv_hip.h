@@ -29,6 +29,9 @@ int rv_abi_version(void);
  * (more flops per joule under the package power cap, profiles/r02_mfma_shape_power_probe.log); 0 = the 32x32x16 loops.
  * Same results to fp32 accumulation order. */
 int rv_set_gemm_mi16(int on);
+/* dK/dV kernel of rv_attn_bwd: 5 = the round-4 kernel (default), 3 = the round-2/3 kernel, 0 = back to the default / RV_ATTN_DKV.
+ * A/B and test knob (both kernels against each other in one process); replaces nothing in the reference. */
+int rv_set_attn_dkv_version(int version);
 /* GEMM kernel selection: -1 = auto (default), 0 = 128x128x64 register-staged, 1 = 128x128x64 global_load_lds,
  * 2 = 256x256x32 ping-pong (two wave groups alternating MFMA / load segments). */
 int rv_set_gemm_variant(int variant);

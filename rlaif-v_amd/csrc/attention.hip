@@ -1502,7 +1502,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
 
 }  // namespace
 
+static int g_dkv_override = 0;
+
 extern "C" {
+
+int rv_set_attn_dkv_version(int version) {
+  RV_REQUIRE(version == 0 || version == 3 || version == 5, "rv_set_attn_dkv_version: 0 (environment / default), 3 or 5");
+  g_dkv_override = version;
+  return 0;
+}
 
 #ifdef RV_ATTN_PROF
 // experiment builds only: read and clear the phase counters of the forward / dQ kernels (16 x u64)
@@ -1593,7 +1601,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   constexpr int DKV_LDS = 2 * (2 * 64 * 256 + 512);
   constexpr int DKV5_LDS = 4 * (2 * 64 * 256 + 512);     // version 5: four-stage ring
   static bool attr_done = false;
-  static int dkv_version = 5;        // round 4: version 5 (tools/gen_attn_dkv5.py); RV_ATTN_DKV=3 selects the round-2/3 kernel
+  static int dkv_env = 5;            // round 4: version 5 (tools/gen_attn_dkv5.py); RV_ATTN_DKV=3 selects the round-2/3 kernel
   static int dkv_ablate = 0;
   (void)dkv_ablate;
   if (!attr_done) {
@@ -1612,9 +1620,10 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
     hipFuncSetAttribute((const void*)attn_bwd_dkv5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV5_LDS);
     hipFuncSetAttribute((const void*)attn_bwd_dkv5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV5_LDS);
     const char* e = getenv("RV_ATTN_DKV");        // A/B knob: 3 = the round-2/3 kernel, 5 = the round-4 kernel (versions 2 and 4: history)
-    if (e && (atoi(e) == 3 || atoi(e) == 5)) dkv_version = atoi(e);
+    if (e && (atoi(e) == 3 || atoi(e) == 5)) dkv_env = atoi(e);
     attr_done = true;
   }
+  const int dkv_version = g_dkv_override ? g_dkv_override : dkv_env;      // rv_set_attn_dkv_version (tests: both kernels in one process)
   // dQ: one workgroup per (query head, query block); dK/dV: per (KEY/VALUE head, key block), looping over its query heads
   const int Hkv = H / kv_group;
   dim3 grid_kv(nxr * Hkv * S);

@@ -24,23 +24,20 @@ from .data import preference_collator_fn
 
 
 class InferenceSampler(torch.utils.data.sampler.Sampler):
+    """Contiguous shard of range(size) for this rank: the first size % world ranks get one more element (the reference's sampler,
+    muffin/eval/muffin_inference_logp.py:55-79)."""
+
     def __init__(self, size: int):
-        self._size = int(size)
         assert size > 0
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self._rank, self._world_size = torch.distributed.get_rank(), torch.distributed.get_world_size()
-        else:
-            self._rank, self._world_size = 0, 1
-        self._local_indices = self._get_local_indices(size, self._world_size, self._rank)
+        ddp = torch.distributed.is_available() and torch.distributed.is_initialized()
+        rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if ddp else (0, 1)
+        self._local_indices = self._get_local_indices(int(size), world, rank)
 
     @staticmethod
     def _get_local_indices(total_size, world_size, rank):
-        shard_size = total_size // world_size
-        left = total_size % world_size
-        shard_sizes = [shard_size + int(r < left) for r in range(world_size)]
-        begin = sum(shard_sizes[:rank])
-        end = min(sum(shard_sizes[:rank + 1]), total_size)
-        return range(begin, end)
+        q, r = divmod(total_size, world_size)
+        begin = rank * q + min(rank, r)
+        return range(begin, begin + q + (rank < r))
 
     def __iter__(self):
         yield from self._local_indices
@@ -82,7 +79,9 @@ def get_multimodal_sample_logps(model, dataloader, tokenizer=None, is_llava15: b
     lists, one entry per sample; per-token lists have spliced_length - 1 entries like the reference's."""
     if not is_llava15:
         raise NotImplementedError("only the LLaVA-1.5 branch is implemented")
-    out = {k: ([], [], []) for k in ("win", "rej")}
+    # results stay on the DEVICE while the loop runs (a few KB per row) and come back once at the end: a .tolist() per batch and
+    # branch stalls the stream 2 x 83 k times on the full RLAIF-V set
+    parts = {k: ([], [], []) for k in ("win", "rej")}
     model.eval()
     for batch in dataloader:
         for key in ("win", "rej"):
@@ -91,9 +90,15 @@ def get_multimodal_sample_logps(model, dataloader, tokenizer=None, is_llava15: b
             S = input_ids.shape[0]
             per_tok = res.per_token_logp.view(S, -1)
             assert per_tok.size(1) >= input_ids.size(1) - 1
-            out[key][0].extend(res.seq_logp.tolist())
-            out[key][1].extend((res.seq_logp / res.seq_cnt).tolist())
-            out[key][2].extend(per_tok.tolist())
+            parts[key][0].append(res.seq_logp.float().clone())
+            parts[key][1].append((res.seq_logp / res.seq_cnt).float())
+            parts[key][2].append(per_tok.float().clone())
+    out = {}
+    for key in ("win", "rej"):
+        logp = torch.cat(parts[key][0]).tolist() if parts[key][0] else []
+        avg = torch.cat(parts[key][1]).tolist() if parts[key][1] else []
+        per = [row for t in parts[key][2] for row in t.cpu().tolist()]
+        out[key] = (logp, avg, per)
     w, r = out["win"], out["rej"]
     return w[0], w[1], w[2], r[0], r[1], r[2]
 

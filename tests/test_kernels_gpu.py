@@ -745,3 +745,66 @@ def test_gemm_tn_tail_split(ops, R, I, J, monkeypatch):
     assert (a.float() - plain.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
     frac_same = (a == plain).float().mean().item()
     assert frac_same > 0.7, frac_same                       # tiles of the full rounds are bit-identical, the tail differs in fp32 order only
+
+
+def test_attn_bwd_dkv5_random_shapes_vs_dkv3_and_reference(ops):
+    """Round 4: the default dK/dV kernel (version 5: generated tile bodies, four-stage LDS ring, counted waits, read-out through
+    LDS) on a sweep of seeded random shapes - ragged lengths around the 64 / 128 tile edges, packed pair rows with arbitrary
+    (shared, chosen-end) bounds incl. empty branches, grouped-query heads, causal and full - against the round-2/3 kernel in the
+    SAME process (rv_set_attn_dkv_version) and against fp32 torch attention.  Also: every launch twice, bit-identical."""
+    from rlaif_v_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(20260926)
+    hd = 128
+    cases = [(1, 1, 1, 1, True, None), (2, 2, 1, 63, True, None), (1, 2, 2, 64, False, None), (2, 4, 2, 65, True, None),
+             (1, 2, 1, 127, True, None), (1, 2, 1, 129, False, None), (2, 2, 1, 191, True, None), (1, 6, 3, 320, True, None)]
+    for _ in range(10):
+        S = int(torch.randint(1, 4, (1,), generator=g))
+        G = int([1, 1, 2, 4][int(torch.randint(0, 4, (1,), generator=g))])
+        H = G * int(torch.randint(1, 3, (1,), generator=g))
+        L = int(torch.randint(2, 700, (1,), generator=g))
+        segs = []
+        for _s in range(S):
+            a = int(torch.randint(0, L, (1,), generator=g))
+            b = int(torch.randint(a, L + 1, (1,), generator=g))
+            segs.append((a, b))
+        cases.append((S, H, G, L, True, segs))
+    try:
+        for (S, H, G, L, causal, segs) in cases:
+            Hkv = H // G
+            width = (H + 2 * Hkv) * hd
+            kc, vc = H * hd, (H + Hkv) * hd
+            qkv = rnd(S * L, width, seed=L + 7 * H + S, dev=dev, scale=0.7)
+            do = rnd(S * L, H * hd, seed=L + 1, dev=dev)
+            seg = None
+            if segs is not None:
+                seg = (torch.tensor([a for a, _ in segs], dtype=torch.int32, device=dev),
+                       torch.tensor([b for _, b in segs], dtype=torch.int32, device=dev))
+            out, lse = ops.attn_fwd(qkv, S, L, H, hd, causal, 0, kc, vc, seg=seg, kv_group=G)
+            res = {}
+            for ver in (5, 3):
+                hip.call("rv_set_attn_dkv_version", ver)
+                a = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, causal, 0, kc, vc, seg=seg, kv_group=G)
+                b = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, causal, 0, kc, vc, seg=seg, kv_group=G)
+                assert torch.equal(a, b), f"dkv{ver} not deterministic: S{S} H{H} G{G} L{L} causal={causal} segs={segs}"
+                assert torch.isfinite(a.float()).all(), f"dkv{ver}: non-finite: S{S} H{H} G{G} L{L} segs={segs}"
+                res[ver] = a
+            # reference (fp32)
+            qf = qkv.float().requires_grad_(True)
+            q = qf[:, :kc].view(S, L, H, hd).transpose(1, 2)
+            k = qf[:, kc:vc].view(S, L, Hkv, hd).transpose(1, 2).repeat_interleave(G, dim=1)
+            v = qf[:, vc:].view(S, L, Hkv, hd).transpose(1, 2).repeat_interleave(G, dim=1)
+            if segs is not None:
+                mask = torch.stack([_packed_mask(L, a, b, dev) for a, b in segs])[:, None]
+            elif causal:
+                mask = torch.full((L, L), float("-inf"), device=dev).triu(1)[None, None]
+            else:
+                mask = torch.zeros(1, 1, L, L, device=dev)
+            ro = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd) + mask, -1) @ v
+            ro.transpose(1, 2).reshape(S * L, H * hd).backward(do.float())
+            what = f"S{S} H{H} G{G} L{L} causal={causal} segs={segs}"
+            for nm, sl in (("q", slice(0, kc)), ("k", slice(kc, vc)), ("v", slice(vc, width))):
+                close(res[5][:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"dkv5 d{nm} {what}")
+                close(res[5][:, sl], res[3][:, sl], rel=1.0e-2, what=f"dkv5 vs dkv3 d{nm} {what}")
+    finally:
+        hip.call("rv_set_attn_dkv_version", 0)
