@@ -198,7 +198,7 @@ def spawn_ranks(n: int) -> int:
     fewer than N GPUs - a line with n_gpus < N is never printed."""
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("RV_DIST_BACKEND") != "gloo":      # (gloo rehearsal: ranks may share a device; never a bench number)
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node; refusing to measure fewer ranks")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -251,6 +251,8 @@ def main():
     rank, local, world = init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if os.environ.get("RV_DIST_BACKEND") == "gloo":
+        local = local % torch.cuda.device_count()                      # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -42,12 +42,17 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
             os.environ.setdefault("NCCL_MAX_NCHANNELS", str(ch))
             os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(ch, 4)))
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  RV_DIST_BACKEND=gloo: rehearsal of the multi-rank code path on a box with fewer GPUs than
+            # ranks (gloo stages device tensors through the host; several ranks may then share one device - tests only)
+            backend = os.environ.get("RV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
+            dist.init_process_group(backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
