@@ -87,6 +87,16 @@ int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const
 int rv_gemm_nt_dropout_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             const void* residual, long ldr, float alpha, float p, int seed, void* stream);
 
+/* C = A B + dropout_{p,seed}(A2 B2) (+ residual) in ONE pass over C: the LoRA input gradient under adapter dropout
+ * (peft lora.Linear: result += lora_B(lora_A(dropout(x))) * scaling, so dx = dy W + mask * (dt A) / (1 - p); replaces
+ * rv_gemm_nn_bf16 followed by rv_gemm_nt_dropout_bf16 with C as its own residual - two more passes over [M][N]).  A [M][K],
+ * B [K][N], A2 = dt [M][K2], B2 = stacked lora_A [K2][N], all row-major; the adapter segment runs FIRST, the mask rv_dropout(p,
+ * seed) draws for a contiguous [M][N] tensor is applied to the fp32 accumulators, the main segment accumulates on top (one
+ * rounding to bf16 instead of two).  K % 64 == 0, K >= 512, K2 % 64 == 0, N % 8 == 0. */
+int rv_gemm_nn_lora_pre_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                             long ldb2, int K2, float p, int seed, void* C, long ldc, int M, int N, int K,
+                             const void* residual, long ldr, void* stream);
+
 /* Split-K form of rv_gemm_tn_bf16 for skinny outputs (LoRA weight gradients: I or J = r): `splits` chunks of the
  * contraction rows are reduced by separate workgroups into fp32 slabs (workspace: splits*I*J floats, caller owned)
  * which a second pass sums in a fixed order: C = bf16(alpha * sum).  Deterministic. */

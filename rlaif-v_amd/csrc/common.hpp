@@ -28,6 +28,11 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
+// logistic function with the hardware reciprocal (v_rcp_f32, 1 ulp) in place of the IEEE division sequence (v_div_scale x 2, 4 fma,
+// v_div_fmas, v_div_fixup: 10 VALU instructions per element - a third of the SwiGLU epilogues' VALU work); the results are rounded
+// to bf16 by every caller.  Shared by the fused GEMM epilogues and the stand-alone kernels so that both round identically.
+__device__ __forceinline__ float sigmoid_rcp(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

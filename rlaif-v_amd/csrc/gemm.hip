@@ -477,6 +477,43 @@ int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const
   return 0;
 }
 
+int rv_gemm_nn_lora_pre_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                             long ldb2, int K2, float p, int seed, void* C, long ldc, int M, int N, int K,
+                             const void* residual, long ldr, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  RV_REQUIRE(K >= 512 && K % 64 == 0 && K2 > 0 && K2 % 64 == 0,
+             "rv_gemm_nn_lora_pre_bf16: K must be a multiple of 64 and >= 512, K2 a positive multiple of 64");
+  RV_REQUIRE(N % 8 == 0 && N >= 8, "rv_gemm_nn_lora_pre_bf16: N must be a multiple of 8 (mask layout of rv_dropout)");
+  RV_REQUIRE(p >= 0.f && p < 1.f, "rv_gemm_nn_lora_pre_bf16: 0 <= p < 1");
+  RV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0),
+             "rv_gemm_nn_lora_pre_bf16: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
+  RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15) == 0,
+             "rv_gemm_nn_lora_pre_bf16: operands must be 16-byte aligned");
+  read_group_env();
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group,
+              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, 0, 0};
+  g.pre_thresh16 = (uint32_t)((double)p * 65536.0 + 0.5);
+  g.pre_key = (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu;
+  g.pre_inv_keep = 1.f / (1.f - p);
+  EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, 1.0f};
+  epi.narrow = epi_narrow();
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStore, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
+  if (nn_mi16())
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, false, true, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  else
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, false, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
 int rv_gemm_nt_dropout_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             const void* residual, long ldr, float alpha, float p, int seed, void* stream) {
   if (M == 0 || N == 0) return 0;

@@ -52,7 +52,29 @@ struct GemmShape {
   long lda2, ldb2;
   int K2, group_cols;
   int group0;
+  // Adapter-FIRST form (gemm_nn_a64_kernel<.., PRE = true>; the LoRA input gradient under adapter dropout):
+  //   D = dropmask(A2 B2) * pre_inv_keep + A B   - the K2 segment runs first, the mask of rv_dropout for a contiguous [M][N]
+  //   tensor (threshold / key as in EpiStore) is applied to the ACCUMULATORS, then the main segment accumulates on top.
+  uint32_t pre_thresh16 = 0, pre_key = 0;
+  float pre_inv_keep = 1.f;
 };
+
+__device__ __forceinline__ uint32_t gemm_mix32(uint32_t h) {    // same mixer as dropout_kernel (elementwise.hip)
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+
+// rv_dropout's keep decision for the 4 consecutive elements (m, n .. n+3), n % 4 == 0, of a contiguous [M][N] tensor (N % 8 == 0)
+__device__ __forceinline__ f32x4_t gemm_dropmask4(f32x4_t v, long m, int n, int N, uint32_t thresh16, uint32_t key, float inv_keep) {
+  const long e = m * N + n;
+  const uint32_t base = (uint32_t)(e >> 33) * 0x9e3779b9u + key;
+  const uint32_t h0 = gemm_mix32((uint32_t)(e >> 1) ^ base), h1 = gemm_mix32(((uint32_t)(e >> 1) + 1u) ^ base);
+  v.x = ((h0 & 0xffffu) >= thresh16) ? v.x * inv_keep : 0.f;
+  v.y = ((h0 >> 16) >= thresh16) ? v.y * inv_keep : 0.f;
+  v.z = ((h1 & 0xffffu) >= thresh16) ? v.z * inv_keep : 0.f;
+  v.w = ((h1 >> 16) >= thresh16) ? v.w * inv_keep : 0.f;
+  return v;
+}
 
 __device__ __forceinline__ int ext_group(int n0, int group0, int group_cols) {
   const int g0 = group0 > 0 ? group0 : group_cols;
@@ -1056,8 +1078,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_256_kernel(GemmShape g,
 // EXT: second contraction segment (A2 slices / B2 [K2][N], K2 % 64 == 0: the fused LoRA form).  The steady loop only
 // covers phases whose fetches lie in the main segment; the few phases around the seam and the adapter's own K2/32
 // phases run in the generic form (addresses rebuilt on the fly, full drain per phase).
-template <class Epi, bool EXT = false, bool MI16 = false>
+// PRE: adapter-FIRST form (GemmShape): the K2 segment (A2 [M][K2], B2 [K2][N]) runs before the main loop, 64 of K2 per step
+// through A stage 2 / B stages 2, 3 with all 8 waves in step (the main prologue - A stages 0, 1, B stages 0, 1 - is issued with
+// the last step and lands under it), the dropout mask is applied to the accumulators while the main prologue is in flight,
+// then the unchanged main loop accumulates on top.  Replaces a second pass over the [M][N] output (rv_gemm_nt_dropout_bf16 with
+// the output as its own residual: 2 x M x N x 2 B of HBM traffic per projection).
+template <class Epi, bool EXT = false, bool MI16 = false, bool PRE = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g, Epi epi) {
+  static_assert(!(EXT && PRE), "the adapter segment runs either first (PRE) or last (EXT)");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const smA = smem;
   uint8_t* const smB = smem + 3 * G4_A_STAGE;
@@ -1165,21 +1193,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
     if (EXT && t >= nt1) return g.B2 + ((long)(t - nt1) * G2_BK + r) * g.ldb2 + col;
     return g.B + ((long)t * G2_BK + r) * ldb + col;
   };
-  // prologue: A0 B0 | A1 B1 B2  (K >= 256 is required by the launcher, so these all lie in the main segment)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) issue_a(0, i, a_src[i]);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) issue_b(0, i, b_src[i]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) issue_a(1, i, a_src[i] + (ntA1 > 1 ? 64 : 0));
-#pragma unroll
-  for (int i = 0; i < 2; ++i) issue_b(1, i, b_src[i] + (long)G2_BK * ldb);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt1 > 2 ? 2 : 1) * G2_BK * ldb);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
-  if (RV_GEMM_PRIO_NN == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);     // wm is wave-uniform (readfirstlane)
 
   // running sources of the pieces issued in M-seg(p): A tile (p>>1)+2, B tile p+3 (clamped to the last tile at the end:
   // the redundant loads land in stages nobody reads any more)
@@ -1195,7 +1208,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) a_pre[ks] = a_row_off + (uint32_t)((((ks * 2 + half) ^ a_sw)) << 4);
 
-  // One phase.  MODE (compile time): 1 = steady (issues 2 A + 2 B pieces from the running pointers, counted wait),
+  // One phase.  MODE (compile time): 2 = adapter-first step (PRE: computes only, nothing is issued), 1 = steady (issues 2 A + 2 B pieces from the running pointers, counted wait),
   // 0 = generic (issues whatever tiles still exist - B tile p+3, with EXT also A tile (p>>1)+2 - and drains completely).  Only three instantiations exist (steady even, steady odd, tail): more copies of
   // the segment made hipcc spill the accumulators.
   auto phase = [&](const int p, const int h, auto hc, auto mode_c) {
@@ -1225,6 +1238,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
     if (MODE == 1) {
       if (p == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // prologue: only B tile 2 may still be in flight
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (MODE == 2) {
+      // adapter-first step: its tiles landed (and were published by a barrier) before the fragment reads above; nothing to wait for
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1244,7 +1259,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
             acc[MI16 ? 0 : tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tn], af[ks][tm], acc[MI16 ? 0 : tm][tn], 0, 0, 0);
           }
           const int k = MI16 ? (kk >> 1) : kk;                       // DMA slots: every 4th (MI16: 8th) MFMA
-          if ((k & 3) == RV_GEMM_DMA_SLOT && (!MI16 || (kk & 1) == 1)) {
+          if (MODE != 2 && (k & 3) == RV_GEMM_DMA_SLOT && (!MI16 || (kk & 1) == 1)) {
             const int j = k >> 2;                                  // 0: A, 1: B, 2: A, 3: B
             __builtin_amdgcn_sched_barrier(0);
             if (MODE == 1) {
@@ -1265,6 +1280,91 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  if constexpr (PRE) {
+    // ---- adapter-first segment (all 8 waves in step: the group skew starts after it)
+    const int nA2 = g.K2 >> 6;
+    for (int st2 = 0; st2 < nA2; ++st2) {
+      const bool last = st2 == nA2 - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int kc = (lane & 7) ^ ((row >> 1) & 7);
+        issue_a(2, i, g.A2 + (long)min(m0 + row, g.M - 1) * g.lda2 + (long)st2 * 64 + kc * 8);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = (wave * 2 + i) * 2 + (lane >> 5), c = lane & 31;
+          const int slot = MI16 ? ((c & 3) ^ (((r >> 3) & 1) << 1)) : (c & 3);
+          const int col = min(n0 + (((c >> 2) ^ (r & 3)) << 5) + (slot << 3), g.N - 8);
+          issue_b(2 + hh, i, g.B2 + ((long)st2 * 64 + hh * 32 + r) * g.ldb2 + col);
+        }
+      if (last) {                                   // main prologue, first part: A0 B0 | A1 B1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_a(0, i, a_src[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) issue_b(0, i, b_src[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_a(1, i, a_src[i] + (ntA1 > 1 ? 64 : 0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) issue_b(1, i, b_src[i] + (long)G2_BK * ldb);
+      }
+      // the step's 8 pieces per wave have landed (in the last step the 12 pieces of the main prologue stay in flight) and are
+      // visible to every wave BEFORE the phases read their fragments (a phase waits for the data of the NEXT one, not its own)
+      if (last) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      phase(10, 0, I0{}, I2{});                     // A stage (10 >> 1) % 3 = 2, B stage 10 % 4 = 2
+      phase(11, 1, I0{}, I2{});                     // A stage 2 (k half 1), B stage 3
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt1 > 2 ? 2 : 1) * G2_BK * ldb);    // main prologue: B2
+    // dropout mask on the adapter term (the main prologue is in flight)
+    if (g.pre_thresh16) {
+      if (MI16) {
+#pragma unroll
+        for (int tm = 0; tm < 8; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            acc16[MI16 ? tm : 0][tn] = gemm_dropmask4(acc16[MI16 ? tm : 0][tn], (long)m0 + wm * 128 + 16 * tm + (lane & 15),
+                                                      n0 + wn * 64 + 16 * tn + 4 * (lane >> 4), g.N, g.pre_thresh16, g.pre_key,
+                                                      g.pre_inv_keep);
+          }
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              f32x16_t& v = acc[MI16 ? 0 : tm][tn];
+              const f32x4_t o = gemm_dropmask4(f32x4_t{v[4 * rg], v[4 * rg + 1], v[4 * rg + 2], v[4 * rg + 3]},
+                                               (long)m0 + wm * 128 + 32 * tm + (lane & 31), n0 + wn * 64 + 32 * tn + 8 * rg + 4 * (lane >> 5),
+                                               g.N, g.pre_thresh16, g.pre_key, g.pre_inv_keep);
+              v[4 * rg] = o.x; v[4 * rg + 1] = o.y; v[4 * rg + 2] = o.z; v[4 * rg + 3] = o.w;
+            }
+      }
+    }
+  } else {
+    // prologue: A0 B0 | A1 B1 B2  (K >= 256 is required by the launcher, so these all lie in the main segment)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_a(0, i, a_src[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_b(0, i, b_src[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_a(1, i, a_src[i] + (ntA1 > 1 ? 64 : 0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_b(1, i, b_src[i] + (long)G2_BK * ldb);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_b(2, i, b_src[i] + (long)(nt1 > 2 ? 2 : 1) * G2_BK * ldb);
+  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+  if (RV_GEMM_PRIO_NN == 1 && wm == 1) __builtin_amdgcn_s_setprio(1);     // wm is wave-uniform (readfirstlane)
+
   // steady pairs: p + 4 < nt1 (A tile (p>>1)+2 and B tiles p+3, p+4 exist and lie in the main segment)
   int p = 0;
   for (; p + 4 < nt1; p += 2) {
@@ -1330,11 +1430,6 @@ __device__ __forceinline__ void epi_xhalf(float a, float b, int half, float& lo,
   lo = half ? recv : a;
   hi = half ? b : recv;
 #endif
-}
-
-__device__ __forceinline__ uint32_t gemm_mix32(uint32_t h) {    // same mixer as dropout_kernel (elementwise.hip)
-  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
-  return h;
 }
 
 struct EpiStore {
@@ -1504,7 +1599,7 @@ struct EpiSwiGLU {
           epi_unpack8(pk, r);
           float o[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = r[2 * j] / (1.f + __expf(-r[2 * j])) * r[2 * j + 1];
+          for (int j = 0; j < 4; ++j) o[j] = r[2 * j] * sigmoid_rcp(r[2 * j]) * r[2 * j + 1];
           uint2 w;
           w.x = pack2bf(o[0], o[1]);
           w.y = pack2bf(o[2], o[3]);
@@ -1561,7 +1656,7 @@ struct EpiSwiGLUBwd {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float gg = (j < 4) ? gu0[2 * j] : gu1[2 * (j - 4)], uu = (j < 4) ? gu0[2 * j + 1] : gu1[2 * (j - 4) + 1];
-            const float sg = 1.f / (1.f + __expf(-gg));
+            const float sg = sigmoid_rcp(gg);
             const float dg = da[j] * uu * sg * (1.f + gg * (1.f - sg)), du = da[j] * (gg * sg);
             if (j < 4) { o0[2 * j] = dg; o0[2 * j + 1] = du; } else { o1[2 * (j - 4)] = dg; o1[2 * (j - 4) + 1] = du; }
           }

@@ -641,9 +641,8 @@ class LlavaDPOModel:
             ops.gemm_nt(dy[:, c0:c0 + og], BT[:, c0:c0 + og], out=dt[:, g * rp:(g + 1) * rp], alpha=sc)
         if self.training and self.lora.lora_dropout > 0.0:
             # dropout sits on the adapter branch only: dx = dy W + mask * (dt A) / (1 - p)
-            dx = ops.linear(dy, st.pT(wkey), st.p(wkey))
-            ops.gemm_nt_dropout(dt, st.pT(akey), self.lora.lora_dropout, self._dropout_seed(i, drop_slot), out=dx,
-                                residual=dx)
+            dx = ops.lora_dgrad_dropout(dy, st.p(wkey), st.pT(wkey), dt, st.p(akey), st.pT(akey), self.lora.lora_dropout,
+                                        self._dropout_seed(i, drop_slot))
             # the dropped adapter input: kept from forward (288 GB HBM) or regenerated from the seed
             xin = xd if xd is not None else ops.dropout(xin, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
         else:

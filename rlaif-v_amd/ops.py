@@ -7,6 +7,7 @@ column slices of fused buffers (q/k/v inside qkv, gate/up inside gu) without cop
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -178,6 +179,28 @@ def gemm_nt_dropout(a: torch.Tensor, b: torch.Tensor, p: float, seed: int, out: 
     hip.call("rv_gemm_nt_dropout_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, K, residual,
              residual.stride(0) if residual is not None else 0, float(alpha), float(p), int(seed) & 0x7FFFFFFF)
     return out
+
+
+def lora_dgrad_dropout(dy: torch.Tensor, w: torch.Tensor, wT: torch.Tensor, dt: torch.Tensor, a: torch.Tensor, aT: torch.Tensor,
+                       p: float, seed: int) -> torch.Tensor:
+    """dx = dy @ w + dropmask_{p,seed}(dt @ a) / (1 - p): the LoRA input gradient under adapter dropout (w [out, in] frozen base
+    weight, wT its [in, out] copy, a = stacked lora_A [G r, in], aT its transpose).  One pass (rv_gemm_nn_lora_pre_bf16: adapter
+    segment first, mask on the accumulators) when the shape fits the 256-tile NN kernel and fills the chip, else the plain input
+    gradient followed by rv_gemm_nt_dropout_bf16 with dx as its own residual."""
+    _chk2d(dy, "dy"), _chk2d(w, "w"), _chk2d(dt, "dt"), _chk2d(a, "a")
+    M, K = dy.shape
+    K2, N = a.shape
+    if w.shape[0] != K or w.shape[1] < N or dt.shape != (M, K2):
+        raise ValueError(f"lora_dgrad_dropout: shape mismatch dy{tuple(dy.shape)} w{tuple(w.shape)} dt{tuple(dt.shape)} a{tuple(a.shape)}")
+    if (K % 64 == 0 and K >= 512 and K2 % 64 == 0 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 192
+            and os.environ.get("RV_LORA_DGRAD_PRE", "1") != "0"):
+        dx = torch.empty(M, N, dtype=BF16, device=dy.device)
+        hip.call("rv_gemm_nn_lora_pre_bf16", dy, dy.stride(0), w, w.stride(0), dt, dt.stride(0), a, a.stride(0), K2, float(p),
+                 int(seed) & 0x7FFFFFFF, dx, dx.stride(0), M, N, K, None, 0)
+        return dx
+    dx = linear(dy, wT, w)
+    gemm_nt_dropout(dt, aT, p, seed, out=dx, residual=dx)
+    return dx
 
 
 _SPLITK_WS = {}

@@ -232,6 +232,41 @@ def test_gemm_nt_dropout_epilogue(M, N, K):
     assert (got2.float() - (ref + res.float())).abs().max() <= 1.6e-2 * (ref + res.float()).abs().max()
 
 
+@pytest.mark.parametrize("M,N,K,K2,p", [(3000, 4096, 1024, 64, 0.05), (3333, 4096, 512, 192, 0.3), (6200, 2048, 1088, 128, 0.0),
+                                        (27664, 4096, 4096, 64, 0.05)])
+def test_lora_dgrad_dropout_one_pass(M, N, K, K2, p, monkeypatch):
+    """dx = dy W + mask * (dt A) / (1 - p) in ONE GEMM (rv_gemm_nn_lora_pre_bf16: adapter segment first, rv_dropout's mask on the
+    fp32 accumulators, main segment on top) against fp32 torch with the mask rv_dropout draws, and against the two-kernel path."""
+    _need_gpu()
+    from rlaif_v_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(M + K2)
+    dy = torch.randn(M, K, device="cuda:0", generator=g).to(torch.bfloat16)
+    w = (torch.randn(K, N, device="cuda:0", generator=g) * 0.03).to(torch.bfloat16)           # frozen base weight [out, in]
+    dt = torch.randn(M, K2, device="cuda:0", generator=g).to(torch.bfloat16)
+    a = (torch.randn(K2, N, device="cuda:0", generator=g) * 0.2).to(torch.bfloat16)           # stacked lora_A [G r, in]
+    wT, aT = w.t().contiguous(), a.t().contiguous()
+    seed = 4711
+    mask = (ops.dropout(torch.ones(M, N, dtype=torch.bfloat16, device="cuda:0"), p, seed) != 0) if p > 0 else None
+    lo = dt.float() @ a.float()
+    ref = dy.float() @ w.float() + (lo * mask / (1 - p) if mask is not None else lo)
+    monkeypatch.setenv("RV_LORA_DGRAD_PRE", "1")
+    got = ops.lora_dgrad_dropout(dy, w, wT, dt, a, aT, p, seed)
+    monkeypatch.setenv("RV_LORA_DGRAD_PRE", "0")
+    two = ops.lora_dgrad_dropout(dy, w, wT, dt, a, aT, p, seed)
+    scale = ref.abs().max()
+    e1, e2 = (got.float() - ref).abs().max() / scale, (two.float() - ref).abs().max() / scale
+    print(f"one pass: max err {e1:.2e} of the largest value, two kernels: {e2:.2e}")
+    assert e1 <= 6e-3 and e1 <= e2 * 1.05 + 1e-6                   # one rounding to bf16 instead of two
+    # the adapter term really is masked element for element: without the base term nothing survives where the mask is 0
+    monkeypatch.setenv("RV_LORA_DGRAD_PRE", "1")
+    if mask is not None:
+        zero_w = torch.zeros_like(w)
+        only = ops.lora_dgrad_dropout(dy, zero_w, zero_w.t().contiguous(), dt, a, aT, p, seed)
+        assert not bool((only[~mask] != 0).any())
+        assert (only.float() - lo * mask / (1 - p)).abs().max() <= 6e-3 * lo.abs().max()
+    assert torch.equal(ops.lora_dgrad_dropout(dy, w, wT, dt, a, aT, p, seed), got)            # deterministic
+
+
 def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch):
     """lora_dropout > 0: replay the device masks (regenerated from the model's seeds) inside the oracle."""
     _need_gpu()
