@@ -70,6 +70,9 @@ class GemmTimer:
         "gemm_nn_lora": ("nn_lora", lambda a, b, a2, b2, *r, **k: 2.0 * a.shape[0] * b.shape[1] * (a.shape[1] + b2.shape[0]),
                          lambda a, b, a2, b2, *r, **k: 2.0 * (a.numel() + b.numel() + b2.numel() + a.shape[0] * b2.shape[0]
                                                                + a.shape[0] * b.shape[1])),
+        "gemm_nn_lora_pre": ("nn_lora_pre", lambda a, b, a2, b2, *r, **k: 2.0 * a.shape[0] * b.shape[1] * (a.shape[1] + b2.shape[0]),
+                             lambda a, b, a2, b2, *r, **k: 2.0 * (a.numel() + b.numel() + b2.numel() + a2.numel()
+                                                                   + a.shape[0] * b.shape[1])),
         "gemm_nt_dropout": ("nt_dropout", lambda a, b, *r, **k: 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
                             lambda a, b, *r, **k: 2.0 * (a.numel() + b.numel() + 2 * a.shape[0] * b.shape[0])),
         # gate|up projection with SwiGLU in the epilogue: writes gu [M, 2f] and act [M, f]
@@ -509,6 +512,8 @@ def main():
                      "nt": "gemm_nt_256_kernel / gemm_nt_kernel (rv_gemm_nt_bf16)",
                      "nn_swiglu": "gemm_nn_a64_kernel<EpiSwiGLU> (rv_gemm_nn_swiglu_bf16)",
                      "nn_swiglu_bwd": "gemm_nn_a64_kernel<EpiSwiGLUBwd> (rv_gemm_nn_swiglu_bwd_bf16)",
+                     "nn_lora": "gemm_nn_a64_kernel<EpiStore, EXT> (rv_gemm_nn_lora_bf16)",
+                     "nn_lora_pre": "gemm_nn_a64_kernel<EpiStore, PRE> (rv_gemm_nn_lora_pre_bf16)",
                      "lmhead_fwd": "gemm_nt_256_kernel<EpiLogpFwd> (rv_lmhead_logp_fwd)",
                      "lmhead_bwd": "gemm_nt_256_kernel<EpiLogpBwd> (rv_lmhead_logp_bwd)"}
             by = {k: dict(kernel=KNAME.get(k, k), launches=d["launches"], avg_launch_ms=d["avg_ms"], ms_per_step=d["ms"] / args.steps,

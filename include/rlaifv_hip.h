@@ -212,6 +212,13 @@ int rv_gelu_bwd(const void* dy, const void* x, void* dx, long n, void* stream);
  * iff hash16(seed, e) >= p * 2^16 and scaled by 1/(1-p); the same (seed, n) regenerates the same mask in backward.
  * y = dropped x (may alias x, may be NULL); acc (optional) += dropped x (gradient accumulation).  Contiguous, n % 8 == 0. */
 int rv_dropout(const void* x, void* y, void* acc, long n, float p, int seed, void* stream);
+/* Producer-side forms: rv_rmsnorm_fwd / rv_swiglu_fwd (block layout) that ALSO write yd = rv_dropout(y; p, seed) as a contiguous
+ * [rows][d] / [rows][f] tensor, bit-identical to running rv_dropout on the output - the LoRA branch input of the projection that
+ * follows (q|k|v, gate|up after the norms; down after SwiGLU) without re-reading the activation. */
+int rv_rmsnorm_fwd_dropout(const void* x, long ldx, const int* row_idx, const void* w, void* y, long ldy, float* rstd,
+                           int rows, int d, float eps, void* yd, float p, int seed, void* stream);
+int rv_swiglu_fwd_dropout(const void* gu, long ldgu, void* act, long lda, long rows, int f, void* actd, float p, int seed,
+                          void* stream);
 
 /* ---- CLIP image preprocessing: CLIPImageProcessor of openai/clip-vit-large-patch14-336 as the reference applies it in
  * its DataLoader workers (muffin/train/train_llava15.py:244, muffin/train/train_utils.py:208) - PIL BICUBIC resize

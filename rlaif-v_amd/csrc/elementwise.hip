@@ -20,12 +20,35 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return v;
 }
 
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+// rv_dropout applied to one 16-byte chunk (8 bf16 values, chunk index i8 in the CONTIGUOUS tensor the mask is defined on): the
+// arithmetic of dropout_kernel, so a producer kernel can emit the dropped copy of its output bit-identically
+__device__ __forceinline__ uint4 dropout_chunk(const uint4 v, long i8, uint32_t thresh16, float inv_keep, uint32_t key) {
+  float f[8];
+  unpack8(v, f);
+  const uint32_t base = (uint32_t)(i8 >> 30) * 0x9e3779b9u + key;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t h = mix32(((uint32_t)i8 * 4u + (uint32_t)j) ^ base);
+    f[2 * j] = ((h & 0xffffu) >= thresh16) ? f[2 * j] * inv_keep : 0.f;
+    f[2 * j + 1] = ((h >> 16) >= thresh16) ? f[2 * j + 1] * inv_keep : 0.f;
+  }
+  return pack8(f);
+}
+
 // ------------------------------------------------------------------ RMSNorm
+// DROP: also writes yd = rv_dropout(y) (contiguous [rows][d], mask index r * d + c): the LoRA branch input of the projection that
+// follows, without a second pass over y
+template <bool DROP>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx,
                                                           const int* __restrict__ row_idx,
                                                           const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
                                                           long ldy, float* __restrict__ rstd_out, int rows, int d,
-                                                          float eps) {
+                                                          float eps, bf16_t* __restrict__ yd, uint32_t thresh16,
+                                                          float inv_keep, uint32_t key) {
   __shared__ float red[16];
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const bf16_t* xr = x + (long)(row_idx ? row_idx[r] : r) * ldx;
@@ -45,7 +68,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
       unpack8(*(const uint4*)(w + c), g);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = f[j] * rs * g[j];
-      *(uint4*)(y + (long)r * ldy + c) = pack8(f);
+      const uint4 pk = pack8(f);
+      *(uint4*)(y + (long)r * ldy + c) = pk;
+      if (DROP) *(uint4*)(yd + (long)r * d + c) = dropout_chunk(pk, ((long)r * d + c) >> 3, thresh16, inv_keep, key);
     }
   }
 }
@@ -345,9 +370,11 @@ __global__ void rope_kernel(bf16_t* __restrict__ x, long ld, const float* __rest
 // IL = 0: gu = [gate (f columns) | up (f columns)] per row;  IL = 1: interleaved (column 2j = gate_j, 2j+1 = up_j) - the
 // layout of the fused gate|up weight whose GEMM epilogue computes SwiGLU itself (EpiSwiGLU); this kernel then only serves the
 // recompute paths (activation checkpointing, RV_KEEP_RECOMPUTABLE=0).
-template <int IL>
+// DROP: also writes actd = rv_dropout(act) (contiguous [rows][f]) - the LoRA branch input of the down projection
+template <int IL, bool DROP = false>
 __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, long ldgu, bf16_t* __restrict__ act, long lda,
-                                  long rows, int f) {
+                                  long rows, int f, bf16_t* __restrict__ actd = nullptr, uint32_t thresh16 = 0,
+                                  float inv_keep = 1.f, uint32_t key = 0) {
   const int cpr = f >> 3;
   const long total = rows * cpr;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -366,7 +393,9 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, long ldgu, bf16
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = g[j] * sigmoid_rcp(g[j]) * u[j];
-    *(uint4*)(act + r * lda + c) = pack8(o);
+    const uint4 pk = pack8(o);
+    *(uint4*)(act + r * lda + c) = pk;
+    if (DROP) *(uint4*)(actd + r * f + c) = dropout_chunk(pk, i, thresh16, inv_keep, key);      // i = (r * f + c) / 8
   }
 }
 
@@ -413,10 +442,6 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, long ldd, con
 // ------------------------------------------------------------------ dropout on the LoRA branch (peft lora_dropout)
 // Counter-based mask: element e of a launch is kept iff its 16 hash bits (mix32 of the element-pair index and a seed-derived key) >= p * 2^16, so the backward
 // pass regenerates the identical mask from (seed, e) and nothing is stored.  y = keep ? x / (1 - p) : 0.
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
-  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
-  return h;
-}
 __global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ acc, long n8,
                                uint32_t thresh16, float inv_keep, uint32_t key) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -940,8 +965,20 @@ int rv_rmsnorm_fwd(const void* x, long ldx, const int* row_idx, const void* w, v
                    int rows, int d, float eps, void* stream) {
   RV_REQUIRE(d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "rv_rmsnorm_fwd: d/ld must be multiples of 8");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx,
-                     row_idx, (const bf16_t*)w, (bf16_t*)y, ldy, rstd, rows, d, eps);
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel<false>, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx,
+                     row_idx, (const bf16_t*)w, (bf16_t*)y, ldy, rstd, rows, d, eps, (bf16_t*)nullptr, 0u, 1.f, 0u);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_rmsnorm_fwd_dropout(const void* x, long ldx, const int* row_idx, const void* w, void* y, long ldy, float* rstd,
+                           int rows, int d, float eps, void* yd, float p, int seed, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "rv_rmsnorm_fwd_dropout: d/ld must be multiples of 8");
+  RV_REQUIRE(yd != nullptr && p >= 0.f && p < 1.f, "rv_rmsnorm_fwd_dropout: yd required, 0 <= p < 1");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx,
+                     row_idx, (const bf16_t*)w, (bf16_t*)y, ldy, rstd, rows, d, eps, (bf16_t*)yd,
+                     (uint32_t)((double)p * 65536.0 + 0.5), 1.f / (1.f - p), (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu);
   RV_CHECK_LAUNCH();
   return 0;
 }
@@ -1039,6 +1076,18 @@ int rv_swiglu_fwd(const void* gu, long ldgu, void* act, long lda, long rows, int
   else
     hipLaunchKernelGGL(swiglu_fwd_kernel<0>, dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
                        (const bf16_t*)gu, ldgu, (bf16_t*)act, lda, rows, f);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_swiglu_fwd_dropout(const void* gu, long ldgu, void* act, long lda, long rows, int f, void* actd, float p, int seed,
+                          void* stream) {
+  RV_REQUIRE(f % 8 == 0 && ldgu % 8 == 0 && lda % 8 == 0, "rv_swiglu_fwd_dropout: alignment");
+  RV_REQUIRE(actd != nullptr && p >= 0.f && p < 1.f, "rv_swiglu_fwd_dropout: actd required, 0 <= p < 1");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL((swiglu_fwd_kernel<0, true>), dim3(grid_for(rows * (f / 8), 256, 16384)), dim3(256), 0, STREAM(stream),
+                     (const bf16_t*)gu, ldgu, (bf16_t*)act, lda, rows, f, (bf16_t*)actd, (uint32_t)((double)p * 65536.0 + 0.5),
+                     1.f / (1.f - p), (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu);
   RV_CHECK_LAUNCH();
   return 0;
 }

@@ -602,21 +602,25 @@ class LlavaDPOModel:
         return (cfg.ffn, 0) if grp == "gu" else (0, 0)
 
     def _proj_fwd(self, x: torch.Tensor, i: int, grp: str, residual: Optional[torch.Tensor] = None,
-                  drop_slot: int = 0):
+                  drop_slot: int = 0, xd: Optional[torch.Tensor] = None):
         """y = x W^T (+ residual); with adapters  y = x W^T + t B^T,  t = (alpha/r) dropout(x) A^T  (peft
-        lora.Linear.forward) - the adapter term rides in the same K loop (rv_gemm_nt_lora_bf16).  Returns (y, t, xd)."""
+        lora.Linear.forward) - the adapter term rides in the same K loop (rv_gemm_nt_lora_bf16).  Returns (y, t, xd).
+        ``xd``: dropout(x) with this slot's seed when the kernel that produced x wrote it already (_lora_drop)."""
         st = self.store
         W = st.p(f"layers.{i}.w{grp}")
         if self.lora is None:
             return ops.linear(x, W, st.pT(f"layers.{i}.w{grp}"), residual=residual), None, None
-        xd = None
-        if self.training and self.lora.lora_dropout > 0.0:
+        if xd is None and self._lora_drop():
             xd = ops.dropout(x, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
         t = ops.gemm_nt(x if xd is None else xd, st.p(f"layers.{i}.lora_{grp}.A"), alpha=self.lora.scaling)
         gc, g0 = self._lora_grouping(grp)
         y = ops.linear_lora(x, W, st.pT(f"layers.{i}.w{grp}"), t, st.p(f"layers.{i}.lora_{grp}.B"),
                             st.pT(f"layers.{i}.lora_{grp}.B"), group_cols=gc, residual=residual, group0=g0)
         return y, t, (xd if self.keep_dropped_inputs else None)
+
+    def _lora_drop(self) -> bool:
+        """The adapter branch drops its input (peft lora_dropout, training mode only)."""
+        return self.lora is not None and self.training and self.lora.lora_dropout > 0.0
 
     def _dropout_seed(self, layer: int, slot: int) -> int:
         return (self._cur_drop_step * 1000003 + self.dropout_rank * 7919 + layer * 8 + slot) & 0x7FFFFFFF
@@ -659,19 +663,33 @@ class LlavaDPOModel:
         cfg, st = self.cfg, self.store
         d, H, hd = cfg.hidden, cfg.heads, cfg.head_dim
         S, L = plan.S, plan.L
-        xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
-        qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0)
+        # LoRA under adapter dropout: the kernels that produce a projection's input also write its dropped copy (one pass less over
+        # the activation per projection; the attention output keeps the stand-alone rv_dropout)
+        drop = self._lora_drop() and os.environ.get("RV_LORA_FUSED_DROPOUT", "1") != "0"
+        p_drop = self.lora.lora_dropout if drop else 0.0
+        xnd = xn2d = actd = None
+        if drop:
+            xn, rstd1, xnd = ops.rmsnorm_fwd_dropout(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps, p_drop, self._dropout_seed(i, 0))
+        else:
+            xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
+        qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0, xd=xnd)
         ops.rope_inplace(qkv, cos, sin, L, H + cfg.n_kv_heads, hd, pos=plan.pos)      # q heads then k heads
         attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, d + cfg.kv_dim, seg=plan.seg, kv_group=cfg.kv_group)
         x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
-        xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
+        if drop:
+            xn2, rstd2, xn2d = ops.rmsnorm_fwd_dropout(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps, p_drop, self._dropout_seed(i, 2))
+        else:
+            xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
         if st.interleave_gu:          # full fine-tune: SwiGLU in the epilogue of the gate|up GEMM (interleaved weight rows)
             gu, act = ops.linear_swiglu(xn2, st.pT(f"layers.{i}.wgu"))
             t_gu = xd_gu = None
         else:
-            gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2)
-            act = ops.swiglu_fwd(gu)
-        x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3)
+            gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2, xd=xn2d)
+            if drop:
+                act, actd = ops.swiglu_fwd_dropout(gu, p_drop, self._dropout_seed(i, 3))
+            else:
+                act = ops.swiglu_fwd(gu)
+        x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3, xd=actd)
         if not save:
             return x_next, None
         keep = self.keep_recomputable

@@ -194,13 +194,26 @@ def lora_dgrad_dropout(dy: torch.Tensor, w: torch.Tensor, wT: torch.Tensor, dt: 
         raise ValueError(f"lora_dgrad_dropout: shape mismatch dy{tuple(dy.shape)} w{tuple(w.shape)} dt{tuple(dt.shape)} a{tuple(a.shape)}")
     if (K % 64 == 0 and K >= 512 and K2 % 64 == 0 and N % 8 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 192
             and os.environ.get("RV_LORA_DGRAD_PRE", "1") != "0"):
-        dx = torch.empty(M, N, dtype=BF16, device=dy.device)
-        hip.call("rv_gemm_nn_lora_pre_bf16", dy, dy.stride(0), w, w.stride(0), dt, dt.stride(0), a, a.stride(0), K2, float(p),
-                 int(seed) & 0x7FFFFFFF, dx, dx.stride(0), M, N, K, None, 0)
-        return dx
+        return gemm_nn_lora_pre(dy, w[:, :N], dt, a, p, seed)
     dx = linear(dy, wT, w)
     gemm_nt_dropout(dt, aT, p, seed, out=dx, residual=dx)
     return dx
+
+
+def gemm_nn_lora_pre(a: torch.Tensor, b: torch.Tensor, a2: torch.Tensor, b2: torch.Tensor, p: float, seed: int,
+                     out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a @ b + dropmask_{p,seed}(a2 @ b2) / (1 - p) (+ residual); b [K, N], b2 [K2, N] row-major (rv_gemm_nn_lora_pre_bf16)."""
+    _chk2d(a, "a"), _chk2d(b, "b"), _chk2d(a2, "a2"), _chk2d(b2, "b2")
+    M, K = a.shape
+    K2, N = b2.shape
+    if b.shape != (K, N) or a2.shape != (M, K2):
+        raise ValueError(f"gemm_nn_lora_pre: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} a2{tuple(a2.shape)} b2{tuple(b2.shape)}")
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    _chk2d(out, "out")
+    hip.call("rv_gemm_nn_lora_pre_bf16", a, a.stride(0), b, b.stride(0), a2, a2.stride(0), b2, b2.stride(0), K2, float(p),
+             int(seed) & 0x7FFFFFFF, out, out.stride(0), M, N, K, residual, residual.stride(0) if residual is not None else 0)
+    return out
 
 
 _SPLITK_WS = {}
@@ -261,6 +274,19 @@ def rmsnorm_fwd(x, w, eps: float, row_idx: Optional[torch.Tensor] = None, out=No
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_rstd else None
     hip.call("rv_rmsnorm_fwd", x, x.stride(0), row_idx, w, out, out.stride(0), rstd, rows, d, float(eps))
     return out, rstd
+
+
+def rmsnorm_fwd_dropout(x, w, eps: float, p: float, seed: int, row_idx: Optional[torch.Tensor] = None, want_rstd: bool = True):
+    """(y, rstd, yd): rmsnorm_fwd plus yd = dropout(y, p, seed) written by the same kernel (rv_rmsnorm_fwd_dropout)."""
+    _chk2d(x, "x")
+    rows = x.shape[0] if row_idx is None else row_idx.numel()
+    d = x.shape[1]
+    out = torch.empty(rows, d, dtype=BF16, device=x.device)
+    outd = torch.empty(rows, d, dtype=BF16, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_rstd else None
+    hip.call("rv_rmsnorm_fwd_dropout", x, x.stride(0), row_idx, w, out, out.stride(0), rstd, rows, d, float(eps), outd, float(p),
+             int(seed) & 0x7FFFFFFF)
+    return out, rstd, outd
 
 
 def rmsnorm_bwd(dy, x, w, rstd, dw: torch.Tensor, dres: Optional[torch.Tensor] = None,
@@ -341,6 +367,17 @@ def swiglu_fwd(gu: torch.Tensor, out=None, interleaved: bool = False):
         out = torch.empty(rows, f, dtype=BF16, device=gu.device)
     hip.call("rv_swiglu_fwd", gu, gu.stride(0), out, out.stride(0), rows, f, int(interleaved))
     return out
+
+
+def swiglu_fwd_dropout(gu: torch.Tensor, p: float, seed: int):
+    """(act, actd): swiglu_fwd on the block layout plus actd = dropout(act, p, seed) from the same kernel (rv_swiglu_fwd_dropout)."""
+    _chk2d(gu, "gu")
+    rows, f2 = gu.shape
+    f = f2 // 2
+    out = torch.empty(rows, f, dtype=BF16, device=gu.device)
+    outd = torch.empty(rows, f, dtype=BF16, device=gu.device)
+    hip.call("rv_swiglu_fwd_dropout", gu, gu.stride(0), out, out.stride(0), rows, f, outd, float(p), int(seed) & 0x7FFFFFFF)
+    return out, outd
 
 
 def swiglu_bwd(dact, gu, out=None, interleaved: bool = False):

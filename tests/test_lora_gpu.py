@@ -212,6 +212,27 @@ def test_dropout_kernel_statistics():
     assert torch.equal(ops.dropout(x, 0.0, seed=1), x)
 
 
+@pytest.mark.parametrize("rows,d,f", [(777, 512, 384), (5000, 4096, 11008)])
+def test_producer_side_dropout_is_rv_dropout(rows, d, f):
+    """rv_rmsnorm_fwd_dropout / rv_swiglu_fwd_dropout: same primary outputs, and the dropped copy equals rv_dropout of them bit for bit."""
+    _need_gpu()
+    from rlaif_v_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(rows)
+    x = torch.randn(rows, d, device="cuda:0", generator=g).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(d, device="cuda:0", generator=g)).to(torch.bfloat16)
+    gu = torch.randn(rows, 2 * f, device="cuda:0", generator=g).to(torch.bfloat16)
+    for p, seed in ((0.05, 11), (0.5, 2**31 - 5)):
+        y, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
+        y2, rstd2, yd = ops.rmsnorm_fwd_dropout(x, w, 1e-5, p, seed)
+        assert torch.equal(y, y2) and torch.equal(rstd, rstd2)
+        assert torch.equal(yd, ops.dropout(y, p, seed))
+        act = ops.swiglu_fwd(gu)
+        act2, actd = ops.swiglu_fwd_dropout(gu, p, seed)
+        assert torch.equal(act, act2)
+        assert torch.equal(actd, ops.dropout(act, p, seed))
+        assert 0 < (yd == 0).float().mean() < 1 and 0 < (actd == 0).float().mean() < 1
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 512, 64), (26000, 4096, 192)])
 def test_gemm_nt_dropout_epilogue(M, N, K):
     """dx += mask * (dt A) / (1 - p) fused into the GEMM epilogue: the mask must be rv_dropout's, element for element."""
