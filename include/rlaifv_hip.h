@@ -92,10 +92,12 @@ int rv_gemm_nt_dropout_bf16(const void* A, long lda, const void* B, long ldb, vo
  * rv_gemm_nn_bf16 followed by rv_gemm_nt_dropout_bf16 with C as its own residual - two more passes over [M][N]).  A [M][K],
  * B [K][N], A2 = dt [M][K2], B2 = stacked lora_A [K2][N], all row-major; the adapter segment runs FIRST, the mask rv_dropout(p,
  * seed) draws for a contiguous [M][N] tensor is applied to the fp32 accumulators, the main segment accumulates on top (one
- * rounding to bf16 instead of two).  K % 64 == 0, K >= 512, K2 % 64 == 0, N % 8 == 0. */
+ * rounding to bf16 instead of two).  K % 64 == 0, K >= 512, K2 % 64 == 0, N % 8 == 0.  group_cols / group0 as in
+ * rv_gemm_nn_lora_bf16 (A2 then has one K2-wide column block per group); with p = 0 this is the adapter-first form of that
+ * function (the forward of a fused projection: one 64-deep adapter step per column tile instead of seam phases in the ring). */
 int rv_gemm_nn_lora_pre_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
-                             long ldb2, int K2, float p, int seed, void* C, long ldc, int M, int N, int K,
-                             const void* residual, long ldr, void* stream);
+                             long ldb2, int K2, int group_cols, int group0, float p, int seed, void* C, long ldc, int M, int N,
+                             int K, const void* residual, long ldr, void* stream);
 
 /* Split-K form of rv_gemm_tn_bf16 for skinny outputs (LoRA weight gradients: I or J = r): `splits` chunks of the
  * contraction rows are reduced by separate workgroups into fp32 slabs (workspace: splits*I*J floats, caller owned)

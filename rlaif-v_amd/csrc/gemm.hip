@@ -478,8 +478,8 @@ int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const
 }
 
 int rv_gemm_nn_lora_pre_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
-                             long ldb2, int K2, float p, int seed, void* C, long ldc, int M, int N, int K,
-                             const void* residual, long ldr, void* stream) {
+                             long ldb2, int K2, int group_cols, int group0, float p, int seed, void* C, long ldc, int M, int N,
+                             int K, const void* residual, long ldr, void* stream) {
   if (M == 0 || N == 0) return 0;
   RV_REQUIRE(K >= 512 && K % 64 == 0 && K2 > 0 && K2 % 64 == 0,
              "rv_gemm_nn_lora_pre_bf16: K must be a multiple of 64 and >= 512, K2 a positive multiple of 64");
@@ -489,9 +489,12 @@ int rv_gemm_nn_lora_pre_bf16(const void* A, long lda, const void* B, long ldb, c
              "rv_gemm_nn_lora_pre_bf16: leading dimensions must be multiples of 8 (inputs) / 4 (output)");
   RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15) == 0,
              "rv_gemm_nn_lora_pre_bf16: operands must be 16-byte aligned");
+  RV_REQUIRE(group_cols == 0 || (group_cols % G2_BN == 0 && group0 % G2_BN == 0 && group0 >= 0 && group0 <= N &&
+                                 (N - (group0 ? group0 : group_cols)) % group_cols == 0),
+             "rv_gemm_nn_lora_pre_bf16: group_cols / group0 must be multiples of 256 that tile N (group0 + k * group_cols = N)");
   read_group_env();
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group,
-              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, 0, 0};
+              (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, group_cols, group0};
   g.pre_thresh16 = (uint32_t)((double)p * 65536.0 + 0.5);
   g.pre_key = (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu;
   g.pre_inv_keep = 1.f / (1.f - p);

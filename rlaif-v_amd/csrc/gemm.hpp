@@ -1284,13 +1284,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   if constexpr (PRE) {
     // ---- adapter-first segment (all 8 waves in step: the group skew starts after it)
     const int nA2 = g.K2 >> 6;
+    const int pre_col0 = g.group_cols > 0 ? ext_group(n0, g.group0, g.group_cols) * g.K2 : 0;     // adapter group of this column tile
     for (int st2 = 0; st2 < nA2; ++st2) {
       const bool last = st2 == nA2 - 1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int kc = (lane & 7) ^ ((row >> 1) & 7);
-        issue_a(2, i, g.A2 + (long)min(m0 + row, g.M - 1) * g.lda2 + (long)st2 * 64 + kc * 8);
+        issue_a(2, i, g.A2 + (long)min(m0 + row, g.M - 1) * g.lda2 + pre_col0 + (long)st2 * 64 + kc * 8);
       }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)

@@ -288,6 +288,35 @@ def test_lora_dgrad_dropout_one_pass(M, N, K, K2, p, monkeypatch):
     assert torch.equal(ops.lora_dgrad_dropout(dy, w, wT, dt, a, aT, p, seed), got)            # deterministic
 
 
+@pytest.mark.parametrize("M,N,K,gc,g0", [(3100, 4096, 1024, 0, 0), (3100, 6144, 512, 2048, 0), (6200, 2560, 1024, 512, 1536)])
+def test_gemm_nn_lora_adapter_first_vs_adapter_last(M, N, K, gc, g0):
+    """The adapter-first form (rv_gemm_nn_lora_pre_bf16, p = 0) against the in-ring form (rv_gemm_nn_lora_bf16) and fp32 torch:
+    uniform groups, unequal groups (grouped-query attention: group0 != group_cols), no groups."""
+    _need_gpu()
+    from rlaif_v_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(N + gc)
+    G = ops._lora_groups(N, gc, g0)
+    a = torch.randn(M, K, device="cuda:0", generator=g).to(torch.bfloat16)
+    b = (torch.randn(K, N, device="cuda:0", generator=g) * 0.05).to(torch.bfloat16)
+    a2 = torch.randn(M, G * 64, device="cuda:0", generator=g).to(torch.bfloat16)
+    b2 = (torch.randn(64, N, device="cuda:0", generator=g) * 0.2).to(torch.bfloat16)
+    res = torch.randn(M, N, device="cuda:0", generator=g).to(torch.bfloat16)
+    first = ops.gemm_nn_lora_pre(a, b, a2, b2, residual=res, group_cols=gc, group0=g0)
+    last = ops.gemm_nn_lora(a, b, a2, b2, group_cols=gc, residual=res, group0=g0)
+    ref = a.float() @ b.float() + res.float()
+    edges = [0] + ([g0 or gc] if gc else [N])
+    while edges[-1] < N:
+        edges.append(edges[-1] + gc)
+    for gi in range(G):
+        c0, c1 = edges[gi], edges[gi + 1]
+        ref[:, c0:c1] += a2[:, gi * 64:(gi + 1) * 64].float() @ b2[:, c0:c1].float()
+    scale = ref.abs().max()
+    e_first, e_last = (first.float() - ref).abs().max() / scale, (last.float() - ref).abs().max() / scale
+    print(f"adapter first {e_first:.2e}, adapter last {e_last:.2e} of the largest value")
+    assert e_first <= 6e-3 and e_first <= 1.2 * e_last + 1e-6
+    assert (first != last).float().mean() < 0.02            # same products, another summation order: rare 1-ulp differences
+
+
 def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch):
     """lora_dropout > 0: replay the device masks (regenerated from the model's seeds) inside the oracle."""
     _need_gpu()
