@@ -303,6 +303,21 @@ int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
   if (check_shape(g, "rv_gemm_nt_bf16")) return 1;
   RV_REQUIRE(ldc % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "rv_gemm_nt_bf16: ldc/ldr must be multiples of 4");
+  // many rows, at most 256 columns, plain store: the streaming kernel (the rank-r side of LoRA; RV_GEMM_NT_SKINNY=0: A/B knob)
+  static int skinny = -1;
+  if (skinny < 0) { const char* e = getenv("RV_GEMM_NT_SKINNY"); skinny = e ? atoi(e) : 1; }
+  if (skinny && variant < 0 && g_default_variant < 0 && N % GSK_BN == 0 && N <= 256 && M >= 4096 && bias == nullptr &&
+      residual == nullptr && act == RV_ACT_NONE) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GSK_LDS_BYTES);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3(((M + GSK_BM - 1) / GSK_BM) * (N / GSK_BN)), dim3(256), GSK_LDS_BYTES,
+                       (hipStream_t)stream, g, (bf16_t*)C, ldc, alpha);
+    RV_CHECK_LAUNCH();
+    return 0;
+  }
   EpiStore epi{(bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, alpha};
   epi.narrow = epi_narrow();
   return dispatch(g, epi, variant, stream);

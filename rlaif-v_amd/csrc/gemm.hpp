@@ -219,6 +219,100 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmShape g, E
 }
 
 // =============================================================================================
+// Skinny NT GEMM: C[M][N] = alpha * A[M][K] B[N][K]^T for N <= 256 (a multiple of 64) and many rows - the rank-r side of LoRA
+// (t = dropout(x) A^T, dt = dy B: 29 k rows, N = 64 per adapter group, K = 4096 .. 22016).  These launches STREAM the activation
+// operand once (2 N flop per byte: HBM-bound for N = 64) and the 128x128 kernel above - one tile of prefetch, drained completely
+// every K step - left them at 1.1 - 1.8 x their streaming time (profiles/r04_lora_skinny_floor.log).  Here: 128 rows x 64 columns
+// per workgroup (4 waves, a 32 x 64 strip each), a THREE-stage LDS ring (16 KB of A + 8 KB of B per stage, 72 KB: two workgroups
+// per CU) filled two K tiles ahead by global_load_lds with a counted vmcnt(6), one barrier per 64-deep K tile.  Column blocks of
+// the same row block sit next to each other in launch order (same XCD): the activation tile comes from HBM once.
+// LDS image and swizzle as gemm_nt_kernel (128-byte rows, 16-byte chunk kc at kc ^ ((row >> 1) & 7)).
+// =============================================================================================
+#define GSK_BM 128
+#define GSK_BN 64
+#define GSK_STAGE (16384 + 8192)
+#define GSK_LDS_BYTES (3 * GSK_STAGE)
+__global__ __launch_bounds__(256, 2) void gemm_nt_skinny_kernel(GemmShape g, bf16_t* __restrict__ C, long ldc, float alpha) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = g.N / GSK_BN, tiles_m = (g.M + GSK_BM - 1) / GSK_BM;
+  const int id = xcd_remap(blockIdx.x, tiles_m * nb);
+  const int m0 = (id / nb) * GSK_BM, n0 = (id % nb) * GSK_BN;
+
+  // DMA pieces (8 rows x 128 B = 1 KB, lane l -> row l >> 3, chunk (l & 7) ^ swizzle): wave w owns A pieces 4w .. 4w+3 (rows 32 w ..)
+  // and B pieces 2w, 2w+1 (rows 16 w ..)
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + (lane >> 3);
+    b_src[i] = g.B + (long)(n0 + row) * g.ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+  auto issue = [&](int t, int stage) {
+    uint8_t* as = smem + stage * GSK_STAGE;
+    uint8_t* bs = as + 16384;
+    const long koff = (long)t * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(as + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(bs + (wave * 2 + i) * 1024), 16, 0, 0);
+  };
+
+  f32x16_t acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int nt = g.K / 64;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  issue(0, 0);
+  issue(min(1, nt - 1), 1);
+  for (int t = 0; t < nt; ++t) {
+    // tile t (issued two iterations ago) has landed for this wave: everything but the newest tile's 6 pieces
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // ... and for every wave; all waves are also done reading stage (t + 2) % 3 = (t - 1) % 3
+    issue(min(t + 2, nt - 1), (t + 2) % 3);                       // (clamped: redundant tail loads keep the count uniform)
+    const uint8_t* as = smem + (t % 3) * GSK_STAGE;
+    const uint8_t* bs = as + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kc = ks * 2 + fhalf;
+      const bf16x8_t af = *(const bf16x8_t*)(as + gemm_lds_off(wave * 32 + frow, kc));
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const bf16x8_t bfr = *(const bf16x8_t*)(bs + gemm_lds_off(tn * 32 + frow, kc));
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[tn], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the clamped tail loads still target this workgroup's LDS
+  // swapped operands: lane (frow, fhalf) holds row m = frow of the strip, columns 32 tn + 8 rg + 4 fhalf + j in register 4 rg + j
+  const int m = m0 + wave * 32 + frow;
+  if (m < g.M) {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        uint2 o;
+        o.x = pack2bf(acc[tn][rg * 4 + 0] * alpha, acc[tn][rg * 4 + 1] * alpha);
+        o.y = pack2bf(acc[tn][rg * 4 + 2] * alpha, acc[tn][rg * 4 + 3] * alpha);
+        *(uint2*)(C + (long)m * ldc + n0 + tn * 32 + rg * 8 + 4 * fhalf) = o;
+      }
+  }
+}
+
+// =============================================================================================
 // 256x256x32 "ping-pong" kernel for large GEMMs.
 //
 // 8 waves (2 M-halves x 4 N-quarters), per-wave output 128x64 = 4x2 MFMA tiles (128 accumulator VGPRs),

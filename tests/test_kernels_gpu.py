@@ -56,6 +56,31 @@ def test_gemm_nt(ops, variant, M, N, K):
     close(out, a.float() @ b.float().t(), what=f"gemm v{variant} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,lda_extra", [(4096, 64, 64, 0), (4100, 64, 128, 0), (29000, 64, 4096, 8192), (12345, 192, 1088, 64),
+                                             (29000, 128, 11008, 0), (5000, 256, 192, 0)])
+def test_gemm_nt_skinny(ops, M, N, K, lda_extra):
+    """Many rows, <= 256 columns, plain store: rv_gemm_nt_bf16 takes the streaming kernel (gemm_nt_skinny_kernel: 3-stage ring, counted
+    waits).  Against fp32 torch and, bit for bit, against the 128x128 kernel (explicit variant 1: same k order of the fp32 sums);
+    activations as a column slice of a wider tensor, ragged last row tile, output into a column slice."""
+    dev = _dev()
+    wide = rnd(M, K + lda_extra, seed=5, dev=dev)
+    a = wide[:, lda_extra // 2: lda_extra // 2 + K] if lda_extra else wide
+    assert a.data_ptr() % 16 == 0
+    b = rnd(N, K, seed=6, dev=dev, scale=0.1)
+    out_wide = torch.full((M, N + 64), 7.0, dtype=BF, device=dev)
+    got = ops.gemm_nt(a, b, out=out_wide[:, 32:32 + N], alpha=0.25)
+    old = ops.gemm_nt(a, b, alpha=0.25, variant=1)
+    close(got, 0.25 * (a.float() @ b.float().t()), what=f"skinny {M}x{N}x{K}")
+    assert torch.equal(got, old)
+    assert bool((out_wide[:, :32] == 7.0).all()) and bool((out_wide[:, 32 + N:] == 7.0).all())       # nothing outside the slice
+    # identity check of the tile / lane mapping: A rows = unit vectors
+    eye = torch.zeros(M, K, dtype=BF, device=dev)
+    idx = torch.arange(M, device=dev) % K
+    eye[torch.arange(M, device=dev), idx] = 1.0
+    b2 = (torch.arange(N * K, device=dev).reshape(N, K) % 251).to(BF)
+    assert torch.equal(ops.gemm_nt(eye, b2), b2.t()[idx].contiguous())
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_gemm_identity_asymmetric(ops, variant):
     """A = I with an asymmetric B catches transposed / permuted output tiles exactly."""

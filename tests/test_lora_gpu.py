@@ -288,6 +288,19 @@ def test_lora_dgrad_dropout_one_pass(M, N, K, K2, p, monkeypatch):
     assert torch.equal(ops.lora_dgrad_dropout(dy, w, wT, dt, a, aT, p, seed), got)            # deterministic
 
 
+def test_lora_dgrad_dropout_one_pass_32x32_mfma_loop():
+    """The same one-pass checks with the GEMM main loops on 32x32x16 MFMAs (RV_GEMM_MI16=0: read once per process, hence a child
+    process) - the adapter-first stage and its accumulator mask exist for both accumulator layouts."""
+    _need_gpu()
+    import subprocess
+    import sys
+    env = dict(os.environ, RV_GEMM_MI16="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                          "test_lora_dgrad_dropout_one_pass and not 32x32 and not 27664"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("M,N,K,gc,g0", [(3100, 4096, 1024, 0, 0), (3100, 6144, 512, 2048, 0), (6200, 2560, 1024, 512, 1536)])
 def test_gemm_nn_lora_adapter_first_vs_adapter_last(M, N, K, gc, g0):
     """The adapter-first form (rv_gemm_nn_lora_pre_bf16, p = 0) against the in-ring form (rv_gemm_nn_lora_bf16) and fp32 torch:
