@@ -258,9 +258,36 @@ static int check_shape(const GemmShape& g, const char* who) {
   return 0;
 }
 
+#ifdef RV_GEMM_H128
+// experiment builds only: RV_H128=1 routes the NN GEMMs (plain and SwiGLU epilogues) to the two-workgroups-per-CU 128 x 256 kernel
+static unsigned* g_h128_dbg = nullptr;
+extern "C" void rv_debug_h128_dbg(unsigned* p) { g_h128_dbg = p; }
+template <class Epi>
+static bool launch_nn_h128(const GemmShape& g, const Epi& epi, hipStream_t st) {
+  static int on = -1, stagger_per_phase = 0;
+  if (on < 0) {
+    const char* e = getenv("RV_H128"); on = e ? atoi(e) : 0;
+    const char* s2 = getenv("RV_H128_STAGGER"); stagger_per_phase = s2 ? atoi(s2) : 0;     // s_memtime ticks per 32-deep phase
+  }
+  if (!on || g.K % 64 != 0 || g.K < 128) return false;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nn_h128_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, H128_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles = ((g.M + 127) / 128) * ((g.N + G2_BN - 1) / G2_BN);
+  hipLaunchKernelGGL((gemm_nn_h128_kernel<Epi>), dim3(tiles), dim3(256), H128_LDS_BYTES, st, g, epi,
+                     stagger_per_phase * (g.K / G2_BK), g_h128_dbg);
+  return true;
+}
+#endif
+
 // NN GEMM with one of the SwiGLU epilogues: the 64-deep-A kernel when K allows, else the 32-deep one
 template <class Epi>
 static int launch_nn_epi(const GemmShape& g, const Epi& epi, hipStream_t st) {
+#ifdef RV_GEMM_H128
+  if (launch_nn_h128(g, epi, st)) { RV_CHECK_LAUNCH(); return 0; }
+#endif
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_nn_256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
@@ -410,6 +437,9 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
     attr_done = true;
   }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
+#ifdef RV_GEMM_H128
+  if (launch_nn_h128(g, epi, (hipStream_t)stream)) { RV_CHECK_LAUNCH(); return 0; }
+#endif
   if (use_a64 && K % 64 == 0 && K >= 512 && nn_mi16())
     hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStore, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
                        (hipStream_t)stream, g, epi);

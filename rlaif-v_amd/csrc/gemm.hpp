@@ -1486,6 +1486,169 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   }
 }
 
+#ifdef RV_GEMM_H128
+// =============================================================================================
+// EXPERIMENT (-DRV_GEMM_H128 builds only): the NN GEMM as TWO 4-wave workgroups per CU on 128 x 256 tiles, so
+// that one workgroup's epilogue (the gate|up load burst + stores of the fused SwiGLU forms) can run under the other's main loop.
+// Per workgroup 80 KiB of LDS: A 2 stages x 16 KiB (128 rows x 64 deep, the A64 image), B 3 stages x 16 KiB (32 k rows x 256).
+// A wave owns 128 x 64 of the tile (the A64 kernel's strip of wave group 0) and runs ONE barrier per 32-deep phase:
+//     wait (tile data of THIS phase: counted)  ->  barrier  ->  fragment reads  ->  32 MFMAs with the DMA issues between them
+// M-seg(p) issues B tile p+2 (4 pieces per wave) and, in even phases, A tile (p>>1)+1 (4 pieces).  Hazards:
+//   RAW: phase p needs B tile p (issued in M-seg(p-2)) and A tile p>>1 (issued in M-seg(p-2) for even p, M-seg(p-3) for odd p): all
+//        but the pieces of M-seg(p-1) have landed -> vmcnt(4) in even phases (M-seg(p-1) was odd: 4 pieces), vmcnt(8) in odd
+//        ones; prologue order A0 B0 B1: vmcnt(4) in phase 0 leaves B1 in flight.
+//   WAR: B stage (p+2)%3 = (p-1)%3 and A stage ((p>>1)+1)&1 = ((p>>1)-1)&1 were last read in L-seg(p-1), which every wave has
+//        behind it when it passes barrier(p).
+// The ping-pong of the 8-wave kernels (one wave group in its MFMA segment while the other reads fragments) is left to the
+// hardware here: the two workgroups of a CU are not synchronised.  `stagger`: workgroups of the first dispatch round whose LDS
+// allocation does not start at 0 (the second one on its CU) first sleep that many s_memtime ticks, so the pair starts half a
+// tile apart.
+// =============================================================================================
+#define H128_A_STAGE 16384
+#define H128_B_STAGE 16384
+#define H128_LDS_BYTES (2 * H128_A_STAGE + 3 * H128_B_STAGE)
+template <class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_nn_h128_kernel(GemmShape g, Epi epi, int stagger, unsigned* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const smA = smem;
+  uint8_t* const smB = smem + 2 * H128_A_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const unsigned lds_alloc = __builtin_amdgcn_s_getreg(6 | (31 << 11));        // HW_REG_LDS_ALLOC, all 32 bits
+  if (dbg && tid == 0) dbg[blockIdx.x] = lds_alloc;
+  if (stagger > 0 && (int)blockIdx.x < 2 * 256 && (lds_alloc & 0xfffu) != 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(32);
+  }
+
+  const int tiles_m = (g.M + 127) / 128, tiles_n = (g.N + G2_BN - 1) / G2_BN;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int GROUP = g.group > 0 ? 2 * g.group : 8;            // the same 1024-row clusters as the 256-row kernel's GROUP 4
+  const int group_size = GROUP * tiles_n;
+  const int first_m = (id / group_size) * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int tile_m = first_m + (id % group_size) % gsz;
+  const int tile_n = (id % group_size) / gsz;
+  const int m0 = tile_m * 128, n0 = tile_n * G2_BN;
+  const long ldb = g.ldb;
+
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wn * 4 + i) * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((row >> 1) & 7);
+    a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + kc * 8;
+    const int r = (wn * 4 + i) * 2 + (lane >> 5);
+    const int c = lane & 31;
+    const int slot = (c & 3) ^ (((r >> 3) & 1) << 1);
+    const int col = (((c >> 2) ^ (r & 3)) << 5) + (slot << 3);
+    b_src[i] = g.B + (long)r * ldb + min(n0 + col, g.N - 8);
+  }
+  const uint32_t piece0 = (uint32_t)(wn * 4) * 1024u;
+  auto issue_a = [&](int T, int i, const bf16_t* src) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smA + (T & 1) * H128_A_STAGE + piece0 + i * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int t, int i, const bf16_t* src) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smB + (t % 3) * H128_B_STAGE + piece0 + i * 1024), 16, 0, 0);
+  };
+
+  const int g4 = lane >> 4, s16 = lane & 15;
+  const uint32_t a16_pre = (uint32_t)(s16 * 128) + (uint32_t)((g4 ^ (s16 >> 1)) << 4);
+  uint32_t q16[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    q16[t] = (uint32_t)((8 * g4 + (s16 >> 2)) * 512) + (uint32_t)(((wn * 2 + (t >> 1)) ^ (s16 >> 2)) << 6) +
+             (uint32_t)((((t & 1) ^ (g4 & 1)) << 5) + 8 * (s16 & 3));
+
+  f32x4_t acc16[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = g.K / G2_BK;                    // 32-deep phases (even: K % 64 == 0)
+  const int ntA = nt >> 1;
+  // prologue: A0 B0 B1
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_a(0, i, a_src[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_b(0, i, b_src[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_b(1, i, b_src[i] + (long)G2_BK * ldb);
+
+  const bf16_t* a_run[4];
+  const bf16_t* b_run[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_run[i] = a_src[i] + (ntA > 1 ? 64 : 0);                       // A tile 1
+    b_run[i] = b_src[i] + (long)(nt > 2 ? 2 : 1) * G2_BK * ldb;      // B tile 2
+  }
+  auto phase = [&](const int p, auto hc) {
+    constexpr int H = decltype(hc)::value;                // = p & 1
+    if (H == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint8_t* stA = smA + ((p >> 1) & 1) * H128_A_STAGE;
+    const uint32_t stB = lds_addr_of(smB + (p % 3) * H128_B_STAGE);
+    const uint32_t hx = (uint32_t)H << 6;
+    bf16x8_t af[8], bfr[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bfr[t] = ds_tr16_pair_asm(stB + q16[t], 0, 2048);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) af[t] = *(const bf16x8_t*)(stA + (a16_pre ^ hx) + t * 2048);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      const int tm = kk >> 2, tn = kk & 3;
+      acc16[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[tm], acc16[tm][tn], 0, 0, 0);
+      if ((kk & 3) == 3) {                                // 8 DMA slots per phase: B pieces in slots 0..3, A pieces (even phases) in 4..7
+        const int j = kk >> 2;
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < 4) issue_b((p + 2), j, b_run[j]);
+        else if (H == 0) issue_a((p >> 1) + 1, j - 4, a_run[j - 4]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  for (int p = 0; p < nt; p += 2) {
+    // running sources of M-seg(p): B tile p+2, A tile (p>>1)+1; they stop at the last tile (redundant tail loads land in stages
+    // nobody reads any more)
+    phase(p, I0{});
+    if (p + 3 < nt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b_run[i] += (long)G2_BK * ldb;
+    }
+    if ((p >> 1) + 2 < ntA) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_run[i] += 64;
+    }
+    phase(p + 1, I1{});
+    if (p + 4 < nt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b_run[i] += (long)G2_BK * ldb;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tail loads still target this workgroup's LDS
+
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm) {
+    f32x16_t blk[2][2];
+    acc16_block_to_acc32(*reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[4 * hm]), blk, lane);
+    epi.apply(blk, m0 + hm * 64, n0 + wn * 64, lane, g.M, g.N);
+  }
+}
+#endif   // RV_GEMM_H128
+
 // ---------------------------------------------------------------------------------------------
 // Epilogues.  apply() receives the wave's 64x64 accumulators and its tile origin.
 // ---------------------------------------------------------------------------------------------
