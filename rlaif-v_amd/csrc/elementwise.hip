@@ -392,7 +392,7 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, long ldgu, bf16
       unpack8(*(const uint4*)(gu + r * ldgu + f + c), u);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = g[j] * sigmoid_rcp(g[j]) * u[j];
+    for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
     const uint4 pk = pack8(o);
     *(uint4*)(act + r * lda + c) = pk;
     if (DROP) *(uint4*)(actd + r * f + c) = dropout_chunk(pk, i, thresh16, inv_keep, key);      // i = (r * f + c) / 8
@@ -421,7 +421,7 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, long ldd, con
     unpack8(*(const uint4*)(dact + r * ldd + c), da);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float sg = sigmoid_rcp(g[j]);
+      const float sg = 1.f / (1.f + __expf(-g[j]));
       const float silu = g[j] * sg;
       dg[j] = da[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
       du[j] = da[j] * silu;

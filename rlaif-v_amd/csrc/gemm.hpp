@@ -1857,7 +1857,7 @@ struct EpiSwiGLU {
           epi_unpack8(pk, r);
           float o[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = r[2 * j] * sigmoid_rcp(r[2 * j]) * r[2 * j + 1];
+          for (int j = 0; j < 4; ++j) o[j] = r[2 * j] / (1.f + __expf(-r[2 * j])) * r[2 * j + 1];
           uint2 w;
           w.x = pack2bf(o[0], o[1]);
           w.y = pack2bf(o[2], o[3]);
@@ -1914,7 +1914,7 @@ struct EpiSwiGLUBwd {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float gg = (j < 4) ? gu0[2 * j] : gu1[2 * (j - 4)], uu = (j < 4) ? gu0[2 * j + 1] : gu1[2 * (j - 4) + 1];
-            const float sg = sigmoid_rcp(gg);
+            const float sg = 1.f / (1.f + __expf(-gg));
             const float dg = da[j] * uu * sg * (1.f + gg * (1.f - sg)), du = da[j] * (gg * sg);
             if (j < 4) { o0[2 * j] = dg; o0[2 * j + 1] = du; } else { o1[2 * (j - 4)] = dg; o1[2 * (j - 4) + 1] = du; }
           }
