@@ -298,6 +298,9 @@ struct TileDma {
 #define RV_ATTN_SMSPLIT 1      // softmax / dS slices computed under the MFMAs of the previous slice (round 3: forward -2.7 %)
 #endif
 #ifndef RV_ATTN_FWD_PRIO
+#ifndef RV_ATTN_DQ_PRIO
+#define RV_ATTN_DQ_PRIO 0      // 1 = s_setprio 1 in the dQ kernel's MFMA phases (experiment, round 4)
+#endif
 #define RV_ATTN_FWD_PRIO 1     // 1 = s_setprio 1 in the QK^T / PV MFMA phases (measured -0.5..-3 % vs 0, profiles/r02_attn_fwd_prio.log); 2 = in the softmax section (+1..2 %)
 #endif
 template <int HD, bool CAUSAL, int ABL = 0>
@@ -712,6 +715,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 #pragma unroll
             for (int j = 0; j < 2; ++j)
               fr3[p][j] = ds_read_b128_asm(ka0 ^ (uint32_t)(p << 5), j * TILE + kt * 32 * HD * 2);
+          if (RV_ATTN_DQ_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             if (ks + 2 < KS) {
@@ -728,6 +732,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr3[ks % 3][0], qf[ks], sacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr3[ks % 3][1], dof[ks], pacc, 0, 0, 0);
           }
+          if (RV_ATTN_DQ_PRIO == 1) __builtin_amdgcn_s_setprio(0);
           // K^T fragments of the first 16 keys: independent of dS, requested before the exp section (latency hidden)
           const uint32_t ks_addr = lds_addr_of(Ks);
           bf16x8_t kfr0[ET], kfr1[ET];
@@ -749,6 +754,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 #pragma unroll
             for (int e = 0; e < ET; ++e) kfr1[e] = tro.read(ks_addr, kt * 32 + 16, e);
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ET) : "memory");     // kfr0 landed; kfr1 may still be in flight
+            if (RV_ATTN_DQ_PRIO == 1) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < ET; ++e) dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr0[e], df, dq[e], 0, 0, 0);
@@ -759,6 +765,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < ET; ++e) dq[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr1[e], df, dq[e], 0, 0, 0);
+            if (RV_ATTN_DQ_PRIO == 1) __builtin_amdgcn_s_setprio(0);
           }
         }
       }
