@@ -638,6 +638,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
     QueryLaneMask<CAUSAL> qmask;
     qmask.init(q, L, sh, e1);
 
+    const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
+    const int nt = (kv_end + 63) / 64;
+    int skip_lo = nt, skip_n = 0;           // chosen-branch key tiles a rejected-branch query block never sees (see forward)
+    if (q0 >= e1 && e1 > sh) {
+      const int lo = (sh + 63) >> 6, hi = e1 >> 6;
+      if (hi > lo) { skip_lo = lo; skip_n = hi - lo; }
+    }
+    const int nte = nt - skip_n;
+    // the first K / V tile is requested BEFORE the row operands: the delta computation below waits for Q / dO / O, and the tile's
+    // latency used to start only after it (the ring is free: the previous pass ended on a barrier and its read-out does not use LDS)
+    dma.issue(kbase, ld, tok0, (skip_lo == 0 ? skip_n : 0) * 64, L, smem, wave);
+    dma.issue(vbase, ld, tok0, (skip_lo == 0 ? skip_n : 0) * 64, L, smem + TILE, wave);
+
     bf16x8_t qf[KS], dof[KS];
     {
       const bf16_t* qp = qkv + (tok0 + qc) * ld + q_col0 + h * HD + 8 * half;
@@ -675,16 +688,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
 #pragma unroll
     for (int e = 0; e < ET; ++e) zero16(dq[e]);
 
-    const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
-    const int nt = (kv_end + 63) / 64;
-    int skip_lo = nt, skip_n = 0;           // chosen-branch key tiles a rejected-branch query block never sees (see forward)
-    if (q0 >= e1 && e1 > sh) {
-      const int lo = (sh + 63) >> 6, hi = e1 >> 6;
-      if (hi > lo) { skip_lo = lo; skip_n = hi - lo; }
-    }
-    const int nte = nt - skip_n;
-    dma.issue(kbase, ld, tok0, (skip_lo == 0 ? skip_n : 0) * 64, L, smem, wave);
-    dma.issue(vbase, ld, tok0, (skip_lo == 0 ? skip_n : 0) * 64, L, smem + TILE, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
