@@ -334,7 +334,7 @@ int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   static int skinny = -1;
   if (skinny < 0) { const char* e = getenv("RV_GEMM_NT_SKINNY"); skinny = e ? atoi(e) : 1; }
   if (skinny && variant < 0 && g_default_variant < 0 && N % GSK_BN == 0 && N <= 256 && M >= 4096 && bias == nullptr &&
-      residual == nullptr && act == RV_ACT_NONE) {
+      residual == nullptr && act == RV_ACT_NONE && ((uintptr_t)C & 7) == 0) {
     static bool attr_done = false;
     if (!attr_done) {
       hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GSK_LDS_BYTES);
