@@ -328,6 +328,20 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
     sd = hip["per_token"] - fx["per_token"]
     m["per_token_mean_signed_err"], m["per_token_rms_err"] = float(sd.mean()), float(sd.pow(2).mean().sqrt())
     cond = "beta_z" in c
+    if not cond and "emu_per_token" in fx and lp.numel() % 2 == 0:
+        # saturated cases: the same sigma yardstick, LOGGED next to the 1e-3 loss bar (how many sigmas of independent per-token
+        # bf16 errors the error of each pair's policy log-ratio is; the loss is beta x that log-ratio wherever -log sigma is linear)
+        beta = float(fx.get("beta", 0.1))
+        B = lp.numel() // 2
+        n_pair = (mask[:B].sum(1) + mask[B:].sum(1)).float()
+        rms_emu = float((fx["emu_per_token"] - fx["per_token"]).pow(2).mean().sqrt())
+        dd = beta * ((lp[:B] - lp[B:]) - (lp_ref[:B] - lp_ref[B:]))
+        el = fx["emu_log_prob"].float()
+        de = beta * ((el[:B] - el[B:]) - (lp_ref[:B] - lp_ref[B:]))
+        m["logit_abs_err"], m["emu_bf16_logit_abs_err"] = dd.abs().tolist(), de.abs().tolist()
+        m["logit_err_in_sigmas"] = (dd.abs() / (beta * rms_emu * n_pair.sqrt())).tolist()
+        m["emu_bf16_logit_err_in_sigmas"] = (de.abs() / (beta * rms_emu * n_pair.sqrt())).tolist()
+        m["loss_one_sigma_rel"] = float(beta * rms_emu * n_pair.sqrt().mean() / (B ** 0.5) / abs(fx["loss"]))
     if cond:
         # the quantity DPO consumes: the logit beta*z = beta*((pw - pr) - (rw - rr)) per pair.  Its error is a SUM of n
         # per-token errors; with the bf16-emulated oracle's per-token RMS error as the yardstick an unbiased bf16
@@ -355,7 +369,10 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
         assert idx_ok, "token indexing differs from the oracle's spliced labels"
         assert m["seq_logp_max_rel_err"] <= 1e-3, m["seq_logp_max_rel_err"]
         if not cond:
-            assert m["loss_rel_err"] <= 1e-3, (m["loss"], m["loss_oracle"])
+            if "logit_err_in_sigmas" in m:       # the robust criterion first: a defect shows here, a re-roll of rounding noise does not
+                assert max(m["logit_err_in_sigmas"]) <= 3.0, (m["logit_abs_err"], m["logit_err_in_sigmas"])
+            assert m["loss_rel_err"] <= 1e-3, (m["loss"], m["loss_oracle"], "one sigma of bf16 rounding noise on this loss: %.1e relative"
+                                               % m.get("loss_one_sigma_rel", float("nan")))
         elif "emu_per_token" in fx:
             # conditioned regime: loss ~ ln 2, |d loss / d logit| <= 1: the loss error is bounded by the mean logit error
             assert max(m["logit_err_in_sigmas"]) <= 3.0, (m["logit_abs_err"], m["logit_err_bar_3sigma"])
