@@ -557,3 +557,45 @@ def test_full_depth_harness_compare_logic():
     bad = copy.deepcopy(hip); bad["post_samples"][names[0]] = w0[names[0]][FD.sample_index(names[0], 4096)] + lr * torch.sign(gs[names[0]])
     with pytest.raises(AssertionError):
         FD.compare("cfg1_step", bad, fx, W0=w0)
+
+
+def test_lora_and_skinny_dispatch_conditions(monkeypatch):
+    """Which C-ABI entry points the LoRA input gradient under adapter dropout takes for which shapes (no GPU: the launches are recorded,
+    not made): the one-pass adapter-first GEMM only when the 256-tile NN kernel can take the shape and the chip is filled, the plain
+    input gradient + rv_gemm_nt_dropout_bf16 otherwise or with RV_LORA_DGRAD_PRE=0; forward fused-LoRA projections stay on the in-ring
+    form unless RV_LORA_FWD_PRE=1."""
+    from rlaif_v_amd import hip, ops
+    calls = []
+    monkeypatch.setattr(hip, "call", lambda name, *a: calls.append(name))
+    monkeypatch.setattr(ops, "_chk2d", lambda t, name: None)            # the wrappers insist on CUDA tensors; here nothing is launched
+    bf = torch.bfloat16
+
+    def dgrad(M, K, N, K2):
+        calls.clear()
+        dy, w, dt, a = (torch.zeros(M, K, dtype=bf), torch.zeros(K, N, dtype=bf), torch.zeros(M, K2, dtype=bf), torch.zeros(K2, N, dtype=bf))
+        out = ops.lora_dgrad_dropout(dy, w, w.t().contiguous(), dt, a, a.t().contiguous(), 0.05, 7)
+        assert out.shape == (M, N)
+        return list(calls)
+    monkeypatch.delenv("RV_LORA_DGRAD_PRE", raising=False)
+    assert dgrad(3072, 512, 4096, 64) == ["rv_gemm_nn_lora_pre_bf16"]                   # 12 x 16 = 192 tiles: fills the chip
+    assert dgrad(3072, 512, 4096, 192) == ["rv_gemm_nn_lora_pre_bf16"]
+    two = dgrad(2816, 512, 4096, 64)                                                     # 11 x 16 tiles: too few
+    assert two[-1] == "rv_gemm_nt_dropout_bf16" and two[0] in ("rv_gemm_nn_bf16", "rv_gemm_nt_bf16") and len(two) == 2
+    assert dgrad(3072, 448, 4096, 64)[-1] == "rv_gemm_nt_dropout_bf16"                   # K < 512
+    assert dgrad(3072, 544, 4096, 64)[-1] == "rv_gemm_nt_dropout_bf16"                   # K % 64 != 0
+    assert dgrad(3072, 512, 4096, 96)[-1] == "rv_gemm_nt_dropout_bf16"                   # K2 % 64 != 0
+    monkeypatch.setenv("RV_LORA_DGRAD_PRE", "0")
+    assert dgrad(3072, 512, 4096, 64)[-1] == "rv_gemm_nt_dropout_bf16"
+    monkeypatch.delenv("RV_LORA_DGRAD_PRE")
+
+    def fwd(M, K, N, gc):
+        calls.clear()
+        G = N // gc if gc else 1
+        x, w, a2, b2 = (torch.zeros(M, K, dtype=bf), torch.zeros(N, K, dtype=bf), torch.zeros(M, 64 * G, dtype=bf), torch.zeros(N, 64, dtype=bf))
+        ops.linear_lora(x, w, w.t().contiguous(), a2, b2, b2.t().contiguous(), group_cols=gc)
+        return list(calls)
+    monkeypatch.delenv("RV_LORA_FWD_PRE", raising=False)
+    assert fwd(3072, 512, 4096, 2048) == ["rv_gemm_nn_lora_bf16"]
+    assert fwd(256, 512, 4096, 2048) == ["rv_gemm_nt_lora_bf16"]
+    monkeypatch.setenv("RV_LORA_FWD_PRE", "1")
+    assert fwd(3072, 512, 4096, 2048) == ["rv_gemm_nn_lora_pre_bf16"]
