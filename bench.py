@@ -134,10 +134,15 @@ class GemmTimer:
 
 
 def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
-    """The oracle (a port of the reference's step) timed on THIS box's host cores at BASELINE config 1's shape
-    (BASELINE.md section 2): 4 synthetic 336-px pairs, text length 512 -> spliced length 1087, fp32, one fwd + bwd + clip +
-    AdamW step at full 7B widths; bounded sample = depths 1 and 2 of the language model (CLIP at full depth), the per-layer
-    slope extrapolated linearly to 32 layers.  The reference's OWN functions, timed the same way in the build container
+    """The oracle (a port of the reference's step) at BASELINE config 1's shape: 4 synthetic 336-px
+    pairs, text length 512 -> spliced length 1087, fp32, one fwd + bwd + clip + AdamW step at full 7B widths.
+    TWO figures, kept apart by ``source``:
+      * ``live_extrapolated`` - timed on THIS box's host cores in THIS run: bounded sample = depths 1 and 2 of the language model
+        (CLIP at full depth), the per-layer slope extrapolated linearly to 32 layers; ``kind`` / ``host_cores`` / ``phases_s`` /
+        ``measured_s`` describe this box;
+      * ``full_depth_measured`` - the same step MEASURED once at all 32 layers on a GPU box's host (another machine of the same
+        pool; profiles/r03_parity_full_depth.json).  When that committed file is present ``value`` / ``cores`` quote IT and
+        ``source`` says so; when it is missing ``value`` is the live extrapolation, ``source`` says that, and stderr gets a line.  The reference's OWN functions, timed the same way in the build container
     (tools/cpu_reference_baseline.py -> profiles/r02_cpu_reference_baseline.json), ride along as ``reference_run``."""
     from oracle import dpo_oracle as O
     cores = os.cpu_count() or 1
@@ -171,11 +176,13 @@ def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
         out["full_depth_measured"] = dict(fd, unit="pairs/s", value=fd["pairs_per_s"], source="profiles/r03_parity_full_depth.json")
         out["value"] = fd["pairs_per_s"]
         out["cores"] = fd["threads"]
+        out["source"] = "full_depth_measured (committed profiles/r03_parity_full_depth.json: another box of the same pool, NOT this run)"
         out["sample"] = (f"oracle fp32 step, config 1 ({fd['pairs']} pairs, T=512, L=1087), ALL {fd['layers']} layers MEASURED on a GPU box's "
                          f"host ({fd['threads']} threads): {fd['step_s']:.0f} s (profiles/r03_parity_full_depth.json); this run's live "
                          f"bounded sample (depths 1,2 -> 32 layers by extrapolation): {step:.0f} s")
-    except Exception:
-        pass
+    except (OSError, KeyError, ValueError) as e:
+        out["source"] = "live_extrapolated (this run, this box)"
+        print(f"bench.py cpu_baseline: profiles/r03_parity_full_depth.json unusable ({e!r}); value = this run's extrapolation", file=sys.stderr)
     try:
         with open(os.path.join(REPO, "profiles", "r02_cpu_reference_baseline.json")) as fh:
             ref = json.load(fh)
@@ -254,8 +261,13 @@ def main():
     rank, local, world = init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
-    if os.environ.get("RV_DIST_BACKEND") == "gloo":
-        local = local % torch.cuda.device_count()                      # rehearsal on fewer GPUs than ranks
+    backend = os.environ.get("RV_DIST_BACKEND", "nccl")
+    devices_visible = torch.cuda.device_count()
+    # A REHEARSAL is any run whose ranks do not each own a GPU and talk RCCL: it exercises the N-rank code path and must never
+    # be read as a measurement: the line is tagged, its metric string suffixed and value / n_gpus are nulled below.
+    rehearsal = world > 1 and (backend != "nccl" or devices_visible < world)
+    if backend == "gloo":
+        local = local % devices_visible                                  # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -500,7 +512,11 @@ def main():
         if not args.no_gemm_timer:
             g = timer.summary()
             traffic, traffic_file = None, None
-            for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # newest committed PMC passes first
+            # the committed PMC passes were collected on THE HEADLINE CONFIG (full fine-tune, 32 layers, L = 2048, 8 pairs, one GPU):
+            # any other workload reports traffic = null instead of a constant that does not describe it
+            pmc_config_matches = (not args.lora and not args.omnilmm and args.layers == 32 and L == 2048 and B == 8
+                                  and not args.gradient_checkpointing)        # per GPU: weak scaling keeps it
+            for name in (() if not pmc_config_matches else ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")):   # newest committed PMC passes first
                 try:   # HBM bytes per GEMM launch (profiles/, separate rocprofv3 --pmc runs of this same command)
                     with open(os.path.join(REPO, "profiles", name)) as fh:
                         traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
@@ -526,9 +542,10 @@ def main():
                                           "backward, fused LM-head log-prob forward and backward, fused-LoRA forms): 256x256 ping-pong tiles",
                                 "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
-                                "traffic_note": "HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
-                                                f"WRITE_SIZE, separate passes (profiles/{traffic_file}); algorithmic "
-                                                "operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
+                                "traffic_note": (("HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
+                                                 f"WRITE_SIZE, separate passes (profiles/{traffic_file}); ") if traffic is not None else
+                                                 "null: no PMC pass was collected on this workload (the committed passes are the headline config's); ")
+                                                + "algorithmic operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
                                 "dominant": dict(by[dom], label=dom) if dom else None,
                                 "by_kernel": by,
                                 "power_capped_mfma_ceiling": {"tflops": 1953.0, "frac": g["tflops"] / 1953.0,
@@ -537,6 +554,12 @@ def main():
                                                                       "profiles/r02_mfma_shape_power_probe.log"},
                                 "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
                                 "gemm_ms_per_step": g["total_ms"] / args.steps}
+        line["backend"] = ("rccl" if backend == "nccl" else backend) if world > 1 else None
+        line["devices_used"] = min(world, devices_visible)
+        if rehearsal:
+            line.update(rehearsal=True, metric=line["metric"] + " [REHEARSAL - NOT A MEASUREMENT: ranks share a device and/or use gloo]",
+                        rehearsal_value=line["value"], rehearsal_ranks=world, value=None, n_gpus=None,
+                        step_tflops_per_gpu=None, step_mfma_frac=None)
         if dp_probe is not None:
             line["dp_standin_probe_1gpu"] = dp_probe
         if dp_diag is not None:

@@ -25,7 +25,11 @@ extern "C" {
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
-/* A/B and test knob: 1 (default, also RV_GEMM_MI16) = the NN-A64 / fused-LoRA NN / TN main loops issue 16x16x32 MFMAs
+/* ---- TEST-ONLY knobs (the three rv_set_* below).  They write process-global state without synchronisation: call them from ONE
+ * thread, with no launch of this library in flight on another thread, and never from production code - the product path
+ * (rlaif-v_amd/*.py) does not call them; tests use them to run two kernel generations against each other inside one process.
+ * Everything else in this library is stateless (per-call arguments only).
+ * A/B and test knob: 1 (default, also RV_GEMM_MI16) = the NN-A64 / fused-LoRA NN / TN main loops issue 16x16x32 MFMAs
  * (more flops per joule under the package power cap, profiles/r02_mfma_shape_power_probe.log); 0 = the 32x32x16 loops.
  * Same results to fp32 accumulation order. */
 int rv_set_gemm_mi16(int on);
@@ -174,6 +178,10 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
                 const void* O, long ldo, const float* lse, float* delta, void* dqkv, long lddq, int S, int L, int H,
                 int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
                 const float* rope_cos, const float* rope_sin, const int* rope_pos, void* stream);
+/* Number of fp32 elements rv_attn_bwd's `delta` workspace must hold for (S, H, L) under THIS library's ABI (3 * S * H * L since
+ * ABI 5).  Callers size the buffer with this query instead of hard-coding the plane count (the signature of rv_attn_bwd carries
+ * no size argument). */
+long rv_attn_bwd_workspace_floats(int S, int H, int L);
 int rv_attn_delta(const void* dO, long lddo, const void* O, long ldo, float* delta, int S, int L, int H, int hd,
                   void* stream);
 

@@ -379,7 +379,7 @@ def lora_linear(x: torch.Tensor, W: Dict[str, torch.Tensor], name: str, lora_sca
     y = F.linear(x, W[name + ".weight"])
     a = W.get(name + ".lora_A.weight") if lora_scale is not None else None
     if a is not None:
-        xa = x * masks[name].view_as(x) if masks is not None and name in masks else x
+        xa = (x * masks[name].view_as(x)).to(x.dtype) if masks is not None and name in masks else x    # (one rounding under bf16 emulation)
         y = y + lora_scale * F.linear(F.linear(xa, a), W[name + ".lora_B.weight"])
     return y
 
@@ -588,8 +588,9 @@ def preference_metrics(out: Dict[str, torch.Tensor], batch, task: str = "train")
 # --------------------------------------------------------------------------------------------
 
 def is_decay_param(name: str) -> bool:
-    """HF get_decay_parameter_names: no weight decay on norm gains and biases."""
-    return not (name.endswith("bias") or "norm" in name)
+    """HF get_decay_parameter_names: no weight decay on norm gains (parameters of LayerNorm / RMSNorm modules - the Llama
+    ``*norm`` gains and the OmniLMM Resampler's ``ln_q`` / ``ln_kv`` / ``ln_post``) and biases."""
+    return not (name.endswith("bias") or "norm" in name or ".ln_" in name)
 
 
 def trainable_names(cfg: LlavaCfg) -> List[str]:

@@ -93,7 +93,8 @@ def resampler_forward(x: torch.Tensor, W: Dict[str, torch.Tensor], num_heads: in
     nq, d = query.shape
     hd = d // num_heads
     pos_q = torch.from_numpy(get_2d_sincos_pos_embed(d, int(math.sqrt(nq)))).float()
-    pos_k = get_abs_pos(pos_q, N)
+    pos_k = get_abs_pos(pos_q, N).to(query.dtype)           # (dtype-generic: the bf16-emulated run keeps the tables in the model dtype,
+    pos_q = pos_q.to(query.dtype)                           #  resampler.py:143-149 adds them to bf16 activations under --bf16)
     xp = F.linear(x, W[RS + "kv_proj.weight"])
     xk = F.layer_norm(xp, (d,), W[RS + "ln_kv.weight"], W[RS + "ln_kv.bias"], eps)
     qn = F.layer_norm(query, (d,), W[RS + "ln_q.weight"], W[RS + "ln_q.bias"], eps)
@@ -162,7 +163,7 @@ def omnilmm_step_forward(batch: Dict[str, object], tower_features: torch.Tensor,
 
 
 def make_omnilmm_batch(cfg: O.LlavaCfg, n_pairs: int, text_len: int, num_query: int, tokens: Tuple[int, int, int],
-                       prompt_len: int = 8, seed: int = 0) -> Dict[str, torch.Tensor]:
+                       prompt_len: int = 8, seed: int = 0, answer_lens=None) -> Dict[str, torch.Tensor]:
     """Synthetic preference batch in the OmniLMM token convention: [bos, prompt.., <im_start>, <im_patch> x nq, <im_end>,
     question.., answer..]; chosen and rejected share everything up to the answer; ragged answer lengths, right padded with
     id 0 / label -100 (the collator's convention, muffin/train/train_muffin.py:43-112)."""
@@ -178,6 +179,9 @@ def make_omnilmm_batch(cfg: O.LlavaCfg, n_pairs: int, text_len: int, num_query: 
         n_ans = text_len - head.numel()
         la = n_ans - int(torch.randint(0, max(n_ans // 3, 1), (1,), generator=g))
         lb = n_ans - int(torch.randint(0, max(n_ans // 3, 1), (1,), generator=g))
+        if answer_lens is not None:       # explicit (chosen, rejected) answer lengths (the random draws above keep the stream aligned)
+            la, lb = answer_lens[b]
+            assert 1 <= la <= n_ans and 1 <= lb <= n_ans
         a = torch.randint(lo, hi, (la,), generator=g)
         r = torch.randint(lo, hi, (lb,), generator=g)
         for ans, ids_l, lab_l in ((a, wins, wl), (r, rejs, rl)):

@@ -1522,6 +1522,8 @@ int rv_set_attn_dkv_version(int version) {
   return 0;
 }
 
+long rv_attn_bwd_workspace_floats(int S, int H, int L) { return 3L * S * H * L; }
+
 #ifdef RV_ATTN_PROF
 // experiment builds only: read and clear the phase counters of the forward / dQ kernels (16 x u64)
 int rv_debug_attn_prof(unsigned long long* out16) {

@@ -137,8 +137,12 @@ class BucketedAllReduce(GradReducer):
         return done
 
     def collect_timeline(self) -> Optional[dict]:
-        """Host side of ``timeline`` (synchronises): per bucket MB, enqueue and completion in ms after the first bucket became
-        ready, and how long after the END of backward the last collective completed (the exposed communication)."""
+        """Host side of ``timeline`` (synchronises): per bucket MB, enqueue time and - in serial mode - completion time in ms after
+        the first bucket became ready, and how long after the END of backward the last collective completed (the exposed
+        communication).  In OVERLAP mode the per-bucket event is recorded on the compute stream inside finish(), i.e. after all
+        of backward has been enqueued: it says when the COMPUTE STREAM passed that bucket's wait, never earlier than
+        ``backward_end_ms``, and cannot show a bucket finishing under backward.  It is reported as
+        ``wait_passed_ms`` there; only ``exposed_after_backward_ms`` is a statement about the collectives themselves."""
         pend = getattr(self, "_timeline_pending", None)
         if pend is None:
             return None
@@ -146,11 +150,12 @@ class BucketedAllReduce(GradReducer):
         self._timeline_pending = None
         torch.cuda.synchronize()
         t0 = events[0][1]
-        rows = [dict(mb=round(nb / 2**20, 1), enqueue_ms=round(t0.elapsed_time(a), 3), done_ms=round(t0.elapsed_time(b), 3))
+        done_key = "done_ms" if self.mode == "serial" else "wait_passed_ms"
+        rows = [{"mb": round(nb / 2**20, 1), "enqueue_ms": round(t0.elapsed_time(a), 3), done_key: round(t0.elapsed_time(b), 3)}
                 for nb, a, b in events]
         bw_end = t0.elapsed_time(t_end)
         self.last_timeline = dict(mode=self.mode, buckets=rows, backward_end_ms=round(bw_end, 3),
-                                  exposed_after_backward_ms=round(max(rows[-1]["done_ms"] - bw_end, 0.0), 3),
+                                  exposed_after_backward_ms=round(max(rows[-1][done_key] - bw_end, 0.0), 3),
                                   total_mb=round(sum(r["mb"] for r in rows), 1))
         return self.last_timeline
 

@@ -23,7 +23,7 @@ def parse_header(path: str = _HEADER) -> Dict[str, Tuple[str, List[Tuple[str, st
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"(const char\*|int)\s+(rv_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const char\*|int|long)\s+(rv_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         parsed = []
         if args and args != "void":
@@ -52,7 +52,7 @@ class HipLib:
         self.decls = parse_header()
         for name, (ret, args) in self.decls.items():
             fn = getattr(self.lib, name)          # AttributeError = header/library drift, fail loudly
-            fn.restype = ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int
+            fn.restype = ctypes.c_char_p if ret.startswith("const char") else (ctypes.c_long if ret == "long" else ctypes.c_int)
             fn.argtypes = [_to_ctype(t) for t, _ in args]
         if self.lib.rv_abi_version() != 5:
             raise RuntimeError("librlaifv_hip.so ABI version mismatch")

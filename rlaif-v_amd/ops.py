@@ -472,7 +472,8 @@ def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv:
     _chk2d(qkv, "qkv"), _chk2d(o, "o"), _chk2d(do, "do")
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
-    delta = torch.empty(3, S, H, L, dtype=torch.float32, device=qkv.device)   # workspace: filled by the dQ kernel (delta, -delta, -lse / scale)
+    # workspace: filled by the dQ kernel (delta, -delta, -lse / scale); sized by the library's own query
+    delta = torch.empty(int(hip.lib().lib.rv_attn_bwd_workspace_floats(S, H, L)), dtype=torch.float32, device=qkv.device)
     hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, do, do.stride(0), o, o.stride(0), lse, delta,
              dqkv, dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None,
              seg[1] if seg else None, int(kv_group), rope[0] if rope else None, rope[1] if rope else None,

@@ -398,13 +398,15 @@ class LLaVA15DPOTrainer:
                 tot += nb * torch.cat([self._pending_metrics, loss.detach().reshape(1)])
                 cnt += nb
         finally:
+            # restored on EVERY exit (an exception in the loop or the empty-set error below must not leave an in-flight
+            # training step's state clobbered: ADVICE r4)
             self.model.train(was_training)
+            self.model.last_out, self.model.last_coef, self._pending_metrics, self._pending_task = saved
         # reduce_metrics returns the cross-rank MEAN: mean(sums) / mean(counts) = sum / count over all ranks
         red = self.reducer.reduce_metrics(torch.cat([tot, torch.tensor([float(cnt)], device=dev)]))
         if float(red[8]) <= 0:
             raise ValueError("evaluate(): empty evaluation set")
         mean = (red[:8] / red[8]).tolist()
-        self.model.last_out, self.model.last_coef, self._pending_metrics, self._pending_task = saved
         m = self._metrics_dict(mean[:7], "test")
         m["eval_loss"] = float(mean[7])
         self.log(m)

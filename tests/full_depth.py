@@ -44,15 +44,74 @@ CASES = {
     "cfg1_cond": dict(base="cfg1_step", beta_z=[-0.5, 0.0, 0.5, 1.0], lr=5e-7, step=True),
     "cfg2_step": dict(seed=43, pairs=2, text_len=2048 - 575, prompt_len=64, ragged=True, answer_lens=None, lr=5e-7, step=True),
     "cfg2_cond": dict(base="cfg2_step", beta_z=[0.0, 1.0], lr=5e-7, step=True),
+    # round 5: the two BASELINE configurations that had no full-depth, full-length parity.
+    # cfg5_* = config 5, RLAIF-V-7B LoRA-DPO: r = 64 / alpha 16 adapters on all seven decoder projections
+    # (muffin/train/train_llava15_lora.py:111-116, 304-318), spliced length L = 4096, all 32 layers, lr 1e-5
+    # (script/train/llava15_train_lora.sh:31).  cfg5_step: two pairs whose chosen answers are longer than the rejected ones
+    # (packed rows of 6,696 and 5,239 tokens; the saturated loss is beta x a difference of ~900 / ~1,700 nats, so one sigma of
+    # bf16 rounding noise sits at ~2e-4 of it and the 1e-3 bar has margin), adapter dropout OFF; cfg5_cond: the same batch in
+    # the regime training starts in; cfg5_drop: ONE pair with adapter dropout p = 0.05 - the masks the device draws
+    # (counter hash of (seed, index): oracle/dropout_mask.py restates it, pinned bit-exactly on the GPU) replayed in the
+    # oracle, reference row layout (the masks index [S L, in] rows), conditioned coefficients.
+    "cfg5_step": dict(kind="lora", seed=45, pairs=2, text_len=4096 - 575, prompt_len=64, ragged=False,
+                      answer_lens=[(3457, 2600), (3100, 1500)], lr=1e-5, step=True, max_len=4096, r=64, alpha=16, dropout=0.0,
+                      row_chunk=1),
+    "cfg5_cond": dict(base="cfg5_step", beta_z=[0.0, 1.0], lr=1e-5, step=True),
+    "cfg5_drop_base": dict(kind="lora", seed=46, pairs=1, text_len=4096 - 575, prompt_len=64, ragged=False,
+                           answer_lens=[(3457, 2000)], lr=1e-5, step=True, max_len=4096, r=64, alpha=16, dropout=0.05,
+                           row_chunk=1, share_prefix=False),
+    "cfg5_drop": dict(base="cfg5_drop_base", beta_z=[0.5], lr=1e-5, step=True),
+    # cfg4_* = config 4, OmniLMM-12B's trainable side: precomputed EVA02 tower tokens [B, 1024, 1792] -> Resampler (64 queries,
+    # omnilmm/model/resampler.py:96-168) -> replacement splice (omnilmm/model/omnilmm.py:221-257) -> Mistral-7B decoder (32
+    # layers, 32 query / 8 key-value heads, f 14336, V 32009) at L = 2048, forward_DPO (trainers.py:66-88), backward incl. the
+    # resampler's gradients, clip + AdamW.  The tower itself stays "parity unpinned" (timm absent).
+    "cfg4_step": dict(kind="omnilmm", seed=47, pairs=2, text_len=2048, ragged=False, answer_lens=[(1967, 1200), (1700, 800)],
+                      lr=5e-7, step=True, max_len=2048, row_chunk=2),
+    "cfg4_cond": dict(base="cfg4_step", beta_z=[0.0, 1.0], lr=5e-7, step=True),
 }
+OMNI = dict(hidden=4096, heads=32, kv_heads=8, ffn=14336, vocab=32009, num_query=64, vision_width=1792, tower_tokens=1024,
+            resampler_heads=32, tokens=(32000, 32001, 32002))
+
+
+def kind_of(case: str) -> str:
+    return CASES[base_case(case)].get("kind", "llava")
 
 
 def base_case(case: str) -> str:
     return CASES[case].get("base", case)
 
 
-def make_cfg(layers: int = 32) -> O.LlavaCfg:
-    return O.LlavaCfg(layers=layers, model_max_length=2048)
+def make_cfg(layers: int = 32, case: Optional[str] = None) -> O.LlavaCfg:
+    """The ORACLE's model configuration of ``case`` (None / configs 1-2: LLaVA-1.5-7B at model_max_length 2048)."""
+    if case is None or kind_of(case) == "llava":
+        return O.LlavaCfg(layers=layers, model_max_length=2048)
+    c = CASES[base_case(case)]
+    if kind_of(case) == "lora":
+        return O.LlavaCfg(layers=layers, model_max_length=c["max_len"])
+    return O.LlavaCfg(hidden=OMNI["hidden"], layers=layers, heads=OMNI["heads"], kv_heads=OMNI["kv_heads"], ffn=OMNI["ffn"],
+                      vocab=OMNI["vocab"], model_max_length=c["max_len"])
+
+
+def make_case_weights(case: str, cfg: O.LlavaCfg) -> Dict[str, torch.Tensor]:
+    """Seeded weights of ``case`` under HF / peft names (bf16-rounded fp32): configs 1-2 the LLaVA-1.5-7B set; config 5 the same
+    plus r = 64 adapters with a NON-zero lora_B (peft's zero init would make the adapter path invisible to parity);
+    config 4 the Mistral-shaped decoder + Resampler, no CLIP tower / projector."""
+    k = kind_of(case)
+    W = O.make_weights(cfg, seed=WEIGHT_SEED)
+    if k == "lora":
+        W.update(O.make_lora_weights(cfg, CASES[base_case(case)]["r"], seed=WEIGHT_SEED + 1, b_std=0.02))
+    elif k == "omnilmm":
+        from oracle import omnilmm_oracle as OO
+        W = {n: v for n, v in W.items() if "vision_tower" not in n and "mm_projector" not in n}
+        W.update(OO.make_resampler_weights(OMNI["hidden"], OMNI["vision_width"], OMNI["num_query"], seed=WEIGHT_SEED + 2))
+    return W
+
+
+def tower_tokens(case: str) -> torch.Tensor:
+    """config 4: the frozen tower's output for the B images, as PRECOMPUTED input (bf16-representable)."""
+    c = CASES[base_case(case)]
+    g = torch.Generator().manual_seed(c["seed"] + 1000)
+    return torch.randn(c["pairs"], OMNI["tower_tokens"], OMNI["vision_width"], generator=g).to(torch.bfloat16).float()
 
 
 def make_batch(case: str, cfg: O.LlavaCfg, fx: Optional[Dict[str, object]] = None):
@@ -62,6 +121,11 @@ def make_batch(case: str, cfg: O.LlavaCfg, fx: Optional[Dict[str, object]] = Non
         batch = make_batch(base_case(case), cfg)
         batch["ref_win_logp"], batch["ref_rej_logp"] = fx["ref_win_logp"].clone(), fx["ref_rej_logp"].clone()
         return batch
+    if c.get("kind") == "omnilmm":
+        from oracle import omnilmm_oracle as OO
+        lo_cfg = O.LlavaCfg(hidden=cfg.hidden, layers=1, heads=cfg.heads, kv_heads=cfg.n_kv_heads, ffn=cfg.ffn, vocab=32000)   # text ids < 32000
+        return OO.make_omnilmm_batch(lo_cfg, c["pairs"], c["text_len"], OMNI["num_query"], OMNI["tokens"], seed=c["seed"],
+                                     answer_lens=c["answer_lens"])
     return O.make_synthetic_batch(cfg, c["pairs"], c["text_len"], c["prompt_len"], seed=c["seed"], ragged=c["ragged"],
                                   answer_lens=c["answer_lens"])
 
@@ -141,14 +205,28 @@ def oracle_streamed(base: str, W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, cond
     from oracle import streamed as S
     c = CASES[base]
     batch = make_batch(base, cfg)
+    kind = c.get("kind", "llava")
+    skw: Dict[str, object] = dict(row_chunk=c.get("row_chunk"))
+    if kind == "lora":
+        skw["lora_scale"] = c["alpha"] / c["r"]
+        if c["dropout"] > 0:        # the masks the HIP model draws in its FIRST training forward on rank 0, one layer at a time
+            from oracle import dropout_mask as DM
+            S_rows = batch["concatenated_input_ids"].shape[0]
+            L_sp = batch["concatenated_input_ids"].shape[1] - 1 + cfg.n_patches
+            skw["lora_masks_fn"] = lambda i: DM.layer_masks(i, S_rows * L_sp, cfg.hidden, cfg.ffn, c["dropout"], step=1, rank=0)
+    make_front = None
+    if kind == "omnilmm":
+        tok = tower_tokens(base)
+        make_front = lambda b_, W_, t_=tok: S.OmniLMMFront(b_, t_.to(W_["model.embed_tokens.weight"].dtype), W_, OMNI["resampler_heads"], OMNI["tokens"])
     common: Dict[str, object] = dict(layers=cfg.layers, weight_seed=WEIGHT_SEED, torch=torch.__version__,
                                      threads=torch.get_num_threads(), oracle="oracle/streamed.py (layer-streamed)")
     if emu_from is not None:
         common.update({k: emu_from[k] for k in ("emu_per_token", "emu_log_prob", "emu_loss")})
     else:
         t0 = time.time()
-        bb, Wb = O.emulate_bf16(batch, W)
-        emu = S.dpo_step_streamed(bb, Wb, cfg, backward=False, log=lambda m: log(f"[{base}] bf16 emulation {m}"))
+        bb, Wb = O.emulate_bf16(batch, W) if kind != "omnilmm" else (dict(batch), {k: v.detach().to(torch.bfloat16) for k, v in W.items()})
+        emu = S.dpo_step_streamed(bb, Wb, cfg, backward=False, log=lambda m: log(f"[{base}] bf16 emulation {m}"),
+                                  front=make_front(bb, Wb) if make_front else None, **skw)
         e = _fwd_summary(emu)
         common.update(emu_per_token=e["per_token"], emu_log_prob=e["log_prob"], emu_loss=e["loss"], emu_s=time.time() - t0)
         del Wb, emu, bb
@@ -177,7 +255,8 @@ def oracle_streamed(base: str, W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, cond
         a["gsamp"][name] = g.flatten()[sample_index(name, g.numel())].float().clone()
 
     ph: Dict[str, float] = {}
-    res = S.dpo_step_streamed(batch, W, cfg, variants=variants, grad_sink=sink, timings=ph, log=lambda m: log(f"[{base}] {m}"))
+    res = S.dpo_step_streamed(batch, W, cfg, variants=variants, grad_sink=sink, timings=ph, log=lambda m: log(f"[{base}] {m}"),
+                              front=make_front(batch, W) if make_front else None, **skw)
     out = {}
     for v, cs in enumerate(cases):
         cc = CASES[cs]
@@ -206,12 +285,24 @@ def save_fixture(fx: Dict[str, object], path: str):
 
 
 # ------------------------------------------------------------------------------------------------ HIP side
-def build_model(cfg: O.LlavaCfg, W: Dict[str, torch.Tensor], with_optimizer: bool = True):
-    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+def build_model(cfg: O.LlavaCfg, W: Dict[str, torch.Tensor], with_optimizer: bool = True, case: Optional[str] = None):
+    """The HIP model + trainer of ``case`` (None / configs 1-2: LLaVA-1.5-7B full fine-tune) loaded with W."""
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel, LoraConfig
     from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
-    model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)), with_optimizer=with_optimizer)
+    kind = "llava" if case is None else kind_of(case)
+    c = CASES[base_case(case)] if case is not None else {}
+    if kind == "omnilmm":
+        from rlaif_v_amd.omnilmm import OmniLMMConfig, OmniLMMDPOModel
+        model = OmniLMMDPOModel(OmniLMMConfig(layers=cfg.layers, model_max_length=cfg.model_max_length), with_optimizer=with_optimizer)
+    elif kind == "lora":
+        model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)), with_optimizer=with_optimizer,
+                              lora=LoraConfig(r=c["r"], lora_alpha=c["alpha"], lora_dropout=c["dropout"]))
+    else:
+        model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)), with_optimizer=with_optimizer)
+    if "share_prefix" in c:
+        model.share_prefix = c["share_prefix"]
     model.load_state_dict(W)
-    return model, LLaVA15DPOTrainer(model=model, args=TrainingArguments())
+    return model, LLaVA15DPOTrainer(model=model, args=TrainingArguments(lora_enable=(kind == "lora"), learning_rate=c.get("lr") or 5e-7))
 
 
 def _trainable_views(model, flat: torch.Tensor):
@@ -223,6 +314,10 @@ def _trainable_views(model, flat: torch.Tensor):
         off, shp = st.offsets[key]
         off -= st.t0
         yield name, st.rows(flat[off:off + math.prod(shp)].view(*shp), r0, n, step)
+    for name, (key, r0, n, ncol) in st.lora_slices(cfg).items():           # peft adapter tensors (LoRA runs; empty otherwise)
+        off, shp = st.offsets[key]
+        off -= st.t0
+        yield name, flat[off:off + math.prod(shp)].view(*shp)[r0:r0 + n, :ncol]
 
 
 def _take(view: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
@@ -254,7 +349,11 @@ def hip_case(case: str, model, trainer, cfg: O.LlavaCfg, full_grads: bool = Fals
     Conditioned cases read their reference log-probs from the oracle fixture ``fx``."""
     c = CASES[case]
     batch = make_batch(case, cfg, fx)
+    if kind_of(case) == "omnilmm":
+        batch["images"] = tower_tokens(case)                  # precomputed tower tokens [B, 1024, 1792]
     model.train(c["step"])
+    if getattr(model, "lora", None) is not None:
+        model._dropout_step = 0                               # the fixture's masks are those of the FIRST training forward
     loss = trainer.compute_loss(model, dict(batch))
     out = model.last_out
     res: Dict[str, object] = dict(tgt=out.plan.tgt.cpu().long(), seq_cnt=out.seq_cnt.cpu(), log_prob=out.seq_logp.float().cpu(),

@@ -425,17 +425,13 @@ def test_dkv5_generated_bodies_are_current():
     import subprocess
     import sys
     import tempfile
-    import shutil
     csrc = os.path.join(REPO, "rlaif-v_amd", "csrc")
-    with tempfile.TemporaryDirectory() as td:
-        keep = {n: open(os.path.join(csrc, n)).read() for n in os.listdir(csrc) if n.startswith("attn_dkv5_")}
-        try:
-            subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_attn_dkv5.py")], check=True, capture_output=True)
-            for n, txt in keep.items():
-                assert open(os.path.join(csrc, n)).read() == txt, f"{n} is stale: run python tools/gen_attn_dkv5.py"
-        finally:
-            for n, txt in keep.items():
-                open(os.path.join(csrc, n), "w").write(txt)
+    keep = {n: open(os.path.join(csrc, n)).read() for n in os.listdir(csrc) if n.startswith("attn_dkv5_")}
+    with tempfile.TemporaryDirectory() as td:            # generated into a scratch directory: the tree is never touched
+        subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_attn_dkv5.py"), "--out", td], check=True, capture_output=True)
+        assert sorted(os.listdir(td)) == sorted(keep)
+        for n, txt in keep.items():
+            assert open(os.path.join(td, n)).read() == txt, f"{n} is stale: run python tools/gen_attn_dkv5.py"
     assert len(keep) == 3
 
 

@@ -46,3 +46,68 @@ def test_streamed_variants_share_one_forward():
         _, grads, _ = _run_full(b, W, cfg)
         for k, g in grads.items():
             assert torch.allclose(got[v][k], g, rtol=1e-4, atol=1e-6 * float(g.abs().max()) + 1e-12), (v, k)
+
+
+def test_streamed_row_chunks_equal_one_graph_step():
+    """rows evaluated one at a time (what the L = 4096 cases need to fit the container) == the one-graph step"""
+    cfg = O.tiny_cfg()
+    cfg.layers = 2
+    W = O.make_weights(cfg, seed=15)
+    batch = O.make_synthetic_batch(cfg, 2, 44, prompt_len=10, seed=19, image_pos=5)
+    out, grads, _ = _run_full(batch, W, cfg)
+    got = {}
+    res = S.dpo_step_streamed(batch, W, cfg, grad_sink=lambda v, n, g: got.__setitem__(n, g.clone()), row_chunk=1)
+    assert torch.allclose(res["log_prob"], out["log_prob"].detach(), rtol=1e-6, atol=1e-5)
+    assert torch.allclose(res["per_token_logps"], out["per_token_logps"].detach(), rtol=1e-5, atol=1e-5)
+    assert set(got) == set(grads)
+    for k, g in grads.items():
+        assert torch.allclose(got[k], g, rtol=1e-4, atol=1e-6 * float(g.abs().max()) + 1e-12), k
+
+
+def test_streamed_lora_with_replayed_masks_equals_one_graph_step():
+    """the adapter model (base frozen, adapters + projector trainable) with per-layer dropout masks handed in layer by layer"""
+    cfg = O.tiny_cfg()
+    cfg.layers = 3
+    W = O.make_weights(cfg, seed=7)
+    W.update(O.make_lora_weights(cfg, 8, seed=3))
+    batch = O.make_synthetic_batch(cfg, 2, 40, prompt_len=12, seed=4, image_pos=5)
+    Sx, L = 4, batch["concatenated_input_ids"].shape[1] - 1 + cfg.n_patches
+    g = torch.Generator().manual_seed(0)
+    dims = {"self_attn.q_proj": cfg.hidden, "self_attn.k_proj": cfg.hidden, "self_attn.v_proj": cfg.hidden, "self_attn.o_proj": cfg.hidden,
+            "mlp.gate_proj": cfg.hidden, "mlp.up_proj": cfg.hidden, "mlp.down_proj": cfg.ffn}
+    masks = {f"model.layers.{i}.{t}": (torch.rand(Sx, L, w, generator=g) >= 0.25).float() / 0.75
+             for i in range(cfg.layers) for t, w in dims.items()}
+    Wc = {k: v.clone() for k, v in W.items()}
+    out, grads, _ = O.dpo_train_step(batch, Wc, cfg, {}, lr=0.0, step=1, sft_weight=0.0, dpo_weight=1.0, lora_scale=0.5, lora_masks=masks)
+    got = {}
+    res = S.dpo_step_streamed(batch, W, cfg, grad_sink=lambda v, n, g: got.__setitem__(n, g.clone()), lora_scale=0.5, row_chunk=2,
+                              lora_masks_fn=lambda i: {k: v for k, v in masks.items() if k.startswith(f"model.layers.{i}.")})
+    assert torch.allclose(res["log_prob"], out["log_prob"].detach(), rtol=1e-6, atol=1e-5)
+    assert set(got) == set(grads) == set(O.lora_trainable_names(W))
+    for k, gr in grads.items():
+        assert torch.allclose(got[k], gr, rtol=1e-4, atol=1e-6 * float(gr.abs().max()) + 1e-12), k
+
+
+def test_streamed_omnilmm_front_equals_one_graph():
+    """OmniLMM front (Resampler + replacement splice, grouped-query decoder) == omnilmm_step_forward + autograd"""
+    from oracle import omnilmm_oracle as OO
+    cfg = O.tiny_gqa_cfg()
+    cfg.layers = 2
+    nq, kvd, heads_rs = 4, 24, 2
+    tokens = (cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1)
+    W = {k: v for k, v in O.make_weights(cfg, seed=21).items() if "vision_tower" not in k and "mm_projector" not in k}
+    W.update(OO.make_resampler_weights(cfg.hidden, kvd, nq, seed=2))
+    batch = OO.make_omnilmm_batch(cfg, 2, 36, nq, tokens, seed=8)
+    tok = torch.randn(2, 9, kvd, generator=torch.Generator().manual_seed(1))
+    Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    ref = OO.omnilmm_step_forward(batch, tok, Wg, cfg, heads_rs, tokens)
+    ref["loss"].backward()
+    got = {}
+    front = S.OmniLMMFront(batch, tok, W, heads_rs, tokens)
+    res = S.dpo_step_streamed(batch, W, cfg, grad_sink=lambda v, n, g: got.__setitem__(n, g.clone()), front=front, row_chunk=3)
+    assert torch.allclose(res["log_prob"], ref["log_prob"].detach(), rtol=1e-6, atol=1e-5)
+    assert abs(float(res["loss"]) - float(ref["loss"])) <= 1e-6 * abs(float(ref["loss"])) + 1e-7
+    assert set(got) == {k for k, v in Wg.items() if v.grad is not None}
+    for k in got:
+        gr = Wg[k].grad
+        assert torch.allclose(got[k], gr, rtol=1e-4, atol=1e-6 * float(gr.abs().max()) + 1e-12), k

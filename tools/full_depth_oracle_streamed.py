@@ -7,7 +7,13 @@ evaluation of the oracle (oracle/streamed.py - the oracle's own functions, chain
     --base cfg2   fulldepth_cfg2_step.pt, fulldepth_cfg2_cond.pt  (BASELINE config 2's packed shape, 2 pairs at L = 2048,
                   forward + backward + clip + AdamW; saturated and conditioned reference log-probs)
 
-Writes the fixtures to tests/golden/ and a log line per case to profiles/r04_oracle_streamed_<base>.json.
+    --base cfg5   fulldepth_cfg5_step.pt, fulldepth_cfg5_cond.pt  (round 5: BASELINE config 5, LoRA r = 64 at L = 4096, two pairs,
+                  adapter + projector gradients, clip + AdamW)
+    --base cfg5_drop  fulldepth_cfg5_drop.pt  (one pair at L = 4096, adapter dropout 0.05 with the device's masks replayed)
+    --base cfg4   fulldepth_cfg4_step.pt, fulldepth_cfg4_cond.pt  (round 5: BASELINE config 4's trainable side - Resampler +
+                  Mistral-7B-shaped decoder at L = 2048, forward_DPO + backward incl. resampler gradients)
+
+Writes the fixtures to tests/golden/ and a log line per case to profiles/r0N_oracle_streamed_<base>.json.
 Test infrastructure: imports oracle/ and tests/full_depth.py; nothing in the product path uses it.
 """
 import argparse
@@ -32,18 +38,19 @@ def log(*a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--base", choices=["cfg1", "cfg2"], required=True)
+    ap.add_argument("--base", choices=["cfg1", "cfg2", "cfg5", "cfg5_drop", "cfg4"], required=True)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--no-emulation", action="store_true")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
-    cfg = FD.make_cfg(args.layers)
+    base, cond = {"cfg1": ("cfg1_step", "cfg1_cond"), "cfg2": ("cfg2_step", "cfg2_cond"), "cfg5": ("cfg5_step", "cfg5_cond"),
+                  "cfg5_drop": ("cfg5_drop_base", "cfg5_drop"), "cfg4": ("cfg4_step", "cfg4_cond")}[args.base]
+    cfg = FD.make_cfg(args.layers, base)
     t0 = time.time()
-    W = O.make_weights(cfg, seed=FD.WEIGHT_SEED)
+    W = FD.make_case_weights(base, cfg)
     log(f"weights ({args.layers} layers): {time.time() - t0:.0f} s")
-    base, cond = ("cfg1_step", "cfg1_cond") if args.base == "cfg1" else ("cfg2_step", "cfg2_cond")
     report = dict(host=dict(cpus=os.cpu_count(), threads=args.threads, torch=torch.__version__), layers=args.layers)
     old = None
     emu_from = None
@@ -53,7 +60,7 @@ def main():
         emu_from = old
     if args.no_emulation and emu_from is None:
         emu_from = dict(emu_per_token=None, emu_log_prob=None, emu_loss=None)
-    fxs = FD.oracle_streamed(base, W, cfg, cond, emu_from=emu_from, log=log)
+    fxs = FD.oracle_streamed(base, W, cfg, cond, emu_from=emu_from, own_refs=(args.base != "cfg5_drop"), log=log)
     suffix = "" if args.layers == 32 else f"_l{args.layers}"
     os.makedirs(args.out, exist_ok=True)
     for cs, fx in fxs.items():
@@ -75,7 +82,7 @@ def main():
                           clip_coef=fx["clip_coef"], timings=fx["timings"], beta_z=fx.get("beta_z"), n_variants=fx["n_variants"],
                           emu_s=fx.get("emu_s"))
     os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
-    with open(os.path.join(REPO, "profiles", f"r04_oracle_streamed_{args.base}{suffix}.json"), "w") as fh:
+    with open(os.path.join(REPO, "profiles", f"{'r04' if args.base in ('cfg1', 'cfg2') else 'r05'}_oracle_streamed_{args.base}{suffix}.json"), "w") as fh:
         json.dump(report, fh, indent=1)
     log("done")
 

@@ -232,8 +232,12 @@ def pre():
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=CSRC, help="directory the three attn_dkv5_*.inc files are written to (default: csrc/)")
+    outdir = ap.parse_args().out
     for name, s in (("body", body()), ("skip", skip()), ("prefetch", pre())):
-        out = os.path.join(CSRC, f"attn_dkv5_{name}.inc")
+        out = os.path.join(outdir, f"attn_dkv5_{name}.inc")
         open(out, "w").write("\n".join(s.lines) + "\n")
         print(out, s.issued, "reads, max wait", s.max_wait)
 
