@@ -81,13 +81,15 @@ class OmniLMMFront:
         return x, self.batch["concatenated_labels"], feats
 
 
-def _tail_logps(x, W, labels, eps, row_chunk):
+def _tail_logps(x, W, labels, eps, row_chunk, hidden_fn=None):
     """per-token / sequence log-probs of ``_tail`` evaluated on row chunks (rows are independent; the [rows, L, V] fp32 logits
     of a chunk are the largest tensor of the whole run at L = 4096)."""
     S = x.shape[0]
     pts, lps, avs = [], [], []
     for r0 in range(0, S, row_chunk):
         hidden = O.rms_norm(x[r0:r0 + row_chunk], W["model.norm.weight"], eps)
+        if hidden_fn is not None:
+            hidden = hidden_fn(hidden)
         logits = F.linear(hidden, W["lm_head.weight"]).float()
         pt, lp, av = O.get_batch_logps(logits, labels[r0:r0 + row_chunk], return_all=True)
         pts.append(pt), lps.append(lp), avs.append(av)
@@ -103,7 +105,7 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
                       lora_scale: Optional[float] = None,
                       lora_masks_fn: Optional[Callable[[int], Dict[str, torch.Tensor]]] = None,
                       row_chunk: Optional[int] = None, front=None,
-                      layer_fn: Optional[Callable] = None) -> Dict[str, object]:
+                      layer_fn: Optional[Callable] = None, hidden_fn: Optional[Callable] = None) -> Dict[str, object]:
     """DPO step (DPO_weight 1, SFT_weight 0, dpo_use_average False) of ``dpo_step_forward`` + ``loss.backward()``.
 
     variants   list of {ref_win_logp, ref_rej_logp} (or a callable (policy_win_logp, policy_rej_logp) -> such a list);
@@ -118,8 +120,9 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
                    weight gradients are summed over the chunks) - the [S, H, L, L] fp32 attention matrices of 4 rows at L = 4096
                    would not fit beside the weights otherwise.
     front          LlavaFront (default) or OmniLMMFront: everything in front of the decoder stack.
-    layer_fn       replaces ``dpo_oracle.llama_layer`` (same signature) - used by the rounding-point study, which needs the
-                   same layer with explicit bf16 roundings inserted.
+    layer_fn       replaces ``dpo_oracle.llama_layer`` (same signature) - used by the rounding-point study (oracle/rounding.py), which
+                   needs the same layer with explicit bf16 roundings inserted; ``hidden_fn`` is applied to the final norm's output
+                   in front of the LM head (forward-only runs).
     Returns the forward quantities of ``dpo_step_forward`` (per variant: loss / losses / rewards under ``variants``)."""
     beta = batch["beta"]
     B = batch["win_input_ids"].shape[0]
@@ -150,7 +153,7 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
             if i % 8 == 7:
                 log(f"forward: layer {i + 1} / {cfg.layers}, {time.time() - t0:.0f} s")
         S = xs[-1].shape[0]
-        per_token, log_prob, avg = _tail_logps(xs[-1], W, labels, cfg.rms_eps, row_chunk or S)
+        per_token, log_prob, avg = _tail_logps(xs[-1], W, labels, cfg.rms_eps, row_chunk or S, hidden_fn)
         if variants is None:
             variants = [dict(ref_win_logp=batch["ref_win_logp"], ref_rej_logp=batch["ref_rej_logp"])]
         elif callable(variants):                       # reference log-probs that depend on the policy's own (conditioned cases)
@@ -167,6 +170,8 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
         timings["fwd_s"] = t1 - t0
     if not backward:
         return res
+    if hidden_fn is not None:
+        raise ValueError("hidden_fn is a forward-only hook")
     nv = len(variants)
 
     def sink(v, name, g):

