@@ -236,6 +236,10 @@ def main():
     ap.add_argument("--omnilmm-precomputed-tower", action="store_true",
                     help="with --omnilmm: hand over synthetic precomputed tower tokens instead of pixels (the tower is frozen, "
                          "its output can be cached across epochs); the tower is then NOT in the number")
+    ap.add_argument("--ragged", action="store_true",
+                    help="NOT the headline line: answer lengths shaped like the RLAIF-V preference data (chosen ~ log-normal, median "
+                         "200 tokens; rejected = chosen x U(0.6, 1.4)) instead of rows that all reach --seq-len; reports what the pad-free "
+                         "token layout skips (use a larger --pairs-per-gpu: such pairs are ~1,100 packed tokens each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dp-probe", action="store_true",
                     help="skip the single-GPU data-parallel probe (steps re-timed with a concurrent reduce-copy kernel on a "
@@ -307,7 +311,7 @@ def main():
                                         image_size=cfg.image_size)
     else:
         ds = SyntheticPreferenceDataset(n=B * world, vocab=cfg.vocab, text_len=L - (cfg.n_patches - 1), prompt_len=64,
-                                        image_size=cfg.image_size, seed=1234)
+                                        image_size=cfg.image_size, seed=1234, length_dist="rlaifv" if args.ragged else None)
     collate = DataCollatorForDPODataset(_Tok(), beta=0.1, mod_token_weight=1.0)
     batch = collate([ds[rank * B + i] for i in range(B)])
     batch["images"] = batch["images"].to(dev)       # inputs resident in HBM before the timed region
@@ -481,9 +485,36 @@ def main():
         seq_dims = {k: v for k, v in dims.items() if k != "vision"}
         saved = sum(flops_per_seq(p, layers=args.layers, lora_r=lr_, n_tgt=0, **seq_dims) for p in shared) / max(len(shared), 1)
         fp = flops_per_pair(L, layers=args.layers, lora_r=lr_, n_tgt=plan.n_sel / (2.0 * B), **dims) - saved
+        ragged_info = None
+        if args.ragged:
+            # rows of different lengths: the required FLOPs are summed over the actual sequences (chosen row, rejected row, minus
+            # the shared prefix computed once), and the line says how many token rows each layout carries
+            e1 = plan.seg_e1.tolist() if plan.seg_e1 is not None else None
+            cnt = (plan.seq_off[1:] - plan.seq_off[:-1]).tolist()
+            if e1 is not None:
+                rl = plan.row_len.tolist() if plan.row_len is not None else None
+                tot = 0.0
+                lens_c, lens_r = [], []
+                for b_ in range(B):
+                    lc = e1[b_]
+                    lr_len = (rl[b_] if rl is not None else None)
+                    lr_len = (lr_len - lc + shared[b_]) if lr_len is not None else lc
+                    lens_c.append(lc), lens_r.append(lr_len)
+                    tot += (flops_per_seq(lc, layers=args.layers, lora_r=lr_, n_tgt=cnt[b_], **seq_dims)
+                            + flops_per_seq(lr_len, layers=args.layers, lora_r=lr_, n_tgt=cnt[B + b_], **seq_dims)
+                            - flops_per_seq(shared[b_], layers=args.layers, lora_r=lr_, n_tgt=0, **seq_dims) + vis)
+                fp = tot / B
+                rect = plan.S * plan.L
+                ragged_info = dict(length_dist="rlaifv (chosen answers log-normal, median 200 tokens; rejected = chosen x U(0.6, 1.4))",
+                                   pad_free=bool(model.pad_free), token_rows_per_step=int(plan.n_tokens), token_rows_rectangular=int(rect),
+                                   token_rows_reference_layout=int(2 * B * max(max(lens_c), max(lens_r))),
+                                   skipped_vs_rectangular_packed=1.0 - plan.n_tokens / rect,
+                                   skipped_vs_reference_layout=1.0 - plan.n_tokens / (2.0 * B * max(max(lens_c), max(lens_r))),
+                                   spliced_len_chosen_mean=sum(lens_c) / B, spliced_len_rejected_mean=sum(lens_r) / B)
         step_tflops_per_gpu = fp * (pairs_per_s / world) / 1e12
         line = {
-            "metric": "preference-pairs/sec (DPO step) " + (("OmniLMM-12B" if tower is not None else "OmniLMM-12B (tower excluded)") if args.omnilmm else "LLaVA-1.5-7B") + " bf16", "value": pairs_per_s, "unit": "pairs/s",
+            "metric": "preference-pairs/sec (DPO step) " + (("OmniLMM-12B" if tower is not None else "OmniLMM-12B (tower excluded)") if args.omnilmm else "LLaVA-1.5-7B") + " bf16"
+                      + (" [RAGGED lengths - not the headline config]" if args.ragged else ""), "value": pairs_per_s, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (("OmniLMM-12B from pixels: EVA02-E/14 tower (63 blocks, width 1792, 448 px -> 1024 tokens, frozen, "
@@ -493,7 +524,8 @@ def main():
                                      "tower tokens); frozen EVA02-E tower NOT run (precomputed synthetic tower tokens) ")
                                     if args.omnilmm else "LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B) ")
                                    + (f"LoRA (r={args.lora_r}, all 7 decoder projections, dropout 0.05)" if args.lora else "full-FT")
-                                   + f" DPO step, {cfg.image_size}px, seq_len={L}, {B} pairs/GPU, random-init weights",
+                                   + f" DPO step, {cfg.image_size}px, seq_len={L}" + (" (maximum; RAGGED answer lengths)" if args.ragged else "")
+                                   + f", {B} pairs/GPU, random-init weights",
                        "pairs_per_gpu": B, "global_batch_pairs": B * world, "seq_len": L, "llm_layers": args.layers,
                        "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0",
                        "trainable_params": int(model.store.n_train),
@@ -505,6 +537,8 @@ def main():
             "shared_prefix_tokens_per_pair": sum(shared) / max(len(shared), 1),
             "tokens_per_step_per_gpu": plan.n_real_tokens,
         }
+        if ragged_info is not None:
+            line["ragged"] = ragged_info
         if tower is not None:
             line["vision_tower"] = dict(kind="EVA02-E/14 (timm eva02_enormous_patch14_clip_224, last block dropped), frozen, forward only",
                                         params=tower.n_params(), flops_per_image=vis_tower, blocks=tower.cfg.blocks_used,
@@ -514,7 +548,7 @@ def main():
             traffic, traffic_file = None, None
             # the committed PMC passes were collected on THE HEADLINE CONFIG (full fine-tune, 32 layers, L = 2048, 8 pairs, one GPU):
             # any other workload reports traffic = null instead of a constant that does not describe it
-            pmc_config_matches = (not args.lora and not args.omnilmm and args.layers == 32 and L == 2048 and B == 8
+            pmc_config_matches = (not args.lora and not args.omnilmm and not args.ragged and args.layers == 32 and L == 2048 and B == 8
                                   and not args.gradient_checkpointing)        # per GPU: weak scaling keeps it
             for name in (() if not pmc_config_matches else ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")):   # newest committed PMC passes first
                 try:   # HBM bytes per GEMM launch (profiles/, separate rocprofv3 --pmc runs of this same command)
@@ -564,7 +598,7 @@ def main():
             line["dp_standin_probe_1gpu"] = dp_probe
         if dp_diag is not None:
             line["dp_diag"] = dp_diag
-        if world == 1 and not args.no_cpu_baseline and not args.lora and not args.omnilmm:     # the CPU leg times the full-FT oracle step
+        if world == 1 and not args.no_cpu_baseline and not args.lora and not args.omnilmm and not args.ragged:     # the CPU leg times the full-FT oracle step
             line["cpu_baseline"] = cpu_baseline()
     if world > 1:
         dist.barrier()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 5
+#define RV_ABI_VERSION 6
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
@@ -161,9 +161,14 @@ int rv_row_coef(const float* coef, const int* seq_of_row, const float* weight, f
 /*   seg_sh / seg_e1 (int32 [S], both NULL = plain causal): packed preference pairs.  Row s holds
  *   [shared prefix | chosen branch | rejected branch]; queries at index >= seg_e1[s] (rejected branch) do not attend
  *   keys in [seg_sh[s], seg_e1[s]) (the chosen branch): the image / prompt prefix is computed ONCE per pair. */
+/*   row_off / row_len (int32 [S], both NULL = S rectangular rows of L tokens; ABI 6): PAD-FREE rows.  Sequence s occupies token
+ *   rows [row_off[s], row_off[s] + row_len[s]) of qkv / out (1 <= row_len[s] <= L); the reference right-pads every row to the batch
+ *   maximum (llava/model/llava_arch.py:305-313) and SURVEY 8a property (i) makes skipping those pads exact.  L stays the MAXIMUM row
+ *   length: it sizes the grid and the [S][H][L] stride of lse (and of the backward's delta planes); seg_sh / seg_e1 are per-row
+ *   offsets as before.  Results of a row do not depend on where it starts (tiles are laid relative to the row's first token). */
 int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
                 int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
-                void* stream);
+                const int* row_off, const int* row_len, void* stream);
 /* kv_group (both calls): grouped-query attention as in HF Mistral / Llama-3 (`repeat_kv`): H query heads share
  * H / kv_group key/value heads, query head h reads kv head h / kv_group (K at k_col0 + (h / kv_group) * hd); 1 = MHA.
  * backward (hd = 128): O = the forward output (rv_attn_fwd's `out`), delta = [3][S, H, L] fp32 WORKSPACE (ABI 5; it was [S, H, L]): the dQ
@@ -173,11 +178,13 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
  * block for dK/dV.  Packed rows: key tiles / query tiles that a whole block cannot see are never fetched.
  * rope_cos / rope_sin (fp32 [positions][64], both NULL = off) + rope_pos (int32 [S * L] position of every row, NULL = row
  * index inside its sequence): dQ and dK are written ALREADY rotated back (apply_rotary_pos_emb's autograd, HF
- * modeling_llama.py) - the separate rv_rope_inplace(backward) pass over dqkv is not needed. */
+ * modeling_llama.py) - the separate rv_rope_inplace(backward) pass over dqkv is not needed.  rope_pos is indexed by the token's row
+ * in the buffer (row_off[s] + i under pad-free rows, where it is required). */
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
                 const void* O, long ldo, const float* lse, float* delta, void* dqkv, long lddq, int S, int L, int H,
                 int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
-                const float* rope_cos, const float* rope_sin, const int* rope_pos, void* stream);
+                const float* rope_cos, const float* rope_sin, const int* rope_pos, const int* row_off, const int* row_len,
+                void* stream);
 /* Number of fp32 elements rv_attn_bwd's `delta` workspace must hold for (S, H, L) under THIS library's ABI (3 * S * H * L since
  * ABI 5).  Callers size the buffer with this query instead of hard-coding the plane count (the signature of rv_attn_bwd carries
  * no size argument). */

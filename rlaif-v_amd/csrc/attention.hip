@@ -167,6 +167,10 @@ __device__ __forceinline__ void pair_blocks(int bx, int n, int L, int sh, int e1
   second = (!single && n - 1 - bx > bx) ? __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m2) - 1) : -1;
 }
 
+// Pad-free rows: the grid has room for ceil(Lmax / 128) blocks per row; a workgroup whose index lies beyond THIS row's blocks
+// (paired: beyond its ceil(n / 2) block pairs) has nothing to do.  Uniform over the workgroup, taken before any barrier.
+__device__ __forceinline__ bool varlen_done(int bx, int n, bool paired) { return paired ? 2 * bx >= n + (n & 1) : bx >= n; }
+
 template <int HD>
 __device__ __forceinline__ uint32_t kvtile_off(int row, int c) {
   if (HD == 128) return (uint32_t)(row * 256 + ((c ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4));
@@ -306,18 +310,25 @@ struct TileDma {
 template <int HD, bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                            int k_col0, int v_col0, bf16_t* __restrict__ out, long ldo,
-                                                           float* __restrict__ lse, int L, int H, int nx, float scale,
+                                                           float* __restrict__ lse, int Lmax, int H, int nx, float scale,
                                                            const int* __restrict__ seg_sh,
-                                                           const int* __restrict__ seg_e1, int kv_group) {
+                                                           const int* __restrict__ seg_e1, int kv_group,
+                                                           const int* __restrict__ row_off,
+                                                           const int* __restrict__ row_len) {
   constexpr int KS = HD / 16, ET = HD / 32, TILE = 64 * HD * 2, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, half = lane >> 5;
-  const int nqb = (L + 127) / 128;
   int bx, h, s;
   attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
-  const long tok0 = (long)s * L;
+  // PAD-FREE rows (row_off / row_len, both NULL = S rectangular rows of Lmax tokens): sequence s occupies token rows
+  // [row_off[s], row_off[s] + row_len[s]) of the token-major buffers; lse (and the backward's delta planes) keep the [S][H][Lmax]
+  // stride.  The grid is sized for Lmax: workgroups beyond this row's last block (pair) leave at once (varlen_done).
+  const int L = row_len ? row_len[s] : Lmax;
+  const long tok0 = row_off ? (long)row_off[s] : (long)s * Lmax;
+  const int nqb = (L + 127) / 128;
+  if (varlen_done(bx, nqb, CAUSAL && !((nx >> 21) & 1))) return;
   // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const float c = scale * LOG2E;
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
           w.y = pack2bf(o[e][rg * 4 + 2] * inv, o[e][rg * 4 + 3] * inv);
           *(uint2*)(op + e * 32 + rg * 8 + 4 * half) = w;
         }
-      if (half == 0) lse[((long)s * H + h) * L + q] = (m_run + log2f(l_run)) * LN2;
+      if (half == 0) lse[((long)s * H + h) * Lmax + q] = (m_run + log2f(l_run)) * LN2;
     }
   }  // pass
   APROF(5);
@@ -599,19 +610,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
                                                               long lddo, const bf16_t* __restrict__ O, long ldo,
                                                               const float* __restrict__ lse,
                                                               float* __restrict__ delta,
-                                                              bf16_t* __restrict__ dqkv, long lddq, int L, int H,
+                                                              bf16_t* __restrict__ dqkv, long lddq, int Lmax, int H,
                                                               int nx, float scale, const int* __restrict__ seg_sh,
                                                               const int* __restrict__ seg_e1, int kv_group,
-        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
+        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos,
+        const int* __restrict__ row_off, const int* __restrict__ row_len) {
   constexpr int HD = 128, KS = 8, ET = 4, TILE = 64 * HD * 2, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, half = lane >> 5;
-  const int nqb = (L + 127) / 128;
   int bx, h, s;
   attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
-  const long tok0 = (long)s * L;
+  // PAD-FREE rows (row_off / row_len, both NULL = S rectangular rows of Lmax tokens): sequence s occupies token rows
+  // [row_off[s], row_off[s] + row_len[s]) of the token-major buffers; lse (and the backward's delta planes) keep the [S][H][Lmax]
+  // stride.  The grid is sized for Lmax: workgroups beyond this row's last block (pair) leave at once (varlen_done).
+  const int L = row_len ? row_len[s] : Lmax;
+  const long tok0 = row_off ? (long)row_off[s] : (long)s * Lmax;
+  const int nqb = (L + 127) / 128;
+  if (varlen_done(bx, nqb, CAUSAL && !((nx >> 21) & 1))) return;
   // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const float c = scale * LOG2E;
@@ -661,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
         dof[ks] = *(const bf16x8_t*)(dp + 16 * ks);
       }
     }
-    const float lse_q = lse[((long)s * H + h) * L + qc] * LOG2E;
+    const float lse_q = lse[((long)s * H + h) * Lmax + qc] * LOG2E;
     // delta[q] = sum_e dO[q][e] * O[q][e] (the softmax-backward row term) is computed HERE from the dO fragments the
     // kernel holds anyway (a lane owns 64 of the row's 128 columns, its partner lane^32 the rest) and published for the
     // dK/dV kernel, which runs after this one on the same stream - no separate attn_delta pass over dO and O.
@@ -678,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const bf16_t* __re
       if (q < L && half == 0) {
         // workspace planes [3][S, H, L]: delta (versions 2-4 of the dK/dV kernel), -delta and -lse / scale (version 5 reads them
         // straight into its MFMA accumulator inputs)
-        const long idx = ((long)s * H + h) * L + q, plane = (long)((int)gridDim.x / ((nx & 0xffff) * H)) * H * L;
+        const long idx = ((long)s * H + h) * Lmax + q, plane = (long)((int)gridDim.x / ((nx & 0xffff) * H)) * H * Lmax;
         delta[idx] = delta_q;
         delta[plane + idx] = -delta_q;
         delta[2 * plane + idx] = -lse[idx] / scale;
@@ -841,10 +858,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ dO, long lddo,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
-                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
+                                                               bf16_t* __restrict__ dqkv, long lddq, int Lmax, int H,
                                                                int nx, float scale, const int* __restrict__ seg_sh,
                                                                const int* __restrict__ seg_e1, int kv_group,
-        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
+        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos,
+        const int* __restrict__ row_off, const int* __restrict__ row_len) {
   constexpr int HD = 128, KS = 8, ET = 4;
   constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64] = 0x8200
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -854,9 +872,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
   const int fr = lane & 31, half = lane >> 5;
   int bx, h, s;
   attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
-  const long tok0 = (long)s * L;
+  const int L = row_len ? row_len[s] : Lmax;                   // pad-free rows: see attn_fwd2_kernel
+  const long tok0 = row_off ? (long)row_off[s] : (long)s * Lmax;
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const int nkb = (L + 127) / 128;
+  if (varlen_done(bx, nkb, CAUSAL && !((nx >> 21) & 1))) return;
   const float c = scale * LOG2E;
   const int HQ = H * kv_group;
 
@@ -893,9 +913,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
       }
     } else if (wave == 0) {
       const int qq = min(qs0 + lane, L - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse + ((long)s * HQ + hq) * L + qq),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse + ((long)s * HQ + hq) * Lmax + qq),
                                        (__attribute__((address_space(3))) void*)(st + 32768), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta + ((long)s * HQ + hq) * L + qq),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta + ((long)s * HQ + hq) * Lmax + qq),
                                        (__attribute__((address_space(3))) void*)(st + 32768 + 256), 4, 0, 0);
     }
   };
@@ -1189,10 +1209,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ dO, long lddo,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
-                                                               bf16_t* __restrict__ dqkv, long lddq, int L, int H,
+                                                               bf16_t* __restrict__ dqkv, long lddq, int Lmax, int H,
                                                                int nx, float scale, const int* __restrict__ seg_sh,
                                                                const int* __restrict__ seg_e1, int kv_group,
-        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos) {
+        const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ rope_pos,
+        const int* __restrict__ row_off, const int* __restrict__ row_len) {
   constexpr int HD = 128, KS = 8, ET = 4;
   constexpr int STAGE = 2 * 64 * 256 + 512;          // Q tile + dO tile + lse[64] + delta[64] = 0x8200
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
@@ -1203,12 +1224,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
   const int fr = lane & 31, half = lane >> 5;
   int bx, h, s;
   attn_block_coords(nx, H, (int)gridDim.x / ((nx & 0xffff) * H), bx, h, s);
-  const long tok0 = (long)s * L;
+  const int L = row_len ? row_len[s] : Lmax;                   // pad-free rows: see attn_fwd2_kernel
+  const long tok0 = row_off ? (long)row_off[s] : (long)s * Lmax;
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const int nkb = (L + 127) / 128;
+  if (varlen_done(bx, nkb, CAUSAL && !((nx >> 21) & 1))) return;
   const float c = scale * LOG2E;
   const int HQ = H * kv_group;
-  const long ws_plane = (long)((int)gridDim.x / ((nx & 0xffff) * H)) * HQ * L;       // one [S, HQ, L] plane of the delta workspace
+  const long ws_plane = (long)((int)gridDim.x / ((nx & 0xffff) * H)) * HQ * Lmax;    // one [S, HQ, Lmax] plane of the delta workspace
 
   int d_row[4], d_chunk[4];
 #pragma unroll
@@ -1237,7 +1260,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
       }
     } else if (wave < 2) {         // plane 2 of the workspace = -lse / scale (wave 0), plane 1 = -delta (wave 1): written by the dQ kernel
       const int qq = min(qs0 + lane, L - 1);
-      const float* src = delta + (wave == 0 ? 2 : 1) * ws_plane + ((long)s * HQ + hq) * L + qq;
+      const float* src = delta + (wave == 0 ? 2 : 1) * ws_plane + ((long)s * HQ + hq) * Lmax + qq;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(st + 32768 + wave * 256), 4, 0, 0);
     }
@@ -1542,8 +1565,10 @@ int rv_debug_dkv5_prof(unsigned long long* out16) {
 #endif
 
 int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, void* out, long ldo, float* lse, int S,
-                int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group, void* stream) {
+                int L, int H, int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
+                const int* row_off, const int* row_len, void* stream) {
   RV_REQUIRE(hd == 64 || hd == 128, "rv_attn_fwd: head dim must be 64 or 128");
+  RV_REQUIRE((row_off == nullptr) == (row_len == nullptr), "rv_attn_fwd: row_off and row_len go together");
   RV_REQUIRE(kv_group >= 1 && H % kv_group == 0, "rv_attn_fwd: kv_group must divide the number of query heads");
   RV_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0 && v_col0 % 8 == 0,
              "rv_attn_fwd: alignment");
@@ -1566,7 +1591,7 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   }
 #define LAUNCH_FWD(HD_, C_)                                                                                      \
   hipLaunchKernelGGL((attn_fwd2_kernel<HD_, C_>), grid, block, 4 * 64 * HD_ * 2, st, (const bf16_t*)qkv, ld, q_col0, \
-                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group)
+                     k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group, row_off, row_len)
 #ifdef RV_ATTN_EXPERIMENTS
   static int fwd_ablate = -1;
   if (fwd_ablate < 0) { const char* a = getenv("RV_FWD_ABLATE"); fwd_ablate = a ? atoi(a) : 0; }
@@ -1574,7 +1599,7 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   if (fwd_ablate == N && hd == 128 && causal) {                                                                            \
     hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);     \
     hipLaunchKernelGGL((attn_fwd2_kernel<128, true, N>), grid, block, 4 * 64 * 128 * 2, st, (const bf16_t*)qkv, ld, q_col0, \
-                       k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group);                   \
+                       k_col0, v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group, row_off, row_len);                   \
     RV_CHECK_LAUNCH();                                                                                                     \
     return 0;                                                                                                              \
   }
@@ -1591,8 +1616,12 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
 int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, const void* dO, long lddo,
                 const void* O, long ldo, const float* lse, float* delta, void* dqkv, long lddq, int S, int L, int H,
                 int hd, int causal, float scale, const int* seg_sh, const int* seg_e1, int kv_group,
-                const float* rope_cos, const float* rope_sin, const int* rope_pos, void* stream) {
+                const float* rope_cos, const float* rope_sin, const int* rope_pos, const int* row_off, const int* row_len,
+                void* stream) {
   RV_REQUIRE(hd == 128, "rv_attn_bwd: head dim must be 128");
+  RV_REQUIRE((row_off == nullptr) == (row_len == nullptr), "rv_attn_bwd: row_off and row_len go together");
+  RV_REQUIRE(row_off == nullptr || rope_cos == nullptr || rope_pos != nullptr,
+             "rv_attn_bwd: pad-free rows with the fused inverse rotation need the position table (rope_pos)");
   RV_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), "rv_attn_bwd: rope_cos and rope_sin go together");
   RV_REQUIRE(O != nullptr && delta != nullptr && ldo % 8 == 0, "rv_attn_bwd: O (forward output) and the delta workspace are required");
   RV_REQUIRE(kv_group >= 1 && H % kv_group == 0, "rv_attn_bwd: kv_group must divide the number of query heads");
@@ -1640,7 +1669,7 @@ int rv_attn_bwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, co
   const int Hkv = H / kv_group;
   dim3 grid_kv(nxr * Hkv * S);
 #define BWD_HEAD (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0, (const bf16_t*)dO, lddo
-#define BWD_TAIL(HH) (bf16_t*)dqkv, lddq, L, HH, nx, scale, seg_sh, seg_e1, kv_group, rope_cos, rope_sin, rope_pos
+#define BWD_TAIL(HH) (bf16_t*)dqkv, lddq, L, HH, nx, scale, seg_sh, seg_e1, kv_group, rope_cos, rope_sin, rope_pos, row_off, row_len
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<true>), grid, block, DQ_LDS, st, BWD_HEAD, (const bf16_t*)O, ldo, lse, delta, BWD_TAIL(H));
     RV_CHECK_LAUNCH();

@@ -14,6 +14,8 @@ import difflib
 from dataclasses import dataclass
 from typing import Dict, List, Sequence, Tuple
 
+import math
+
 import torch
 from typing import Optional
 
@@ -151,7 +153,8 @@ class SyntheticPreferenceDataset(torch.utils.data.Dataset):
     exercised.  No tokenizer / parquet / JPEG is involved (none exist offline)."""
 
     def __init__(self, n: int, vocab: int, text_len: int, prompt_len: int = 64, image_size: int = 336,
-                 image_pos: int = 35, seed: int = 0, ragged: bool = False, omnilmm: Optional[dict] = None):
+                 image_pos: int = 35, seed: int = 0, ragged: bool = False, omnilmm: Optional[dict] = None,
+                 length_dist: Optional[str] = None):
         """``omnilmm`` = dict(tokens=(im_patch, im_start, im_end), num_query=, tower_tokens=, width=): the OmniLMM token
         convention (<im_start> <im_patch> x num_query <im_end> inside the prompt, omnilmm.py:221-257) and, as ``image``,
         precomputed tower tokens [tower_tokens, width] (the tower is frozen; rlaif-v_amd/omnilmm.py) - or, with
@@ -159,6 +162,12 @@ class SyntheticPreferenceDataset(torch.utils.data.Dataset):
         self.n, self.vocab, self.text_len, self.prompt_len = n, vocab, text_len, prompt_len
         self.image_size, self.image_pos, self.seed, self.ragged = image_size, min(image_pos, prompt_len - 2), seed, ragged
         self.omnilmm = omnilmm
+        # "rlaifv": answer lengths shaped like the RLAIF-V preference data (tools/host_pipeline_bench.py synthesises rows of ~229
+        # text tokens with a wide spread): chosen ~ log-normal(median 200, sigma 0.6), rejected = chosen x U(0.6, 1.4), both clipped
+        # to [8, text_len - prompt_len].  None: ``ragged`` (uniform in the upper half) or full length.
+        if length_dist not in (None, "rlaifv"):
+            raise ValueError(f"length_dist must be None or 'rlaifv', got {length_dist!r}")
+        self.length_dist = length_dist
         if omnilmm is not None and self.image_pos + omnilmm["num_query"] + 2 > prompt_len:
             raise ValueError("prompt_len too short for <im_start> + num_query patches + <im_end>")
         if omnilmm is not None and vocab > min(omnilmm["tokens"]):
@@ -185,8 +194,15 @@ class SyntheticPreferenceDataset(torch.utils.data.Dataset):
             else:
                 image = torch.randn(o["tower_tokens"], o["width"], generator=g).to(torch.bfloat16)
         out = []
+        amax = self.text_len - self.prompt_len
+        if self.length_dist == "rlaifv":
+            base = float(torch.exp(math.log(200.0) + 0.6 * torch.randn((), generator=g)))
+            ratio = float(0.6 + 0.8 * torch.rand((), generator=g))
+            dist_len = {"win": int(min(max(base, 8), amax)), "rej": int(min(max(base * ratio, 8), amax))}
         for tag in ("rej", "win"):
-            if self.ragged:
+            if self.length_dist == "rlaifv":
+                alen = dist_len[tag]
+            elif self.ragged:
                 lo = max(2, (self.text_len - self.prompt_len) // 2)
                 alen = int(torch.randint(lo, self.text_len - self.prompt_len + 1, (1,), generator=g))
             else:

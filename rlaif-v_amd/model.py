@@ -358,6 +358,9 @@ class LlavaDPOModel:
         self.grad_ready_hook = None     # callable(name, start, end) fired when a slice of flat_g is final
         # compute the prefix shared by the chosen and rejected sequence of a pair once (splice.build_packed_plan)
         self.share_prefix = os.environ.get("RV_SHARE_PREFIX", "1") != "0"
+        # packed rows are concatenated without inter-row padding (splice.build_packed_plan pad_free; RV_PAD_FREE=0: every packed
+        # row right-padded to the longest, the round-1..4 layout).  Log-probs are bit-identical either way (SURVEY 8a property (i))
+        self.pad_free = os.environ.get("RV_PAD_FREE", "1") != "0"
         self.fuse_rope_bwd = os.environ.get("RV_FUSE_ROPE_BWD", "1") != "0"
 
     # ------------------------------------------------------------------ weights
@@ -674,7 +677,7 @@ class LlavaDPOModel:
             xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
         qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0, xd=xnd)
         ops.rope_inplace(qkv, cos, sin, L, H + cfg.n_kv_heads, hd, pos=plan.pos)      # q heads then k heads
-        attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, d + cfg.kv_dim, seg=plan.seg, kv_group=cfg.kv_group)
+        attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, d + cfg.kv_dim, seg=plan.seg, kv_group=cfg.kv_group, rows=plan.rows)
         x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
         if drop:
             xn2, rstd2, xn2d = ops.rmsnorm_fwd_dropout(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps, p_drop, self._dropout_seed(i, 2))
@@ -734,12 +737,12 @@ class LlavaDPOModel:
                                      splicer=self._row_splicer())
         elif self.share_prefix and input_ids.shape[0] == 2 * B:
             plan = build_packed_plan(input_ids, labels, cfg.n_image_tokens, B, cfg.model_max_length, cfg.pad_token_id,
-                                     splicer=self._row_splicer())
+                                     splicer=self._row_splicer(), pad_free=self.pad_free)
         else:
             plan = build_splice_plan(input_ids, labels, cfg.n_image_tokens, B, cfg.model_max_length, splicer=self._row_splicer())
         plan = plan.to(self.device)
         S, L = plan.S, plan.L
-        N = S * L
+        N = plan.n_tokens                # S * L in the rectangular layouts, the sum of the packed rows' lengths when pad-free
         feats = self.encode_images(images, ctx if save_for_backward else None)
         x = ops.splice_fwd(plan.src, st.p("model.embed_tokens.weight"), feats, d)
         cos, sin = self._rope(L)
@@ -835,7 +838,8 @@ class LlavaDPOModel:
             dattn = self._proj_bwd(dx_mid, c["attn"], c["t_o"], i, "o", drop_slot=1, xd=c["xd_o"])
             # dQ / dK leave the attention backward already rotated back (RV_FUSE_ROPE_BWD=0: separate rv_rope_inplace pass)
             dqkv = ops.attn_bwd(c["qkv"], c["attn"], dattn, c["lse"], S, L, H, hd, True, 0, d, d + cfg.kv_dim,
-                                seg=plan.seg, kv_group=cfg.kv_group, rope=(cos, sin, plan.pos) if self.fuse_rope_bwd else None)
+                                seg=plan.seg, kv_group=cfg.kv_group, rope=(cos, sin, plan.pos) if self.fuse_rope_bwd else None,
+                                rows=plan.rows)
             del dattn
             if not self.fuse_rope_bwd:
                 ops.rope_inplace(dqkv, cos, sin, L, H + cfg.n_kv_heads, hd, backward=True, pos=plan.pos)

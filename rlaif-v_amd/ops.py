@@ -454,21 +454,25 @@ def gelu_bwd(dy, x):
 # ------------------------------------------------------------------------------------- attention
 def attn_fwd(qkv: torch.Tensor, S: int, L: int, H: int, hd: int, causal: bool, q_col0: int, k_col0: int,
              v_col0: int, out: Optional[torch.Tensor] = None, seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-             kv_group: int = 1):
-    """Returns (out [S*L, H*hd], lse [S,H,L]).  kv_group > 1: grouped-query attention (H / kv_group key/value heads)."""
+             kv_group: int = 1, rows: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """Returns (out [tokens, H*hd], lse [S,H,L]).  kv_group > 1: grouped-query attention (H / kv_group key/value heads).
+    ``rows`` = (row_off, row_len) int32 [S]: PAD-FREE rows - sequence s occupies token rows [row_off[s], row_off[s] + row_len[s])
+    of qkv, L is the maximum row length; None: S rectangular rows of L tokens."""
     _chk2d(qkv, "qkv")
     if out is None:
-        out = torch.empty(S * L, H * hd, dtype=BF16, device=qkv.device)
+        out = torch.empty(qkv.shape[0] if rows is not None else S * L, H * hd, dtype=BF16, device=qkv.device)
     lse = torch.empty(S, H, L, dtype=torch.float32, device=qkv.device)
     hip.call("rv_attn_fwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, out, out.stride(0), lse, S, L, H, hd,
-             int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None, seg[1] if seg else None, int(kv_group))
+             int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None, seg[1] if seg else None, int(kv_group),
+             rows[0] if rows else None, rows[1] if rows else None)
     return out, lse
 
 
 def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv: Optional[torch.Tensor] = None,
-             seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, kv_group: int = 1, rope=None):
+             seg: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, kv_group: int = 1, rope=None,
+             rows: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Returns dqkv with dQ/dK/dV written at the qkv column offsets.  ``rope`` = (cos, sin, pos | None): dQ and dK come out
-    already rotated back (the backward of apply_rotary_pos_emb fused into the stores)."""
+    already rotated back (the backward of apply_rotary_pos_emb fused into the stores).  ``rows``: pad-free rows (attn_fwd)."""
     _chk2d(qkv, "qkv"), _chk2d(o, "o"), _chk2d(do, "do")
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
@@ -477,7 +481,7 @@ def attn_bwd(qkv, o, do, lse, S, L, H, hd, causal, q_col0, k_col0, v_col0, dqkv:
     hip.call("rv_attn_bwd", qkv, qkv.stride(0), q_col0, k_col0, v_col0, do, do.stride(0), o, o.stride(0), lse, delta,
              dqkv, dqkv.stride(0), S, L, H, hd, int(causal), 1.0 / math.sqrt(hd), seg[0] if seg else None,
              seg[1] if seg else None, int(kv_group), rope[0] if rope else None, rope[1] if rope else None,
-             rope[2] if rope else None)
+             rope[2] if rope else None, rows[0] if rows else None, rows[1] if rows else None)
     return dqkv
 
 

@@ -51,6 +51,9 @@ class SplicePlan:
     seg_e1: Optional[torch.Tensor] = None     # int32 [S] end of the chosen branch
     shared_len: Optional[List[int]] = None    # per pair (accounting)
     n_real_tokens: int = 0                    # rows that carry a real token / image feature
+    row_off: Optional[torch.Tensor] = None    # int32 [S] PAD-FREE packed layout: first token row of packed row s (None: s * L)
+    row_len: Optional[torch.Tensor] = None    # int32 [S] ... and its length; L is then the LONGEST row (grid / lse stride / RoPE table)
+    n_tokens: int = 0                         # rows of the token-major activation buffers (S * L when rectangular)
 
     def to(self, device) -> "SplicePlan":
         kw = {}
@@ -61,6 +64,11 @@ class SplicePlan:
     @property
     def seg(self):
         return (self.seg_sh, self.seg_e1) if self.seg_sh is not None else None
+
+    @property
+    def rows(self):
+        """(row_off, row_len) for the attention kernels, None in the rectangular layouts."""
+        return (self.row_off, self.row_len) if self.row_off is not None else None
 
 
 def _splice_rows(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
@@ -191,13 +199,19 @@ def build_splice_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
     return SplicePlan(S=S, L=L, n_seq=S, src=flat.to(torch.int32), labels=lab_full, sel_idx=sel, tgt=tgt,
                       seq_off=seq_off, seq_of_row=s_idx.to(torch.int32), uniq_ids=uniq, seg_off=seg_off,
                       pos_sorted=pos_sorted, feat_src_a=a, feat_src_b=b, n_sel=int(sel.numel()),
-                      n_real_tokens=int(sum(x.numel() for x in rows_src)))
+                      n_real_tokens=int(sum(x.numel() for x in rows_src)), n_tokens=S * L)
 
 
 def build_packed_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_tokens: int, n_images: int,
-                      max_len: Optional[int], pad_token_id: int = 0, splicer=None) -> SplicePlan:
+                      max_len: Optional[int], pad_token_id: int = 0, splicer=None, pad_free: bool = False) -> SplicePlan:
     """One row per pair: [shared prefix | chosen branch | rejected branch] (module docstring).
-    input_ids / labels: [2B, T], wins then rejects."""
+    input_ids / labels: [2B, T], wins then rejects.
+    ``pad_free``: the B packed rows are CONCATENATED (row b starts at row_off[b], no inter-row padding) instead of being
+    right-padded to the longest - the reference pads every row to the batch maximum (llava/model/llava_arch.py:305-313) and
+    SURVEY 8a property (i) (a sequence's log-prob does not depend on its padding or its batch mates) makes dropping those rows
+    exact.  Everything token-major (GEMMs, norms, SwiGLU, LM head, splice, embedding gradient) simply sees fewer rows; the
+    attention kernels take (row_off, row_len) and the RoPE position table is indexed by buffer row.  Identical index tables up
+    to the row renumbering: selected rows / targets / sequence offsets keep their (sequence, position) order."""
     input_ids = input_ids.cpu().long()
     labels = labels.cpu().long()
     S2 = input_ids.shape[0]
@@ -235,16 +249,28 @@ def build_packed_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
         sel_rows[0][b], sel_tgts[0][b] = ci, cl[1:][ci]
         sel_rows[1][b], sel_tgts[1][b] = Lc + (ri - sh), rl[1:][ri]
     L = max(int(x.numel()) for x in packed_src)
-    src_full = torch.full((B, L), -1, dtype=torch.int64)
-    pos_full = torch.zeros((B, L), dtype=torch.int64)
-    for b in range(B):
-        n = packed_src[b].numel()
-        src_full[b, :n] = packed_src[b]
-        pos_full[b, :n] = packed_pos[b]
+    lens = [int(x.numel()) for x in packed_src]
+    if pad_free:
+        starts = [0] * B
+        for b in range(1, B):
+            starts[b] = starts[b - 1] + lens[b - 1]
+        n_tokens = starts[-1] + lens[-1]
+        flat = torch.cat(packed_src)
+        pos_flat = torch.cat(packed_pos)
+    else:
+        starts = [b * L for b in range(B)]
+        n_tokens = B * L
+        src_full = torch.full((B, L), -1, dtype=torch.int64)
+        pos_full = torch.zeros((B, L), dtype=torch.int64)
+        for b in range(B):
+            n = packed_src[b].numel()
+            src_full[b, :n] = packed_src[b]
+            pos_full[b, :n] = packed_pos[b]
+        flat, pos_flat = src_full.reshape(-1), pos_full.reshape(-1)
     sel, tgt, seq_of, counts = [], [], [], []
     for br in range(2):
         for b in range(B):
-            sel.append(b * L + sel_rows[br][b])
+            sel.append(starts[b] + sel_rows[br][b])
             tgt.append(sel_tgts[br][b])
             seq_of.append(torch.full((sel_rows[br][b].numel(),), br * B + b, dtype=torch.int64))
             counts.append(sel_rows[br][b].numel())
@@ -253,10 +279,11 @@ def build_packed_plan(input_ids: torch.Tensor, labels: torch.Tensor, n_img_token
     seq_of = torch.cat(seq_of).to(torch.int32)
     seq_off = torch.zeros(S2 + 1, dtype=torch.int32)
     seq_off[1:] = torch.cumsum(torch.tensor(counts), 0).to(torch.int32)
-    flat = src_full.reshape(-1)
     uniq, seg_off, pos_sorted, a, bb = _tables(flat, max(n_images, 1) * n_img_tokens)
     return SplicePlan(S=B, L=L, n_seq=S2, src=flat.to(torch.int32), labels=None, sel_idx=sel, tgt=tgt, seq_off=seq_off,
                       seq_of_row=seq_of, uniq_ids=uniq, seg_off=seg_off, pos_sorted=pos_sorted, feat_src_a=a,
-                      feat_src_b=bb, n_sel=int(sel.numel()), pos=pos_full.reshape(-1).to(torch.int32),
+                      feat_src_b=bb, n_sel=int(sel.numel()), pos=pos_flat.to(torch.int32),
                       seg_sh=torch.tensor(shs, dtype=torch.int32), seg_e1=torch.tensor(e1s, dtype=torch.int32),
-                      shared_len=shs, n_real_tokens=int(sum(x.numel() for x in packed_src)))
+                      shared_len=shs, n_real_tokens=int(sum(lens)), n_tokens=n_tokens,
+                      row_off=torch.tensor(starts, dtype=torch.int32) if pad_free else None,
+                      row_len=torch.tensor(lens, dtype=torch.int32) if pad_free else None)

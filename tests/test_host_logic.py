@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert len(lib.decls) >= 37
     for name in lib.decls:
         assert hasattr(lib.lib, name), name
-    assert lib.lib.rv_abi_version() == 5
+    assert lib.lib.rv_abi_version() == 6
     # argument errors are reported through the ABI (no launch happens for an invalid shape)
     assert lib.lib.rv_set_gemm_variant(7) == 1 and "rv_set_gemm_variant" in lib.last_error()
     assert lib.lib.rv_set_gemm_variant(1) == 0
@@ -154,6 +154,41 @@ def test_packed_plan_is_a_lossless_repacking(seed, max_len, common_answer):
     assert p.n_real_tokens < ref.n_real_tokens
     if common_answer == 0 and max_len is None:
         assert all(s == 13 - 1 + cfg.n_patches - 1 for s in p.shared_len)   # whole prompt minus its last token
+
+
+@pytest.mark.parametrize("seed", [1, 5])
+def test_pad_free_plan_is_the_rectangular_plan_without_its_padding(seed):
+    """build_packed_plan(pad_free=True): the B packed rows concatenated - every index table maps to the SAME tokens as the
+    rectangular packed plan (llava_arch.py:305-313 pads; SURVEY 8a property (i) says dropping pads is exact)."""
+    from rlaif_v_amd.splice import build_packed_plan
+    cfg = O.tiny_cfg()
+    B = 4
+    b = O.make_synthetic_batch(cfg, B, 52, 13, seed=seed, ragged=True)
+    ids, lab = b["concatenated_input_ids"], b["concatenated_labels"]
+    r = build_packed_plan(ids, lab, cfg.n_patches, B, None, cfg.pad_token_id)
+    p = build_packed_plan(ids, lab, cfg.n_patches, B, None, cfg.pad_token_id, pad_free=True)
+    assert r.row_off is None and r.rows is None and r.n_tokens == r.S * r.L
+    assert p.S == r.S and p.L == r.L and p.n_seq == r.n_seq and p.n_sel == r.n_sel
+    lens = p.row_len.tolist()
+    assert p.row_off.tolist() == [sum(lens[:i]) for i in range(B)] and p.n_tokens == sum(lens) == p.n_real_tokens == r.n_real_tokens
+    assert p.n_tokens < r.n_tokens and max(lens) == p.L                      # a ragged batch really loses rows
+    src_r, pos_r = r.src.view(B, r.L), r.pos.view(B, r.L)
+    for i in range(B):
+        a, n = int(p.row_off[i]), lens[i]
+        assert torch.equal(p.src[a:a + n], src_r[i, :n]) and bool((src_r[i, n:] == -1).all())
+        assert torch.equal(p.pos[a:a + n], pos_r[i, :n])
+    assert torch.equal(p.tgt, r.tgt) and torch.equal(p.seq_off, r.seq_off) and torch.equal(p.seq_of_row, r.seq_of_row)
+    assert torch.equal(p.seg_sh, r.seg_sh) and torch.equal(p.seg_e1, r.seg_e1)
+    # a selected row is the same (packed row, offset) in both layouts
+    row_r, off_r = r.sel_idx.long() // r.L, r.sel_idx.long() % r.L
+    assert torch.equal(p.sel_idx.long(), p.row_off.long()[row_r] + off_r)
+    # embedding-gradient segments and feature users: same token ids / same (row, offset) positions
+    assert torch.equal(p.uniq_ids, r.uniq_ids) and torch.equal(p.seg_off, r.seg_off)
+    to_pf = lambda t: p.row_off.long()[t.long() // r.L] + t.long() % r.L                                      # noqa: E731
+    assert torch.equal(p.pos_sorted.long(), to_pf(r.pos_sorted))
+    for fa, fb in ((p.feat_src_a, r.feat_src_a), (p.feat_src_b, r.feat_src_b)):
+        used = fb >= 0
+        assert torch.equal(fa >= 0, used) and torch.equal(fa[used].long(), to_pf(fb[used]))
 
 
 @pytest.mark.parametrize("seed", [1, 2])

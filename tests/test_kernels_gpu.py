@@ -571,6 +571,41 @@ def test_attn_long_rows_fwd_bwd(ops, name, L, G, segs):
         close(dqkv[:, sl], qf.grad[:, sl], rel=2.5e-2, what=f"{name}: d{nm}")
 
 
+@pytest.mark.parametrize("G", [1, 2])
+def test_attn_pad_free_rows_bit_identical_to_rectangular(ops, G):
+    """rv_attn_fwd / rv_attn_bwd with (row_off, row_len): every row of a CONCATENATED buffer gives bit-identical out / lse / dQ /
+    dK / dV to the same row evaluated alone as a rectangular S = 1 launch (tiles are laid relative to the row's first token, so a
+    row's arithmetic does not depend on where it starts; blocks past a row's end leave at once).  Packed segments, fused inverse
+    RoPE through the position table, grouped-query attention; row lengths from 1 tile to the launch maximum."""
+    dev = _dev()
+    H, hd = 4, 128
+    Hkv = H // G
+    width, kc, vc = (H + 2 * Hkv) * hd, H * hd, (H + Hkv) * hd
+    lens = [1100, 64, 333, 897, 130]
+    segs = [(638, 900), (10, 30), (129, 131), (0, 256), (130, 130)]
+    off = [sum(lens[:i]) for i in range(len(lens))]
+    N, S, Lmax = sum(lens), len(lens), max(lens)
+    qkv = rnd(N, width, seed=3, dev=dev, scale=0.7)
+    do = rnd(N, H * hd, seed=4, dev=dev)
+    cos, sin = ops.rope_tables(2048, hd, 10000.0, dev)
+    pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int32).to(dev)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)                       # noqa: E731
+    rows = (i32(off), i32(lens))
+    seg = (i32([a for a, _ in segs]), i32([b for _, b in segs]))
+    out, lse = ops.attn_fwd(qkv, S, Lmax, H, hd, True, 0, kc, vc, seg=seg, kv_group=G, rows=rows)
+    dqkv = ops.attn_bwd(qkv, out, do, lse, S, Lmax, H, hd, True, 0, kc, vc, seg=seg, kv_group=G, rope=(cos, sin, pos), rows=rows)
+    assert out.shape == (N, H * hd)
+    for s_, (a, n) in enumerate(zip(off, lens)):
+        sl = slice(a, a + n)
+        seg1 = (seg[0][s_:s_ + 1], seg[1][s_:s_ + 1])
+        o1, l1 = ops.attn_fwd(qkv[sl], 1, n, H, hd, True, 0, kc, vc, seg=seg1, kv_group=G)
+        d1 = ops.attn_bwd(qkv[sl], o1, do[sl], l1, 1, n, H, hd, True, 0, kc, vc, seg=seg1, kv_group=G, rope=(cos, sin, pos[sl].contiguous()))
+        assert torch.equal(out[sl], o1), f"row {s_}: forward output"
+        assert torch.equal(lse[s_, :, :n], l1[0]), f"row {s_}: lse"
+        assert torch.equal(dqkv[sl], d1), f"row {s_}: dqkv"
+    assert torch.equal(ops.attn_bwd(qkv, out, do, lse, S, Lmax, H, hd, True, 0, kc, vc, seg=seg, kv_group=G, rope=(cos, sin, pos), rows=rows), dqkv)
+
+
 def test_rope_position_table(ops):
     dev = _dev()
     n, H, hd, L = 150, 2, 128, 64
