@@ -32,7 +32,7 @@ for st in "$@"; do
     yardstick) timeout 600 python tools/yardstick_hipblaslt.py 2>&1 | tee $OUT/yardstick_hipblaslt.log | tail -40 ;;
     bench)     timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_err.log; tail -c 1500 $OUT/bench_line.json ;;
     benchfast) timeout 600 python bench.py --no-cpu-baseline --no-dp-probe > $OUT/bench_line_fast.json 2> $OUT/bench_fast_err.log; head -c 600 $OUT/bench_line_fast.json; echo ;;
-    ragged)    for pf in 1 0; do RV_PAD_FREE=$pf timeout 600 python bench.py --ragged --pairs-per-gpu 24 --no-dp-probe --steps 4 > $OUT/bench_line_ragged_padfree$pf.json 2> $OUT/bench_ragged_err$pf.log; head -c 500 $OUT/bench_line_ragged_padfree$pf.json; echo; done ;;
+    ragged)    for pf in 1 0; do RV_PAD_FREE=$pf timeout 600 python bench.py --ragged --pairs-per-gpu ${RV_RAGGED_PAIRS:-12} --no-dp-probe --steps 4 > $OUT/bench_line_ragged_padfree$pf.json 2> $OUT/bench_ragged_err$pf.log; head -c 500 $OUT/bench_line_ragged_padfree$pf.json; echo; done ;;
     lora)      timeout 600 python bench.py --lora --seq-len 4096 --pairs-per-gpu 4 --no-dp-probe > $OUT/bench_line_lora.json 2> $OUT/bench_lora_err.log; head -c 600 $OUT/bench_line_lora.json; echo ;;
     prof)      bash tools/profile_bench.sh $R/bench_kernel python bench.py --steps 3 --no-cpu-baseline --no-dp-probe --no-gemm-timer; head -25 gpurun_out/$R/bench_kernel_stats.csv ;;
     smoke)     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log ;;
