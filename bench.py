@@ -84,9 +84,43 @@ class GemmTimer:
         # fused LM head: logits tile -> online log-softmax statistics (forward), recomputed tile -> dlogits (backward)
         "lmhead_logp_fwd": ("lmhead_fwd", lambda h, w, tgt, n, *r, **k: 2.0 * n * w.shape[0] * w.shape[1],
                             lambda h, w, tgt, n, *r, **k: 2.0 * (n * w.shape[1] + w.numel())),
+        "attn_fwd": ("attn_fwd", lambda qkv, S, L, H, hd, causal, *r, **k: 4.0 * hd * H * GemmTimer._pairs(S, L, causal),
+                     lambda qkv, S, L, H, hd, causal, *r, **k: 2.0 * (qkv.numel() + qkv.shape[0] * H * hd)),
+        "attn_bwd": ("attn_bwd", lambda qkv, o, do, lse, S, L, H, hd, causal, *r, **k: 10.0 * hd * H * GemmTimer._pairs(S, L, causal),
+                     lambda qkv, o, do, lse, S, L, H, hd, causal, *r, **k: 2.0 * (2 * qkv.numel() + 2 * o.numel())),
         "lmhead_logp_bwd": ("lmhead_bwd", lambda h, w, tgt, lse, coef, n, *r, **k: 2.0 * n * w.shape[0] * w.shape[1],
                             lambda h, w, tgt, lse, coef, n, *r, **k: 2.0 * (n * w.shape[1] + w.numel() + n * w.shape[0])),
     }
+
+    # The three attention kernels (the kernel class furthest below its roofline was not in the table).  Algorithmic
+    # work of a (query, key) pair that the mask lets through, per query head: forward 4 hd flop (S = QK^T, O = PV); backward 10 hd
+    # (S, dP, dQ, dK, dV).  rv_attn_bwd is two launches - dQ (+ delta) and dK/dV - that EACH recompute S and dP, so the launch pair
+    # executes 14 hd per pair for 10 hd of algorithmic work; the table prices the pair at the algorithmic figure.  The number of
+    # visible pairs of the decoder's packed-causal rows comes from the plan (set_attention_plan), the CLIP tower's rows are full.
+    _attn_pairs = {"causal": None}
+
+    @classmethod
+    def set_attention_plan(cls, plan):
+        """visible (query, key) pairs of one decoder attention launch: row [shared | chosen | rejected] of length n with bounds
+        (sh, e1): query i < e1 sees i + 1 keys, a rejected-branch query i >= e1 sees sh + (i - e1 + 1)."""
+        S, L = plan.S, plan.L
+        lens = plan.row_len.tolist() if plan.row_len is not None else [L] * S
+        if plan.seg_sh is not None:
+            sh, e1 = plan.seg_sh.tolist(), plan.seg_e1.tolist()
+        else:
+            sh, e1 = [0] * S, list(lens)
+        tot = 0
+        for n, a, b in zip(lens, sh, e1):
+            b = min(b, n)
+            r = n - b
+            tot += b * (b + 1) // 2 + r * a + r * (r + 1) // 2
+        cls._attn_pairs["causal"] = float(tot)
+
+    @classmethod
+    def _pairs(cls, S, L, causal):
+        if not causal:
+            return float(S) * L * L
+        return cls._attn_pairs["causal"] if cls._attn_pairs["causal"] is not None else float(S) * L * (L + 1) / 2
 
     def __init__(self):
         self.records = []          # (start event, end event, flops, bytes, class label)
@@ -126,11 +160,12 @@ class GemmTimer:
         for d in by.values():
             d["tflops"] = d["flops"] / max(d["ms"], 1e-9) / 1e9
             d["avg_ms"] = d["ms"] / max(d["launches"], 1)
-        tot_ms = sum(d["ms"] for d in by.values())
-        tot_fl = sum(d["flops"] for d in by.values())
-        n = len(self.records)
+        gemm = {k: d for k, d in by.items() if not k.startswith("attn_")}       # roofline.frac / achieved stay the ALL-GEMM figure
+        tot_ms = sum(d["ms"] for d in gemm.values())
+        tot_fl = sum(d["flops"] for d in gemm.values())
+        n = sum(d["launches"] for d in gemm.values())
         return dict(launches=n, total_ms=tot_ms, avg_ms=tot_ms / max(n, 1), tflops=tot_fl / max(tot_ms, 1e-9) / 1e9,
-                    flops=tot_fl, alg_bytes=sum(d["alg_bytes"] for d in by.values()), by_kernel=by)
+                    flops=tot_fl, alg_bytes=sum(d["alg_bytes"] for d in gemm.values()), by_kernel=by)
 
 
 def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
@@ -323,6 +358,8 @@ def main():
         one_step()
     timer = GemmTimer()
     if not args.no_gemm_timer:
+        if getattr(model, "last_out", None) is not None:
+            GemmTimer.set_attention_plan(model.last_out.plan)      # the batch (hence the plan) is the same in every step
         timer.install()
     import gc
     gc.collect()
@@ -565,12 +602,17 @@ def main():
                      "nn_lora": "gemm_nn_a64_kernel<EpiStore, EXT> (rv_gemm_nn_lora_bf16)",
                      "nn_lora_pre": "gemm_nn_a64_kernel<EpiStore, PRE> (rv_gemm_nn_lora_pre_bf16)",
                      "lmhead_fwd": "gemm_nt_256_kernel<EpiLogpFwd> (rv_lmhead_logp_fwd)",
-                     "lmhead_bwd": "gemm_nt_256_kernel<EpiLogpBwd> (rv_lmhead_logp_bwd)"}
+                     "lmhead_bwd": "gemm_nt_256_kernel<EpiLogpBwd> (rv_lmhead_logp_bwd)",
+                     "attn_fwd": "attn_fwd2_kernel (rv_attn_fwd: decoder packed-causal rows + the CLIP tower's full rows); algorithmic 4 hd "
+                                 "flop per visible (query, key) pair and head",
+                     "attn_bwd": "attn_bwd_dq2_kernel + attn_bwd_dkv5_kernel (rv_attn_bwd, two launches timed together); algorithmic 10 hd "
+                                 "flop per visible pair and head (the pair of launches executes 14 hd: S and dP are recomputed in both)"}
             by = {k: dict(kernel=KNAME.get(k, k), launches=d["launches"], avg_launch_ms=d["avg_ms"], ms_per_step=d["ms"] / args.steps,
                           achieved=d["tflops"], frac=d["tflops"] / PEAK_BF16_TFLOPS,
                           alg_bytes_per_launch=d["alg_bytes"] / max(d["launches"], 1))
                   for k, d in sorted(g["by_kernel"].items(), key=lambda kv: -kv[1]["ms"])}
-            dom = next(iter(by)) if by else None
+            dom = next((k for k in by if not k.startswith("attn_")), None)      # the dominant kernel is a GEMM class (75 % of GPU time)
+            weakest = min((k for k in by if by[k]["ms_per_step"] >= 5.0), key=lambda k: by[k]["frac"], default=None)
             line["roofline"] = {"bound": "mfma",
                                 "kernel": "ALL MFMA GEMM launches of the step (plain NN / TN / NT, SwiGLU-epilogue NN forward and "
                                           "backward, fused LM-head log-prob forward and backward, fused-LoRA forms): 256x256 ping-pong tiles",
@@ -581,6 +623,7 @@ def main():
                                                  "null: no PMC pass was collected on this workload (the committed passes are the headline config's); ")
                                                 + "algorithmic operand+result bytes per launch: " + f"{g['alg_bytes'] / max(g['launches'], 1):.3e}",
                                 "dominant": dict(by[dom], label=dom) if dom else None,
+                                "weakest_mfma_kernel": dict(by[weakest], label=weakest) if weakest else None,
                                 "by_kernel": by,
                                 "power_capped_mfma_ceiling": {"tflops": 1953.0, "frac": g["tflops"] / 1953.0,
                                                               "note": "pure register-operand v_mfma_f32_16x16x32_bf16 loop on all 256 CUs "

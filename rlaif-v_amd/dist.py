@@ -67,10 +67,19 @@ class BucketedAllReduce(GradReducer):
                should RCCL's persistent workgroups disturb the 256-workgroup GEMMs they run beside (two LDS-filling GEMMs side
                by side broke each other's XCD lockstep: 1.7-3.6 x, profiles/r03_wgrad_side_stream_negative_result.log);
       skip     no collective at all (WRONG gradients for world > 1: measurement only - step time without communication).
-    ``timeline``: per-bucket (bytes, enqueue, complete) from device events, see ``last_timeline``."""
+    ``timeline``: per-bucket (bytes, enqueue, complete) from device events, see ``last_timeline``.
+
+    reduce_dtype (env RV_GRAD_REDUCE_DTYPE = "bf16" | "fp32", default the buffer's own dtype): the arithmetic of the cross-rank SUM.
+      buffer dtype (bf16 on the device)  the collective sums the bf16 gradients as they lie: RCCL's ring adds in bf16, i.e. the
+               sum of N ranks is rounded N - 1 times (DeepSpeed ZeRO-2 under --bf16 reduces bf16 gradients the same way);
+      fp32     every bucket is widened to an fp32 staging buffer (a dtype-converting copy), summed in fp32 by the collective, and
+               rounded ONCE when it is copied back in finish(): twice the bytes on the wire and 2 x the bucket in staging memory
+               while a bucket is in flight, for a sum that equals the exact one rounded to bf16 up to fp32 accumulation.  The
+               two agree bit for bit at world size 2 (one addition, one rounding either way) and differ from 3 ranks on
+               (tests/test_dist_gloo.py::test_fp32_gradient_sum_world3 measures both against the float64 sum)."""
 
     def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 400 << 20, force: bool = False,
-                 mode: Optional[str] = None, timeline: bool = False):
+                 mode: Optional[str] = None, timeline: bool = False, reduce_dtype: Optional[str] = None):
         self.flat = flat_grad
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -80,6 +89,11 @@ class BucketedAllReduce(GradReducer):
         if self.mode not in ("overlap", "serial", "skip"):
             raise ValueError(f"RV_ALLREDUCE_MODE must be overlap | serial | skip, got {self.mode!r}")
         self.timeline = bool(timeline) and flat_grad.is_cuda
+        rd = (reduce_dtype or os.environ.get("RV_GRAD_REDUCE_DTYPE") or "").lower()
+        if rd not in ("", "bf16", "fp32"):
+            raise ValueError(f"RV_GRAD_REDUCE_DTYPE must be bf16 | fp32, got {rd!r}")
+        self.widen = rd == "fp32" and flat_grad.dtype != torch.float32
+        self._staged: List = []                        # (start, end, fp32 staging tensor) of the buckets in flight (widen only)
         self._pending: Optional[Tuple[int, int]] = None
         self._works: List = []
         self._events: List = []                        # (bytes, enqueue event, completion event) per collective
@@ -97,11 +111,19 @@ class BucketedAllReduce(GradReducer):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()                              # compute stream: the bucket's gradients are final here
             self._events.append(((end - start) * self.flat.element_size(), ev[0], ev[1]))
-        w = dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        buf = self.flat[start:end]
+        if self.widen:                                  # fp32 sum: widen -> all-reduce fp32 -> round once on the way back (finish)
+            buf = torch.empty(end - start, dtype=torch.float32, device=self.flat.device)
+            buf.copy_(self.flat[start:end])
+            self._staged.append((start, end, buf))
+        w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.mode == "serial":
             w.wait()                                    # the compute stream waits: nothing of backward runs beside the collective
             if ev is not None:
                 ev[1].record()
+            if self.widen:
+                a, b, t = self._staged.pop()
+                self.flat[a:b].copy_(t)
         else:
             self._works.append(w)
 
@@ -129,6 +151,9 @@ class BucketedAllReduce(GradReducer):
             w.wait()                                    # collectives of one communicator complete in order
             if self.timeline:
                 self._events[i][2].record()
+        for a, b, t in self._staged:                    # (overlap mode) stream-ordered behind the waits above: one rounding to bf16
+            self.flat[a:b].copy_(t)
+        self._staged = []
         self._works = []
         if self.timeline and self._events:
             self._timeline_pending = (self._events, t_end)

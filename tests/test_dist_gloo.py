@@ -101,3 +101,54 @@ def test_bucketed_allreduce_gloo_world2(lora):
     for rank, ok_sum, ok_metric, ok_again, ok_shard, n in res:
         assert ok_sum and ok_metric and ok_again and ok_shard, (rank, ok_sum, ok_metric, ok_again, ok_shard)
         assert n >= 2
+
+
+def _worker_sum(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from rlaif_v_amd.dist import BucketedAllReduce, init_process_group_from_env
+    init_process_group_from_env("gloo")
+    n = 1 << 16
+    locals_ = [(torch.randn(n, generator=torch.Generator().manual_seed(7 + k)) * (1.0 + k)).to(torch.bfloat16) for k in range(world)]
+    exact = sum(t.double() for t in locals_)
+    out = {}
+    for rd in ("bf16", "fp32"):
+        for mode in ("overlap", "serial"):
+            flat = locals_[rank].clone()
+            red = BucketedAllReduce(flat, bucket_bytes=1 << 14, mode=mode, reduce_dtype=rd)
+            for a in range(0, n, 5000):
+                red.on_bucket_ready("x", a, min(a + 5000, n))
+            red.finish()
+            assert flat.dtype == torch.bfloat16 and not red._staged
+            out[(rd, mode)] = flat
+    ok_modes = torch.equal(out[("bf16", "overlap")], out[("bf16", "serial")]) and torch.equal(out[("fp32", "overlap")], out[("fp32", "serial")])
+    once = exact.to(torch.bfloat16)                     # the exact sum rounded ONCE
+    err = {rd: float((out[(rd, "overlap")].double() - exact).abs().mean()) for rd in ("bf16", "fp32")}
+    q.put((rank, ok_modes, bool(torch.equal(out[("fp32", "overlap")], once)), err["bf16"], err["fp32"],
+           int((out[("bf16", "overlap")] != once).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_fp32_gradient_sum_world3(world):
+    """RV_GRAD_REDUCE_DTYPE=fp32: bf16 gradient buckets widened to fp32 for the cross-rank SUM and rounded once.
+    World 2: one addition, one rounding either way - both sums are the exact sum rounded once, bit for bit.  World 3: the fp32 sum
+    still is; the bf16 ring sum (two roundings) is measurably further from the float64 sum."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sum, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_modes, fp32_is_exact_once, e_bf16, e_fp32, n_diff in res:
+        assert ok_modes and fp32_is_exact_once, (rank, ok_modes, fp32_is_exact_once)
+        if world == 2:
+            assert n_diff == 0
+        else:
+            assert n_diff > 0 and e_fp32 < e_bf16, (n_diff, e_bf16, e_fp32)

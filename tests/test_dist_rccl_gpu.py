@@ -105,6 +105,16 @@ def _two_rank_worker(rank, world, port, q):
     red.finish()
     torch.cuda.synchronize()
     g_dp = model.store.flat_g.float() / w
+    # the same exchange with the SUM carried in fp32 (RV_GRAD_REDUCE_DTYPE=fp32): at world size 2 one addition and
+    # one rounding either way -> bit-identical to the bf16 sum; from 3 ranks on it is the closer one (tests/test_dist_gloo.py)
+    red32 = BucketedAllReduce(model.store.flat_g, bucket_bytes=1 << 20, reduce_dtype="fp32")
+    tr.reducer, tr._reduce_hook = red32, red32.on_bucket_ready
+    tr.compute_loss(model, dict(shards[rank]))
+    model.backward(model.last_out, model.last_coef)
+    red32.finish()
+    torch.cuda.synchronize()
+    same_sum = bool(torch.equal(model.store.flat_g.float() / w, g_dp)) if w == 2 else True
+    tr.reducer, tr._reduce_hook = red, red.on_bucket_ready
     union = _cat_batches(shards)
     model.grad_ready_hook = None                          # single-process reference: no exchange
     tr.compute_loss(model, dict(union))
@@ -126,7 +136,7 @@ def _two_rank_worker(rank, world, port, q):
     dist.all_gather(other, mine)
     same = all(torch.equal(other[0], t) for t in other)
     moved = float((mine != start).float().mean())        # fraction of fp32 masters the two steps moved
-    q.put((rank, same, float(loss), len(m), moved, cos, nrel))
+    q.put((rank, same and same_sum, float(loss), len(m), moved, cos, nrel))
     dist.barrier()
     dist.destroy_process_group()
 
