@@ -52,6 +52,9 @@ __device__ __forceinline__ void mfma_agpr_zero(f32x16_t& acc) {
 #ifndef RV_ATTN_PERMLANE
 #define RV_ATTN_PERMLANE 1
 #endif
+#ifndef RV_ATTN_FWD_NW_DEFAULT
+#define RV_ATTN_FWD_NW_DEFAULT 4
+#endif
 __device__ __forceinline__ void xhalf_pair(float x, float& a, float& b) {
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
   const unsigned u = __builtin_bit_cast(unsigned, x);
@@ -137,7 +140,7 @@ __device__ __forceinline__ void attn_block_coords(int nx, int H, int S, int& x, 
 // KEYS = false: query blocks (forward, dQ); true: key blocks (dK / dV).  n > 64 or bit 20 of nx clear: plain pairing.
 // single = true (bit 21 of nx; the launcher then starts ONE workgroup per block): workgroup bx takes the block of rank bx
 // alone - twice as many, half as long workgroups in strict longest-first order, so the tail of the launch is one LIGHT block.
-template <bool KEYS>
+template <bool KEYS, int BS = 128>
 __device__ __forceinline__ void pair_blocks(int bx, int n, int L, int sh, int e1, int lane, bool balanced, bool single,
                                             int& first, int& second) {
   if (!balanced || n > 64) {
@@ -145,14 +148,14 @@ __device__ __forceinline__ void pair_blocks(int bx, int n, int L, int sh, int e1
     second = (!single && n - 1 - bx > bx) ? n - 1 - bx : -1;
     return;
   }
-  const int x = lane, b0 = x * 128;
+  const int x = lane, b0 = x * BS;
   int w;
   if (!KEYS) {
-    const int nt = (min(L, b0 + 128) + 63) >> 6;
+    const int nt = (min(L, b0 + BS) + 63) >> 6;
     const int skip = (b0 >= e1 && e1 > sh) ? max((e1 >> 6) - ((sh + 63) >> 6), 0) : 0;
     w = nt - skip;
   } else {
-    const int nt = (b0 >= sh && b0 + 127 < e1) ? min((L + 63) >> 6, (e1 + 63) >> 6) : (L + 63) >> 6;
+    const int nt = (b0 >= sh && b0 + BS - 1 < e1) ? min((L + 63) >> 6, (e1 + 63) >> 6) : (L + 63) >> 6;
     w = nt - (b0 >> 6);
   }
   if (x >= n) w = -1;
@@ -307,8 +310,12 @@ struct TileDma {
 #endif
 #define RV_ATTN_FWD_PRIO 1     // 1 = s_setprio 1 in the QK^T / PV MFMA phases (measured -0.5..-3 % vs 0, profiles/r02_attn_fwd_prio.log); 2 = in the softmax section (+1..2 %)
 #endif
-template <int HD, bool CAUSAL, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
+// NW = waves per workgroup = 32-query slices that share one K / V ring (round 5).  NW = 4: 128 queries, two workgroups per CU
+// (rounds 1-4).  NW = 8: 256 queries, ONE workgroup per CU - every K / V tile is staged once per 256 queries, i.e. HALF the LDS-DMA
+// instructions per CU and key tile (each wave issues 4 instead of 8): the phase stamps of round 4 put 18 % of a tile in those issues,
+// which the CU's address path serves one wave-instruction at a time (profiles/r04_attn_fwd_dq_phase_profile.log).
+template <int HD, bool CAUSAL, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, long ld, int q_col0,
                                                            int k_col0, int v_col0, bf16_t* __restrict__ out, long ldo,
                                                            float* __restrict__ lse, int Lmax, int H, int nx, float scale,
                                                            const int* __restrict__ seg_sh,
@@ -327,13 +334,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   // stride.  The grid is sized for Lmax: workgroups beyond this row's last block (pair) leave at once (varlen_done).
   const int L = row_len ? row_len[s] : Lmax;
   const long tok0 = row_off ? (long)row_off[s] : (long)s * Lmax;
-  const int nqb = (L + 127) / 128;
+  constexpr int BQ = 32 * NW;                     // queries per workgroup block
+  const int nqb = (L + BQ - 1) / BQ;
   if (varlen_done(bx, nqb, CAUSAL && !((nx >> 21) & 1))) return;
   // packed (chosen | rejected) rows: queries at index >= e1 (the rejected branch) do not see keys in [sh, e1)
   const int sh = seg_sh ? seg_sh[s] : 0, e1 = seg_e1 ? seg_e1[s] : 0;
   const float c = scale * LOG2E;
 
-  TileDma<HD> dma;
+  TileDma<HD, NW> dma;
   dma.init(wave, lane, ld);
   TrOffsets<HD> tro;
   tro.init(lane);
@@ -344,13 +352,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   const bf16_t* vbase = qkv + v_col0 + (h / kv_group) * HD;
 
   int blk_first, blk_second;
-  pair_blocks<false>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
+  pair_blocks<false, BQ>(bx, nqb, L, sh, e1, lane, CAUSAL && ((nx >> 20) & 1), CAUSAL && ((nx >> 21) & 1), blk_first, blk_second);
   APROF_DECL
   const int npass = CAUSAL ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     const int qb = (pass == 0) ? blk_first : blk_second;
     if (qb < 0) break;
-    const int q0 = qb * 128, q0w = q0 + wave * 32;
+    const int q0 = qb * BQ, q0w = q0 + wave * 32;
     const int q = q0w + fr;
     QueryLaneMask<CAUSAL> qmask;
     qmask.init(q, L, sh, e1);
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     for (int e = 0; e < ET; ++e) zero16(o[e]);
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int kv_end = CAUSAL ? min(L, q0 + 128) : L;
+    const int kv_end = CAUSAL ? min(L, q0 + BQ) : L;
     const int nt = (kv_end + 63) / 64;
     // A query block that lies entirely in the rejected branch never sees the key tiles that lie entirely in the chosen
     // branch [sh, e1): those tiles are not fetched at all (block-uniform: DMA and barriers are workgroup-wide).  The loop
@@ -1577,16 +1585,21 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   static int map_mode = -1;
   if (map_mode < 0) { const char* e = getenv("RV_ATTN_MAP"); map_mode = e ? atoi(e) : 1; }
   hipStream_t st = (hipStream_t)stream;
-  const int nb = (L + 127) / 128;
+  static int fwd_nw = -1;         // RV_ATTN_FWD_NW: 4 = 128-query workgroups (two per CU), 8 = 256-query workgroups on one K / V ring (hd 128)
+  if (fwd_nw < 0) { const char* e = getenv("RV_ATTN_FWD_NW"); fwd_nw = (e && atoi(e) == 8) ? 8 : RV_ATTN_FWD_NW_DEFAULT; }
+  const int nw = (hd == 128) ? fwd_nw : 4;
+  const int nb = (L + 32 * nw - 1) / (32 * nw);
   static int pair_mode = -1;      // RV_ATTN_PAIR: 0 = the plain (x, n-1-x) pairing, 1 = pair_blocks (ranked pairs), 2 = one ranked block per workgroup
   if (pair_mode < 0) { const char* e = getenv("RV_ATTN_PAIR"); pair_mode = e ? atoi(e) : 1; }
   const int nxr = (causal && pair_mode != 2) ? (nb + 1) / 2 : nb;
   const int nx = nxr | (map_mode << 16) | ((pair_mode ? 1 : 0) << 20) | ((causal && pair_mode == 2 ? 1 : 0) << 21);
-  dim3 grid(nxr * H * S), block(256);
+  dim3 grid(nxr * H * S), block(64 * nw);
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, false, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr_done = true;
   }
 #define LAUNCH_FWD(HD_, C_)                                                                                      \
@@ -1606,7 +1619,14 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   LAUNCH_FWD_ABL(1) LAUNCH_FWD_ABL(2) LAUNCH_FWD_ABL(3) LAUNCH_FWD_ABL(6)
 #undef LAUNCH_FWD_ABL
 #endif
-  if (hd == 128) { if (causal) LAUNCH_FWD(128, true); else LAUNCH_FWD(128, false); }
+  if (hd == 128 && nw == 8) {
+    if (causal)
+      hipLaunchKernelGGL((attn_fwd2_kernel<128, true, 0, 8>), grid, block, 4 * 64 * 128 * 2, st, (const bf16_t*)qkv, ld, q_col0, k_col0,
+                         v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group, row_off, row_len);
+    else
+      hipLaunchKernelGGL((attn_fwd2_kernel<128, false, 0, 8>), grid, block, 4 * 64 * 128 * 2, st, (const bf16_t*)qkv, ld, q_col0, k_col0,
+                         v_col0, (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group, row_off, row_len);
+  } else if (hd == 128) { if (causal) LAUNCH_FWD(128, true); else LAUNCH_FWD(128, false); }
   else { if (causal) LAUNCH_FWD(64, true); else LAUNCH_FWD(64, false); }
 #undef LAUNCH_FWD
   RV_CHECK_LAUNCH();
