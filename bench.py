@@ -288,7 +288,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))                 # no launcher: spawn one rank per GPU ourselves
-    from rlaif_v_amd.dist import init_process_group_from_env, BucketedAllReduce
+    from rlaif_v_amd.dist import init_process_group_from_env, BucketedAllReduce, make_reducer
     rccl_log = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.no_dp_diag:
         # RCCL's own account of what it built (ranks, channels, transport) per rank -> parsed into dp_diag below
@@ -330,7 +330,7 @@ def main():
         cfg = LlavaConfig(layers=args.layers, model_max_length=L)
         model = LlavaDPOModel(cfg, device=dev, lora=lora)
     model.init_random(seed=0)            # identical weights on every rank
-    reducer = BucketedAllReduce(model.store.flat_g) if world > 1 else None
+    reducer = make_reducer(model.store.flat_g) if world > 1 else None      # RV_ZERO1=1: opt-in sharded optimizer
     targs = TrainingArguments(max_steps=1000, per_device_train_batch_size=B, lora_enable=args.lora,
                               lora_r=args.lora_r, learning_rate=1e-5 if args.lora else 5e-7,
                               gradient_checkpointing=args.gradient_checkpointing)
@@ -383,7 +383,10 @@ def main():
     dt = float(t.item())
 
     dp_diag = None
-    if world > 1 and not args.no_dp_diag:
+    zero1 = getattr(reducer, "sharded", False)
+    if world > 1 and zero1:
+        dp_diag = dict(skipped="RV_ZERO1=1: the three-mode re-timing swaps in the replicated reducer, whose optimizer state this run freed")
+    if world > 1 and not args.no_dp_diag and not zero1:
         # The first N-GPU run explains itself: nothing below touches the timed region above.
         #   * the same step re-timed (median of 3, max over ranks) with the gradient exchange overlapped (the default), SERIALISED on
         #     the compute stream, and SKIPPED: exposed communication = overlap - skip, what overlap buys = serial - overlap;
@@ -564,7 +567,7 @@ def main():
                                    + f" DPO step, {cfg.image_size}px, seq_len={L}" + (" (maximum; RAGGED answer lengths)" if args.ragged else "")
                                    + f", {B} pairs/GPU, random-init weights",
                        "pairs_per_gpu": B, "global_batch_pairs": B * world, "seq_len": L, "llm_layers": args.layers,
-                       "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0",
+                       "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master + clip 1.0" + (" (ZeRO-1: state and update sharded over the ranks)" if getattr(reducer, "sharded", False) else ""),
                        "trainable_params": int(model.store.n_train),
                        "gradient_checkpointing": bool(args.gradient_checkpointing), "shared_prefix_reuse": bool(model.share_prefix)},
             "loss": float(loss), "max_memory_allocated_gb": torch.cuda.max_memory_allocated() / 2**30,

@@ -275,6 +275,13 @@ int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float pr
                  void* stream);
 int rv_adamw_step(void* p, float* master, float* m, float* v, const void* g, long n, float lr, float beta1, float beta2,
                   float eps, float wd, int step, const float* clip, void* stream);
+/* The two halves of rv_grad_norm for a SHARDED optimizer (opt-in ZeRO-1, rlaif-v_amd/dist.py ShardedGradReducer; the reference
+ * shards its optimizer the same way under DeepSpeed ZeRO-2, script/zero2.json:16-22): each rank holds the reduced gradient of its
+ * shard only.  rv_grad_sumsq: out1[0] (+)= sum g^2 over a bf16 slice (partial: rv_sumsq_nblocks floats of scratch); the caller
+ * all-reduces out1 over the ranks; rv_clip_from_sumsq: out2 = [pre_scale * sqrt(sumsq), pre_scale * min(1, max_norm / (that + 1e-6))],
+ * the pair rv_grad_norm produces. */
+int rv_grad_sumsq(const void* g, long n, float* partial, float* out1, int accumulate, void* stream);
+int rv_clip_from_sumsq(const float* sumsq, float max_norm, float pre_scale, float* out2, void* stream);
 /* --gradient_accumulation_steps (HF Trainer, script/train/llava15_train.sh:23): fp32 accumulation of the bf16 micro-batch
  * gradients.  mode 0: acc = g;  1: acc += g;  2: g = bf16((acc + g) * scale)  (scale = 1 / accumulation steps). */
 int rv_grad_accum(float* acc, void* g, long n, int mode, float scale, void* stream);

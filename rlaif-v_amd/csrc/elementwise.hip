@@ -732,6 +732,21 @@ __global__ void gradnorm_finish_kernel(const float* __restrict__ partial, int np
   }
 }
 
+// ZeRO-1 (sharded optimizer, dist.ShardedGradReducer): every rank holds the reduced gradient of ITS shard only, so the global norm is
+// sum-of-squares per rank -> one-float all-reduce -> clip factor.  out1[0] (+)= sum of the block partials.
+__global__ void sumsq_finish_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ out1, int accumulate) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out1[0] = accumulate ? out1[0] + s : s;
+}
+__global__ void clip_from_sumsq_kernel(const float* __restrict__ sumsq, float max_norm, float pre_scale, float* __restrict__ out) {
+  const float nrm = sqrtf(sumsq[0]) * pre_scale;          // same arithmetic as gradnorm_finish_kernel
+  out[0] = nrm;
+  out[1] = pre_scale * ((max_norm > 0.f) ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f);
+}
+
 // Gradient accumulation over micro-batches (HF Trainer --gradient_accumulation_steps): fp32 side buffer.
 //   mode 0: acc = g            (first micro-batch: no zeroing pass)
 //   mode 1: acc += g           (middle micro-batches)
@@ -1238,6 +1253,21 @@ int rv_grad_norm(const void* g, long n, float* partial, float max_norm, float pr
   RV_CHECK_LAUNCH();
   hipLaunchKernelGGL(gradnorm_finish_kernel, dim3(1), dim3(256), 0, STREAM(stream), partial, 1024, max_norm, pre_scale,
                      out2);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_grad_sumsq(const void* g, long n, float* partial, float* out1, int accumulate, void* stream) {
+  RV_REQUIRE(n % 8 == 0, "rv_grad_sumsq: n%8");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, STREAM(stream), (const bf16_t*)g, n / 8, partial);
+  RV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, STREAM(stream), partial, 1024, out1, accumulate);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_clip_from_sumsq(const float* sumsq, float max_norm, float pre_scale, float* out2, void* stream) {
+  hipLaunchKernelGGL(clip_from_sumsq_kernel, dim3(1), dim3(1), 0, STREAM(stream), sumsq, max_norm, pre_scale, out2);
   RV_CHECK_LAUNCH();
   return 0;
 }

@@ -191,3 +191,254 @@ class BucketedAllReduce(GradReducer):
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t / self.world_size
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Opt-in ZeRO-1: sharded optimizer.  The reference trains under DeepSpeed ZeRO-2 (script/zero2.json:16-22,
+# script/train/llava15_train.sh:6): gradients reduce-scattered, optimizer state partitioned, updated parameters all-gathered.
+# On 288 GB parts nothing FORCES the partition (replicated state: 108 GB), so the replicated BucketedAllReduce stays the default
+# until a hardware A/B exists; what the partition buys is (N - 1) / N of the AdamW pass per step (32 ms of HBM streaming at
+# N = 1: ~3 % of a step at N = 8) and (N - 1) / N of the 81 GB of fp32 state.  Bytes on the wire are those of the all-reduce it
+# replaces: reduce-scatter (N - 1) / N x G  +  all-gather (N - 1) / N x P, with G = P = 13.5 GB of bf16.
+# ----------------------------------------------------------------------------------------------------------------------
+class ShardedGradReducer(BucketedAllReduce):
+    """The bucket schedule of BucketedAllReduce with a REDUCE-SCATTER per launched range [a, b): c = floor((b - a) / (8 W)) * 8
+    elements per rank, rank r receives the SUM of chunk [a + r c, a + (r + 1) c) into its compact ``g_shard`` (at a running
+    offset), asynchronously on RCCL's stream like the all-reduce it replaces.  The < 8 W + 8 trailing elements of a range that do
+    not divide (``remainders``) are summed by ONE small all-reduce in finish() and handled redundantly by every rank - no padding,
+    no staging copy, no collective ever reads or writes outside [a, b)."""
+    sharded = True
+
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 400 << 20, force: bool = False,
+                 mode: Optional[str] = None):
+        super().__init__(flat_grad, group=group, bucket_bytes=bucket_bytes, force=force, mode=mode, reduce_dtype=None)
+        if self.widen:
+            raise ValueError("RV_GRAD_REDUCE_DTYPE=fp32 is implemented for the replicated all-reduce only")
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collective = dist.is_initialized() and (self.world_size > 1 or force)     # else: one rank, plain copies
+        W = self.world_size
+        self.g_shard = torch.zeros(flat_grad.numel() // W + 8 * 1024, dtype=flat_grad.dtype, device=flat_grad.device)
+        self.ranges: List[Tuple[int, int, int, int]] = []          # (a, b, c, offset into g_shard) of the LAST completed step
+        self._step_ranges: List[Tuple[int, int, int, int]] = []
+        self._off = 0
+        self.rem_buf: Optional[torch.Tensor] = None               # packed reduced remainders of the last completed step
+        self.rem_spans: List[Tuple[int, int]] = []
+
+    def split(self, start: int, end: int) -> int:
+        return ((end - start) // (8 * self.world_size)) * 8
+
+    def plan(self, schedule) -> List[Tuple[int, int, int, int]]:
+        """The ranges a step will launch for ``schedule`` = [(name, start, end), ...] (dry run of the merging logic)."""
+        out, pending, off = [], None, 0
+
+        def launch(a, b):
+            nonlocal off
+            c = self.split(a, b)
+            out.append((a, b, c, off))
+            off += c
+        for _, a, b in schedule:
+            if pending is not None and pending[1] == a:
+                a = pending[0]
+            elif pending is not None:
+                launch(*pending)
+            pending = (a, b)
+            if b - a >= self.bucket_elems:
+                launch(a, b)
+                pending = None
+        if pending is not None:
+            launch(*pending)
+        return out
+
+    def _launch(self, start: int, end: int):
+        if end <= start:
+            return
+        c = self.split(start, end)
+        self._step_ranges.append((start, end, c, self._off))
+        self.launched.append((start, end))
+        off, self._off = self._off, self._off + c
+        if self.mode == "skip" or c == 0:
+            return
+        W = self.world_size
+        if not self.collective:
+            self.g_shard[off:off + c].copy_(self.flat[start:start + c])
+            return
+        w = dist.reduce_scatter_tensor(self.g_shard[off:off + c], self.flat[start:start + W * c], op=dist.ReduceOp.SUM,
+                                       group=self.group, async_op=True)
+        if self.mode == "serial":
+            w.wait()
+        else:
+            self._works.append(w)
+
+    def finish(self):
+        if self._pending is not None:
+            self._launch(*self._pending)
+            self._pending = None
+        for w in self._works:
+            w.wait()
+        self._works = []
+        W = self.world_size
+        spans = [(a + W * c, b) for a, b, c, _ in self._step_ranges if b > a + W * c]
+        if spans and self.mode != "skip" and self.collective:
+            buf = torch.cat([self.flat[x:y] for x, y in spans])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.rem_buf = buf
+        else:
+            self.rem_buf = torch.cat([self.flat[x:y] for x, y in spans]) if spans else self.flat[:0]
+        self.rem_spans = spans
+        if self._step_ranges:
+            self.ranges = self._step_ranges
+        self._step_ranges, self._off = [], 0
+        done, self.launched = self.launched, []
+        return done
+
+
+def make_reducer(flat_grad: torch.Tensor, **kw) -> GradReducer:
+    """The gradient exchange the environment selects: RV_ZERO1=1 -> ShardedGradReducer (opt-in ZeRO-1: reduce-scatter + sharded
+    AdamW + parameter all-gather), else the replicated BucketedAllReduce (default)."""
+    if os.environ.get("RV_ZERO1", "0") not in ("", "0"):
+        return ShardedGradReducer(flat_grad, **kw)
+    return BucketedAllReduce(flat_grad, **kw)
+
+
+class _DeviceOptKernels:
+    """The HIP kernels of the optimizer (rlaif-v_amd/ops.py); tests/test_dist_gloo.py substitutes CPU stand-ins with the same
+    signatures to drive the partition / exchange logic under gloo."""
+
+    @staticmethod
+    def sumsq(g, out1, accumulate):
+        from . import ops
+        ops.grad_sumsq(g, out1, accumulate)
+
+    @staticmethod
+    def clip(sumsq, max_norm, out2, pre_scale):
+        from . import ops
+        ops.clip_from_sumsq(sumsq, max_norm, out2, pre_scale)
+
+    @staticmethod
+    def adamw(p, master, m, v, g, lr, b1, b2, eps, wd, step, clip):
+        from . import ops
+        ops.adamw_step(p, master, m, v, g, lr, b1, b2, eps, wd, step, clip=clip)
+
+    @staticmethod
+    def to_param(master, p):
+        from . import ops
+        ops.cast_f32_to_bf16(master, p)
+
+
+class ShardedAdamW:
+    """AdamW + clip_grad_norm_ on 1 / W of the parameters (the chunks ShardedGradReducer hands this rank) followed by an in-place
+    all-gather of the updated bf16 parameters, issued in FORWARD order (embedding / projector, layer 0, ... lm_head = the reverse
+    of backward's completion order) so that the parameters the next step needs first arrive first.
+    Elementwise arithmetic identical to the replicated path (same kernels on the same values); the only difference is the
+    summation order of the global gradient norm (per-rank partial sums), i.e. the clip factor agrees to fp32 rounding and is
+    IDENTICAL whenever clipping is inactive (norm <= max_grad_norm)."""
+
+    def __init__(self, train_p: torch.Tensor, n_decay: int, reducer: ShardedGradReducer, schedule, kernels=None,
+                 full_state: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
+        self.p, self.n_decay, self.red, self.k = train_p, n_decay, reducer, kernels or _DeviceOptKernels
+        self.W, self.rank = reducer.world_size, reducer.rank
+        self.ranges = reducer.plan(schedule)
+        W = self.W
+        self.rem_spans = [(a + W * c, b) for a, b, c, _ in self.ranges if b > a + W * c]
+        n_shard = sum(c for _, _, c, _ in self.ranges)
+        n_rem = sum(y - x for x, y in self.rem_spans)
+        dev = train_p.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.master, self.m, self.v = torch.zeros(n_shard, **f32), torch.zeros(n_shard, **f32), torch.zeros(n_shard, **f32)
+        self.rem_master, self.rem_m, self.rem_v = torch.zeros(n_rem, **f32), torch.zeros(n_rem, **f32), torch.zeros(n_rem, **f32)
+        self._sumsq = torch.zeros(1, **f32)
+        if full_state is not None:
+            self.load_full_state(*full_state)
+        else:
+            self.sync_master_from_params()
+
+    # ---- this rank's chunk of a range, as (lo, hi) in trainable-relative indices
+    def _mine(self, a, c):
+        return a + self.rank * c, a + (self.rank + 1) * c
+
+    def sync_master_from_params(self):
+        for a, b, c, off in self.ranges:
+            lo, hi = self._mine(a, c)
+            self.master[off:off + c].copy_(self.p[lo:hi])
+        o = 0
+        for x, y in self.rem_spans:
+            self.rem_master[o:o + y - x].copy_(self.p[x:y])
+            o += y - x
+
+    def _decay_pieces(self, lo, hi):
+        """[lo, hi) split at the weight-decay boundary: (lo, hi, has_decay)"""
+        nd = self.n_decay
+        if hi <= nd:
+            return [(lo, hi, True)]
+        if lo >= nd:
+            return [(lo, hi, False)]
+        return [(lo, nd, True), (nd, hi, False)]
+
+    def step(self, lr, b1, b2, eps, wd, step, max_norm, clip_out: torch.Tensor):
+        red, k, W = self.red, self.k, self.W
+        if [(a, b, c) for a, b, c, _ in red.ranges] != [(a, b, c) for a, b, c, _ in self.ranges]:
+            raise RuntimeError("the step's gradient ranges differ from the optimizer's partition (bucket schedule changed?)")
+        n_shard = self.master.numel()
+        # ---- global gradient norm: local sum of squares (+ the replicated remainders, counted once: on rank 0) -> 1-float all-reduce
+        k.sumsq(red.g_shard[:n_shard], self._sumsq, False)
+        if self.rank == 0 and red.rem_buf.numel():
+            k.sumsq(red.rem_buf, self._sumsq, True)
+        if red.collective:
+            dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=red.group)
+        k.clip(self._sumsq, max_norm, clip_out, 1.0 / W)
+        # ---- AdamW on this rank's chunks and on the replicated remainders
+        for a, b, c, off in self.ranges:
+            lo, hi = self._mine(a, c)
+            for x, y, dec in self._decay_pieces(lo, hi):
+                s = slice(off + x - lo, off + y - lo)
+                k.adamw(self.p[x:y], self.master[s], self.m[s], self.v[s], red.g_shard[s], lr, b1, b2, eps, wd if dec else 0.0, step, clip_out)
+        o = 0
+        for x0, y0 in self.rem_spans:
+            for x, y, dec in self._decay_pieces(x0, y0):
+                s = slice(o + x - x0, o + y - x0)
+                k.adamw(self.p[x:y], self.rem_master[s], self.rem_m[s], self.rem_v[s], red.rem_buf[s], lr, b1, b2, eps, wd if dec else 0.0,
+                        step, clip_out)
+            o += y0 - x0
+        # ---- updated bf16 parameters back to every rank: in-place all-gather per range, forward order
+        works = []
+        if red.collective:
+            for a, b, c, off in reversed(self.ranges):
+                if c == 0:
+                    continue
+                lo, hi = self._mine(a, c)
+                works.append(dist.all_gather_into_tensor(self.p[a:a + W * c], self.p[lo:hi], group=red.group, async_op=True))
+        for w in works:
+            w.wait()
+
+    # ---- checkpoints keep the REPLICATED format (full master / m / v in flat order): a sharded run resumes a replicated one and back
+    def gather_full_state(self):
+        """(master, m, v) as full fp32 CPU tensors [n_train] on every rank (collective: all ranks must call)."""
+        W, n = self.W, self.p.numel()
+        out = []
+        for shard, rem in ((self.master, self.rem_master), (self.m, self.rem_m), (self.v, self.rem_v)):
+            full = torch.zeros(n, dtype=torch.float32)
+            for a, b, c, off in self.ranges:
+                if c == 0:
+                    continue
+                tmp = torch.empty(W * c, dtype=torch.float32, device=shard.device)
+                if self.red.collective:
+                    dist.all_gather_into_tensor(tmp, shard[off:off + c].contiguous(), group=self.red.group)
+                else:
+                    tmp.copy_(shard[off:off + c])
+                full[a:a + W * c] = tmp.cpu()
+            o = 0
+            for x, y in self.rem_spans:
+                full[x:y] = rem[o:o + y - x].cpu()
+                o += y - x
+            out.append(full)
+        return tuple(out)
+
+    def load_full_state(self, master, m, v):
+        for shard, rem, full in ((self.master, self.rem_master, master), (self.m, self.rem_m, m), (self.v, self.rem_v, v)):
+            for a, b, c, off in self.ranges:
+                lo, hi = self._mine(a, c)
+                shard[off:off + c].copy_(full[lo:hi])
+            o = 0
+            for x, y in self.rem_spans:
+                rem[o:o + y - x].copy_(full[x:y])
+                o += y - x

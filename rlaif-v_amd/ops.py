@@ -628,6 +628,23 @@ def grad_norm(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = N
     return out2
 
 
+def grad_sumsq(g: torch.Tensor, out1: torch.Tensor, accumulate: bool = False):
+    """out1[0] (+)= sum of squares of the bf16 slice g (device scalar, no host sync): the local half of a sharded grad norm."""
+    if g.numel() == 0:
+        if not accumulate:
+            out1.zero_()
+        return out1
+    partial = torch.empty(hip.lib().lib.rv_sumsq_nblocks(), dtype=torch.float32, device=g.device)
+    hip.call("rv_grad_sumsq", g, g.numel(), partial, out1, int(accumulate))
+    return out1
+
+
+def clip_from_sumsq(sumsq: torch.Tensor, max_norm: float, out2: torch.Tensor, pre_scale: float = 1.0):
+    """out2 = [||pre_scale g||, pre_scale * clip coefficient] from the (all-reduced) sum of squares: grad_norm's second half."""
+    hip.call("rv_clip_from_sumsq", sumsq, float(max_norm), float(pre_scale), out2)
+    return out2
+
+
 def grad_accum(acc: torch.Tensor, g: torch.Tensor, mode: int, scale: float = 1.0):
     """fp32 gradient accumulation over micro-batches: mode 0 acc = g, 1 acc += g, 2 g = bf16((acc + g) * scale)."""
     if acc.dtype != torch.float32 or g.dtype != BF16 or acc.numel() != g.numel() or not (acc.is_contiguous() and g.is_contiguous()):

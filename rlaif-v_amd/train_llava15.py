@@ -174,13 +174,13 @@ def safe_save_model_for_hf_trainer(trainer: LLaVA15DPOTrainer, output_dir: str):
 
 
 def train(argv=None, tokenizer=None):
-    from .dist import BucketedAllReduce, init_process_group_from_env
+    from .dist import init_process_group_from_env, make_reducer
     model_args, data_args, training_args = parse_args(argv)
     rank, local, world = init_process_group_from_env()
     data_args.data_source_names = data_args.data_source_names.split("#")
     data_args.data_source_weights = [int(x) for x in data_args.data_source_weights.split("#")]
     model, data_module, tokenizer = init_model(model_args, data_args, training_args, tokenizer=tokenizer)
-    reducer = BucketedAllReduce(model.store.flat_g) if world > 1 else None
+    reducer = make_reducer(model.store.flat_g) if world > 1 else None       # RV_ZERO1=1: opt-in sharded optimizer (dist.py)
     trainer = LLaVA15DPOTrainer(model=model, tokenizer=tokenizer, args=training_args, reducer=reducer, **data_module)
     ckpts = sorted(glob.glob(os.path.join(training_args.output_dir, "checkpoint-*")),
                    key=lambda p: int(p.rsplit("-", 1)[1]) if p.rsplit("-", 1)[1].isdigit() else -1)

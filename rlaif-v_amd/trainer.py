@@ -297,6 +297,12 @@ class LLaVA15DPOTrainer:
         self.reducer.finish()                                  # all gradient buckets reduced (SUM over ranks)
         step = self.state["global_step"] + 1
         lr = self.current_lr() if lr is None else lr
+        if getattr(self.reducer, "sharded", False):            # opt-in ZeRO-1 (dist.ShardedGradReducer + ShardedAdamW)
+            self._sharded_optimizer().step(lr, a.adam_beta1, a.adam_beta2, a.adam_epsilon, a.weight_decay, step, a.max_grad_norm,
+                                           self._clip)
+            st.refresh_transposes(trainable_only=True)
+            self.state["global_step"] = step
+            return
         ops.grad_norm(st.flat_g, a.max_grad_norm, self._clip, pre_scale=1.0 / self.reducer.world_size)
         nd, tp = st.n_decay, st.train_p          # the optimizer owns flat_p[t0:] (everything, or adapters + projector)
         ops.adamw_step(tp[:nd], st.flat_master[:nd], st.flat_m[:nd], st.flat_v[:nd], st.flat_g[:nd], lr,
@@ -305,6 +311,17 @@ class LLaVA15DPOTrainer:
                        a.adam_beta1, a.adam_beta2, a.adam_epsilon, 0.0, step, clip=self._clip)
         st.refresh_transposes(trainable_only=True)
         self.state["global_step"] = step
+
+    def _sharded_optimizer(self):
+        """The ZeRO-1 optimizer of this trainer, built on first use: takes this rank's shards of the fp32 state from the store's
+        replicated buffers (fresh from the parameters, or just loaded from a checkpoint) and FREES those buffers."""
+        if getattr(self, "_zero1", None) is None:
+            from .dist import ShardedAdamW
+            st = self.model.store
+            full = (st.flat_master, st.flat_m, st.flat_v) if st.flat_master is not None else None
+            self._zero1 = ShardedAdamW(st.train_p, st.n_decay, self.reducer, st.bucket_schedule(), full_state=full)
+            st.flat_master = st.flat_m = st.flat_v = None      # (N - 1) / N of the 12 bytes per parameter are gone
+        return self._zero1
 
     def training_step(self, inputs: dict) -> torch.Tensor:
         """forward + backward (+ overlapped gradient all-reduce) of ONE micro-batch; the optimizer runs when the
@@ -471,10 +488,20 @@ class LLaVA15DPOTrainer:
                     n_train=int(st.n_train), t0=int(st.t0), entries_crc32=zlib.crc32(order.encode()))
 
     def save_checkpoint(self, path: str):
+        st = self.model.store
+        if getattr(self.reducer, "sharded", False):
+            # ZeRO-1: the file keeps the REPLICATED layout (full fp32 master / m / v in flat order), so a sharded run resumes a
+            # replicated one and back.  Collective: every rank takes part in the gather, rank 0 writes.
+            master, m_, v_ = self._sharded_optimizer().gather_full_state()
+            if int(os.environ.get("RANK", "0")) == 0:
+                os.makedirs(path, exist_ok=True)
+                torch.save(dict(master=master, m=m_, v=v_, state=self.state, dropout_step=int(self.model._dropout_step),
+                                layout=self._optimizer_layout()), os.path.join(path, "optimizer.pt"))
+                self._save(path)
+            return
         if int(os.environ.get("RANK", "0")) != 0:
             return
         os.makedirs(path, exist_ok=True)
-        st = self.model.store
         # data position (epoch + batches consumed in it) rides in self.state; the LoRA dropout counter too, so that a
         # resumed run draws the masks the uninterrupted run would have drawn
         torch.save(dict(master=st.flat_master.cpu(), m=st.flat_m.cpu(), v=st.flat_v.cpu(), state=self.state,
@@ -508,8 +535,13 @@ class LLaVA15DPOTrainer:
                              f"{ {k: have.get(k) for k in diff} } vs this model { {k: want[k] for k in diff} }); resume with the "
                              "same RV_FUSE_SWIGLU / LoRA / vocabulary settings, or load the HF-layout weights "
                              "(from_pretrained) and restart the optimizer")
-        st.flat_master.copy_(blob["master"]), st.flat_m.copy_(blob["m"]), st.flat_v.copy_(blob["v"])
-        ops.cast_f32_to_bf16(st.flat_master, st.train_p)
+        if getattr(self.reducer, "sharded", False):
+            z = self._sharded_optimizer()
+            z.load_full_state(blob["master"], blob["m"], blob["v"])
+            st.train_p.copy_(blob["master"])                     # fp32 -> bf16, round to nearest even like rv_cast_f32_to_bf16
+        else:
+            st.flat_master.copy_(blob["master"]), st.flat_m.copy_(blob["m"]), st.flat_v.copy_(blob["v"])
+            ops.cast_f32_to_bf16(st.flat_master, st.train_p)
         st.refresh_transposes(trainable_only=True)
         self.state = dict(dict(epoch=0, batches_in_epoch=0), **blob["state"])
         self.model._dropout_step = int(blob.get("dropout_step", 0))

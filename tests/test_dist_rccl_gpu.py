@@ -49,6 +49,57 @@ def test_training_step_with_rccl_bucket_reduce():
         dist.destroy_process_group()
 
 
+def test_zero1_sharded_optimizer_on_device_one_rank(tmp_path):
+    """Opt-in ZeRO-1 on the REAL kernels (rv_grad_sumsq, rv_clip_from_sumsq, rv_adamw_step on chunk views, RCCL reduce-scatter /
+    all-gather forced on in a 1-rank group): two training steps give bit-identical parameters and loss to the replicated path,
+    the full-size fp32 buffers are gone, and a checkpoint written by the sharded run (replicated file format) resumes in a
+    REPLICATED trainer to the same third step.  The partition logic for W > 1 is covered under gloo (tests/test_dist_gloo.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.distributed as dist
+    from rlaif_v_amd.dist import ShardedGradReducer
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    from rlaif_v_amd.trainer import LLaVA15DPOTrainer, TrainingArguments
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = O.tiny_cfg()
+        W = O.make_weights(cfg, seed=9)
+        batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=9)
+        args = dict(learning_rate=1e-3, warmup_ratio=0.0, lr_scheduler_type="constant", output_dir=str(tmp_path))
+        runs = {}
+        for sharded in (False, True):
+            model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)))
+            model.load_state_dict(W)
+            red = ShardedGradReducer(model.store.flat_g, bucket_bytes=1 << 20, force=True) if sharded else None
+            tr = LLaVA15DPOTrainer(model=model, args=TrainingArguments(**args), reducer=red)
+            for _ in range(2):
+                loss = tr.training_step(dict(batch))
+            torch.cuda.synchronize()
+            runs[sharded] = (float(loss), model.store.flat_p.clone(), model, tr)
+        assert runs[True][0] == runs[False][0] and torch.equal(runs[True][1], runs[False][1])
+        m_sh, tr_sh = runs[True][2], runs[True][3]
+        assert m_sh.store.flat_master is None and tr_sh._zero1.master.numel() == m_sh.store.n_train      # W = 1: the whole range
+        full = tr_sh._zero1.gather_full_state()
+        assert torch.equal(full[0], runs[False][2].store.flat_master.cpu()) and torch.equal(full[2], runs[False][2].store.flat_v.cpu())
+        # checkpoint interoperability: sharded save -> replicated resume -> the same third step as the never-interrupted replicated run
+        ck = os.path.join(str(tmp_path), "checkpoint-2")
+        tr_sh.save_checkpoint(ck)
+        model3 = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)))
+        model3.load_state_dict(W)
+        tr3 = LLaVA15DPOTrainer(model=model3, args=TrainingArguments(**args))
+        tr3.load_checkpoint(ck)
+        l3 = tr3.training_step(dict(batch))
+        l_ref = runs[False][3].training_step(dict(batch))
+        torch.cuda.synchronize()
+        assert float(l3) == float(l_ref) and torch.equal(model3.store.flat_p, runs[False][2].store.flat_p)
+    finally:
+        dist.destroy_process_group()
+
+
 def _cat_batches(batches):
     """Union of collator batches: wins of all shards, then rejects of all shards (rows right-padded to a common width)."""
     def cat(key):
