@@ -884,7 +884,7 @@ class LlavaDPOModel:
         if S * L * cfg.vocab * 2 > (16 << 30):
             raise ValueError("forward(): logits would exceed 16 GB - use forward_logps (fused LM head) for training shapes")
         x = inputs_embeds.to(self.device, BF16).reshape(S * L, d).contiguous()
-        plan = SimpleNamespace(S=S, L=L, pos=None, seg=None)
+        plan = SimpleNamespace(S=S, L=L, pos=None, seg=None, rows=None)
         cos, sin = self._rope(L)
         for i in range(cfg.layers):
             x, _ = self._layer_fwd(i, x, plan, cos, sin, False)
