@@ -12,7 +12,7 @@ per-token log-probs (bf16 activations through the whole stack against an fp32 or
 from the fp32 oracle than the oracle evaluated the way HF runs under --bf16 (oracle.emulate_bf16) - and at 4 layers mean |err|
 within 5e-3 of the mean |log-prob|, worst token within 2e-2; gradients: per-tensor norm within 3 %, direction cosine >= 0.99.
 (The file sorts last on purpose: these cases spend minutes in the CPU oracle.)  The measured numbers are written to
-gpurun_out/parity_<round>.json (RV_ROUND, default r04; copied to profiles/).
+gpurun_out/parity_<round>.json (RV_ROUND, default r05; copied to profiles/).
 """
 import json
 import os
@@ -48,7 +48,7 @@ def _host_ram_gb():
 
 
 def _record(key, value):
-    path = os.path.join(REPO, "gpurun_out", f"parity_{os.environ.get('RV_ROUND', 'r04')}.json")
+    path = os.path.join(REPO, "gpurun_out", f"parity_{os.environ.get('RV_ROUND', 'r05')}.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     blob = {}
     if os.path.exists(path):
