@@ -517,6 +517,8 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
     # ---- optimizer: post-step fp32 masters and first moment on the sampled elements
     lr = c["lr"]
     agree, total, worst_m_cos, agree_big, total_big = 0, 0, 1.0, 0, 0
+    agree_same, total_same, flips_big = 0, 0, 0
+    worst_tensors = []
     for k, p_ref in fx["post_samples"].items():
         p_hip = hip["post_samples"][k]
         total += p_ref.numel()
@@ -526,12 +528,51 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
         big = g_ref.abs() >= 0.25 * g_ref.pow(2).mean().sqrt()        # elements whose gradient is not lost in bf16 compute noise
         agree_big += int((ok & big).sum())
         total_big += int(big.sum())
+        # Step 1 of Adam moves a weight by lr x g / (|g| + eps) = lr x sign(g) wherever the clipped gradient is far above eps = 1e-8,
+        # so the two post-step masters differ where the two gradients differ in SIGN - and, for tensors whose clipped gradients are
+        # of the order of eps (config 5: the q / k lora_B of the last layers, |clip x g| ~ 5e-8), where bf16 noise moves |g|:
+        # d update = lr eps dg / (|g| + eps)^2.  Both are statements about the GRADIENT (asserted through the per-tensor cosines);
+        # the statement about the OPTIMIZER is separate and exact: see `optimizer_self_consistency` below.
+        same = (hip["grad_samples"][k] * g_ref) > 0
+        agree_same += int((ok & big & same).sum())
+        total_same += int((big & same).sum())
+        flips_big += int((big & ~same).sum())
+        bad = big & same & ~ok
+        if int(bad.sum()):
+            j = int(torch.nonzero(bad)[0])
+            worst_tensors.append((int(bad.sum()), k, dict(n_big=int(big.sum()), example=dict(
+                p_hip=float(p_hip[j]), p_ref=float(p_ref[j]), g_hip=float(hip["grad_samples"][k][j]), g_ref=float(g_ref[j]),
+                m_hip=float(hip["m_samples"][k][j]), p0=float(W0[k].flatten()[sample_index(k, W0[k].numel())][j]) if W0 is not None else None))))
         m_ref = 0.1 * fx["clip_coef"] * fx["grad_samples"][k]          # AdamW first moment after step 1: (1 - beta1) x clipped g
         if float(m_ref.norm()) > 0:
             worst_m_cos = min(worst_m_cos, _cos(hip["m_samples"][k], m_ref))
     m.update(master_update_agree_frac=agree / max(total, 1), master_samples=total, adam_m_worst_sample_cosine=worst_m_cos,
-             master_update_agree_frac_large_grads=agree_big / max(total_big, 1), master_samples_large_grads=total_big)
-    if W0 is not None:      # how many sampled masters moved at all (guards against a vacuous comparison)
+             master_update_agree_frac_large_grads=agree_big / max(total_big, 1), master_samples_large_grads=total_big,
+             master_update_agree_frac_same_gradient_sign=agree_same / max(total_same, 1),
+             grad_sign_flip_frac_large_grads=flips_big / max(total_big, 1),
+             master_disagree_same_sign_by_tensor=[(n, k, e) for n, k, e in sorted(worst_tensors, key=lambda t: -t[0])[:12]],
+             master_disagree_same_sign_tensors=len(worst_tensors))
+    if W0 is not None:
+        # THE OPTIMIZER, EXACTLY: every sampled post-step master of the HIP path must be what AdamW step 1 (torch.optim.AdamW as
+        # selected by train_llava15.py:75, HF decay groups, clip_grad_norm_ folded into the clip factor) makes of the HIP path's OWN
+        # gradient element, clip factor and initial weight - evaluated here in float64.  No noise model, no fitted bar: the kernel's
+        # fp32 arithmetic (a handful of roundings) is the only slack.
+        b1, b2, eps_, wd_ = 0.9, 0.999, 1e-8, 0.01
+        n_ok = n_all = 0
+        worst = 0.0
+        for k in fx["post_samples"]:
+            idx = sample_index(k, W0[k].numel())
+            p0 = W0[k].flatten()[idx].double()
+            g = hip["grad_samples"][k].double() * float(hip["clip_coef"])
+            mh, vh = (1 - b1) * g / (1 - b1), (1 - b2) * g * g / (1 - b2)
+            exp_p = p0 * ((1.0 - lr * wd_) if O.is_decay_param(k) else 1.0) - lr * mh / (vh.sqrt() + eps_)
+            err = (hip["post_samples"][k].double() - exp_p).abs()
+            tol = 1e-4 * lr + 2.4e-7 * p0.abs()
+            n_ok += int((err <= tol).sum())
+            n_all += err.numel()
+            worst = max(worst, float((err / lr).max()))
+        m.update(optimizer_self_consistency_frac=n_ok / max(n_all, 1), optimizer_self_consistency_worst_err_over_lr=worst)
+        # how many sampled masters moved at all (guards against a vacuous comparison)
         moved = sum(int(((hip["post_samples"][k] - W0[k].flatten()[sample_index(k, W0[k].numel())]).abs() > 0).sum())
                     for k in fx["post_samples"])
         m["master_moved_frac"] = moved / max(total, 1)
@@ -543,7 +584,15 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
         # (logged, no bar of its own: VERDICT r3 weak 1 - a bar fitted to the measurement says nothing)
         # ... and where the gradient is NOT noise-level (|g| >= a quarter of its tensor's RMS: 70 % of the elements) the update
         # must agree almost everywhere (measured 99.90 %)
-        assert m["master_update_agree_frac_large_grads"] >= 0.995, m["master_update_agree_frac_large_grads"]
+        # (rounds 3-4 asserted agree_frac_large_grads >= 0.995 - a number fitted to the full fine-tune's 0.9990; config 5's adapters
+        # measure 0.99499 with every gradient bar met: tensors whose clipped gradients are of the order of Adam's eps.  The fitted
+        # bar is replaced by the statements it mixed: the optimizer checked EXACTLY against its own inputs, the gradient's sign
+        # noise bounded loosely, and the old number kept as a coarse floor.)
+        if "optimizer_self_consistency_frac" in m:
+            assert m["optimizer_self_consistency_frac"] >= 0.9999, (m["optimizer_self_consistency_frac"],
+                                                                     m["optimizer_self_consistency_worst_err_over_lr"])
+        assert m["grad_sign_flip_frac_large_grads"] <= 0.01, m["grad_sign_flip_frac_large_grads"]
+        assert m["master_update_agree_frac_large_grads"] >= 0.99, m["master_update_agree_frac_large_grads"]    # (logged: 0.995 - 0.999)
         assert worst_m_cos >= 0.99, worst_m_cos
         if W0 is not None:
             assert m["master_moved_frac"] >= 0.9
