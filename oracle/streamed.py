@@ -105,7 +105,8 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
                       lora_scale: Optional[float] = None,
                       lora_masks_fn: Optional[Callable[[int], Dict[str, torch.Tensor]]] = None,
                       row_chunk: Optional[int] = None, front=None,
-                      layer_fn: Optional[Callable] = None, hidden_fn: Optional[Callable] = None) -> Dict[str, object]:
+                      layer_fn: Optional[Callable] = None, hidden_fn: Optional[Callable] = None,
+                      coef_override: Optional[Sequence[torch.Tensor]] = None) -> Dict[str, object]:
     """DPO step (DPO_weight 1, SFT_weight 0, dpo_use_average False) of ``dpo_step_forward`` + ``loss.backward()``.
 
     variants   list of {ref_win_logp, ref_rej_logp} (or a callable (policy_win_logp, policy_rej_logp) -> such a list);
@@ -123,6 +124,9 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
     layer_fn       replaces ``dpo_oracle.llama_layer`` (same signature) - used by the rounding-point study (oracle/rounding.py), which
                    needs the same layer with explicit bf16 roundings inserted; ``hidden_fn`` is applied to the final norm's output
                    in front of the LM head (forward-only runs).
+    coef_override  per variant the vector d loss / d log_prob [S] to back-propagate instead of the one this run's own log-probs give
+                   (the bf16-EMULATED backward is driven by the fp32 run's coefficients, so that the two gradients differ by the
+                   backward's rounding only - the same separation tests/full_depth.py applies to the HIP path's conditioned cases).
     Returns the forward quantities of ``dpo_step_forward`` (per variant: loss / losses / rewards under ``variants``)."""
     beta = batch["beta"]
     B = batch["win_input_ids"].shape[0]
@@ -185,6 +189,9 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
     for v in variants:
         losses, _, _ = O.dpo_loss(lp_leaf[:B], lp_leaf[B:], v["ref_win_logp"], v["ref_rej_logp"], beta)
         coefs.append(torch.autograd.grad(losses.mean(), lp_leaf)[0])          # [S]
+    if coef_override is not None:
+        coefs = [c.to(log_prob.dtype) for c in coef_override]
+    res["coefs"] = [c.detach().float().clone() for c in coefs]
     xL = xs.pop()
     tail_names = [] if lora else ["model.norm.weight", "lm_head.weight"]
     rc = row_chunk or S

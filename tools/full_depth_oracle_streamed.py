@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--no-emulation", action="store_true")
+    ap.add_argument("--add-emu-backward", action="store_true",
+                    help="load the base's existing fixtures and ADD the bf16-emulated oracle's backward (emu_grad_norms / emu_grad_samples: "
+                         "the yardstick of the per-tensor gradient bars); the fp32 run is not repeated")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     base, cond = {"cfg1": ("cfg1_step", "cfg1_cond"), "cfg2": ("cfg2_step", "cfg2_cond"), "cfg5": ("cfg5_step", "cfg5_cond"),
@@ -52,6 +55,18 @@ def main():
     W = FD.make_case_weights(base, cfg)
     log(f"weights ({args.layers} layers): {time.time() - t0:.0f} s")
     report = dict(host=dict(cpus=os.cpu_count(), threads=args.threads, torch=torch.__version__), layers=args.layers)
+    if args.add_emu_backward:
+        suffix = "" if args.layers == 32 else f"_l{args.layers}"
+        names = [cs for cs in (base, cond) if os.path.exists(os.path.join(args.out, f"fulldepth_{cs}{suffix}.pt"))]
+        fxs = {cs: torch.load(os.path.join(args.out, f"fulldepth_{cs}{suffix}.pt"), weights_only=False) for cs in names}
+        worst = FD.add_emulated_backward(base, W, cfg, fxs, log=log)
+        for cs, fx in fxs.items():
+            FD.save_fixture(fx, os.path.join(args.out, f"fulldepth_{cs}{suffix}.pt"))
+        path = os.path.join(REPO, "profiles", f"r05_oracle_emulated_backward_{args.base}{suffix}.json")
+        json.dump(dict(report, emu_bf16_backward_worst_sample_cosine=worst, timings={cs: fxs[cs]["emu_backward_timings"] for cs in fxs}),
+                  open(path, "w"), indent=1)
+        log("done")
+        return
     old = None
     emu_from = None
     old_path = os.path.join(REPO, "tests", "golden", f"fulldepth_{base}.pt")
