@@ -615,7 +615,7 @@ def main():
                           alg_bytes_per_launch=d["alg_bytes"] / max(d["launches"], 1))
                   for k, d in sorted(g["by_kernel"].items(), key=lambda kv: -kv[1]["ms"])}
             dom = next((k for k in by if not k.startswith("attn_")), None)      # the dominant kernel is a GEMM class (75 % of GPU time)
-            weakest = min((k for k in by if by[k]["ms_per_step"] >= 5.0), key=lambda k: by[k]["frac"], default=None)
+            weakest = min((k for k in by if by[k]["ms_per_step"] >= 10.0), key=lambda k: by[k]["frac"], default=None)
             line["roofline"] = {"bound": "mfma",
                                 "kernel": "ALL MFMA GEMM launches of the step (plain NN / TN / NT, SwiGLU-epilogue NN forward and "
                                           "backward, fused LM-head log-prob forward and backward, fused-LoRA forms): 256x256 ping-pong tiles",

@@ -13,6 +13,7 @@
 #   benchfast     headline config without the CPU baseline / DP probe
 #   ragged        bench.py --ragged, pad-free vs rectangular
 #   lora          bench.py --lora --seq-len 4096 --pairs-per-gpu 4
+#   omnilmm       bench.py --omnilmm (config 4 from pixels)
 #   prof          rocprofv3 --kernel-trace --stats of the headline bench (3 steps)
 #   smoke         __graft_entry__.smoke()
 R=${RV_ROUND:-r05}
@@ -34,7 +35,8 @@ for st in "$@"; do
     benchfast) timeout 600 python bench.py --no-cpu-baseline --no-dp-probe > $OUT/bench_line_fast.json 2> $OUT/bench_fast_err.log; head -c 600 $OUT/bench_line_fast.json; echo ;;
     ragged)    for pf in 1 0; do RV_PAD_FREE=$pf timeout 600 python bench.py --ragged --pairs-per-gpu ${RV_RAGGED_PAIRS:-12} --no-dp-probe --steps 4 > $OUT/bench_line_ragged_padfree$pf.json 2> $OUT/bench_ragged_err$pf.log; head -c 500 $OUT/bench_line_ragged_padfree$pf.json; echo; done ;;
     lora)      timeout 600 python bench.py --lora --seq-len 4096 --pairs-per-gpu 4 --no-dp-probe > $OUT/bench_line_lora.json 2> $OUT/bench_lora_err.log; head -c 600 $OUT/bench_line_lora.json; echo ;;
-    prof)      bash tools/profile_bench.sh $R/bench_kernel python bench.py --steps 3 --no-cpu-baseline --no-dp-probe --no-gemm-timer; head -25 gpurun_out/$R/bench_kernel_stats.csv ;;
+    omnilmm)   timeout 900 python bench.py --omnilmm --no-dp-probe > $OUT/bench_line_omnilmm_pixels.json 2> $OUT/bench_omnilmm_err.log; head -c 600 $OUT/bench_line_omnilmm_pixels.json; echo ;;
+    prof)      bash tools/profile_bench.sh $R/bench_kernel python $PWD/bench.py --steps 3 --no-cpu-baseline --no-dp-probe --no-gemm-timer; head -25 gpurun_out/$R/bench_kernel_stats.csv ;;
     smoke)     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log ;;
     *)         echo "unknown stage $st" ;;
   esac
