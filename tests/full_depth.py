@@ -68,6 +68,14 @@ CASES = {
     "cfg4_step": dict(kind="omnilmm", seed=47, pairs=2, text_len=2048, ragged=False, answer_lens=[(1967, 1200), (1700, 800)],
                       lr=5e-7, step=True, max_len=2048, row_chunk=2),
     "cfg4_cond": dict(base="cfg4_step", beta_z=[0.0, 1.0], lr=5e-7, step=True),
+    # cfg1m_step = BASELINE config 1 AGAIN (4 synthetic 336-px pairs, T = 512 -> L = 1087, 32 layers, one whole step) on a batch whose
+    # 1e-3 loss bar has MARGIN ("buy margin on the 1e-3 bar").  cfg1_step's ragged draw gives a saturated
+    # loss of 13.8 = beta x small differences of ~330-token sums: one sigma of ANY bf16 forward's rounding noise is 4.9e-3 of it, so
+    # its 3.4e-4 is one lucky draw (a 1-ulp v_rcp_f32 re-rolled it to 1.9e-3 in round 4).  Here every chosen answer is 200 - 300
+    # tokens longer than the rejected one: the loss is beta x differences of ~2,500 nats and one sigma sits at ~2e-4 of it, i.e. the
+    # north_star bar is a >= 4-sigma statement on this batch, as it is on the config-2 / 4 / 5 batches.  Both batches are config 1.
+    "cfg1m_step": dict(seed=48, pairs=4, text_len=512, prompt_len=64, ragged=False,
+                       answer_lens=[(448, 150), (400, 120), (448, 200), (350, 100)], lr=5e-7, step=True),
 }
 OMNI = dict(hidden=4096, heads=32, kv_heads=8, ffn=14336, vocab=32009, num_query=64, vision_width=1792, tower_tokens=1024,
             resampler_heads=32, tokens=(32000, 32001, 32002))

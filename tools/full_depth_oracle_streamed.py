@@ -7,6 +7,7 @@ evaluation of the oracle (oracle/streamed.py - the oracle's own functions, chain
     --base cfg2   fulldepth_cfg2_step.pt, fulldepth_cfg2_cond.pt  (BASELINE config 2's packed shape, 2 pairs at L = 2048,
                   forward + backward + clip + AdamW; saturated and conditioned reference log-probs)
 
+    --base cfg1m  fulldepth_cfg1m_step.pt  (round 5: config 1 on a batch whose 1e-3 loss bar has >= 4 sigma of margin)
     --base cfg5   fulldepth_cfg5_step.pt, fulldepth_cfg5_cond.pt  (round 5: BASELINE config 5, LoRA r = 64 at L = 4096, two pairs,
                   adapter + projector gradients, clip + AdamW)
     --base cfg5_drop  fulldepth_cfg5_drop.pt  (one pair at L = 4096, adapter dropout 0.05 with the device's masks replayed)
@@ -38,18 +39,19 @@ def log(*a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--base", choices=["cfg1", "cfg2", "cfg5", "cfg5_drop", "cfg4"], required=True)
+    ap.add_argument("--base", choices=["cfg1", "cfg1m", "cfg2", "cfg5", "cfg5_drop", "cfg4"], required=True)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--no-emulation", action="store_true")
+    ap.add_argument("--emu-backward", action="store_true", help="fresh run: also produce the bf16-emulated backward yardstick")
     ap.add_argument("--add-emu-backward", action="store_true",
                     help="load the base's existing fixtures and ADD the bf16-emulated oracle's backward (emu_grad_norms / emu_grad_samples: "
                          "the yardstick of the per-tensor gradient bars); the fp32 run is not repeated")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     base, cond = {"cfg1": ("cfg1_step", "cfg1_cond"), "cfg2": ("cfg2_step", "cfg2_cond"), "cfg5": ("cfg5_step", "cfg5_cond"),
-                  "cfg5_drop": ("cfg5_drop_base", "cfg5_drop"), "cfg4": ("cfg4_step", "cfg4_cond")}[args.base]
+                  "cfg5_drop": ("cfg5_drop_base", "cfg5_drop"), "cfg4": ("cfg4_step", "cfg4_cond"), "cfg1m": ("cfg1m_step", None)}[args.base]
     cfg = FD.make_cfg(args.layers, base)
     t0 = time.time()
     W = FD.make_case_weights(base, cfg)
@@ -76,6 +78,9 @@ def main():
     if args.no_emulation and emu_from is None:
         emu_from = dict(emu_per_token=None, emu_log_prob=None, emu_loss=None)
     fxs = FD.oracle_streamed(base, W, cfg, cond, emu_from=emu_from, own_refs=(args.base != "cfg5_drop"), log=log)
+    if args.emu_backward:
+        keep = {cs: fx for cs, fx in fxs.items() if not (cs == "cfg1_step" and old is not None)}
+        report["emu_bf16_backward_worst_sample_cosine"] = FD.add_emulated_backward(base, W, cfg, keep, log=log)
     suffix = "" if args.layers == 32 else f"_l{args.layers}"
     os.makedirs(args.out, exist_ok=True)
     for cs, fx in fxs.items():
