@@ -271,6 +271,8 @@ class ParamStore:
     def sync_master_from_params(self):
         if self.flat_master is not None:
             self.flat_master.copy_(self.train_p)     # bf16 -> fp32 (device copy, plumbing)
+        if getattr(self, "sharded_optimizer", None) is not None:
+            self.sharded_optimizer.sync_master_from_params()      # opt-in ZeRO-1: the fp32 masters live in the trainer's shards
 
     # ---- HF state-dict mapping ------------------------------------------------------------
     def hf_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int, int]]:

@@ -321,6 +321,7 @@ class LLaVA15DPOTrainer:
             full = (st.flat_master, st.flat_m, st.flat_v) if st.flat_master is not None else None
             self._zero1 = ShardedAdamW(st.train_p, st.n_decay, self.reducer, st.bucket_schedule(), full_state=full)
             st.flat_master = st.flat_m = st.flat_v = None      # (N - 1) / N of the 12 bytes per parameter are gone
+            st.sharded_optimizer = self._zero1                 # load_state_dict / merge_lora re-sync the masters through the store
         return self._zero1
 
     def training_step(self, inputs: dict) -> torch.Tensor:
