@@ -664,7 +664,9 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
                                                                      m["optimizer_self_consistency_worst_err_over_lr"])
         assert m["grad_sign_flip_frac_large_grads"] <= 0.01, m["grad_sign_flip_frac_large_grads"]
         assert m["master_update_agree_frac_large_grads"] >= 0.99, m["master_update_agree_frac_large_grads"]    # (logged: 0.995 - 0.999)
-        assert worst_m_cos >= 0.99, worst_m_cos
+        # Adam's first moment after step 1 is (1 - beta1) x clip x g: its worst sample cosine IS the gradient's (asserted above against
+        # the calibrated bar); what is asserted here is that the optimizer state carries that gradient and nothing else
+        assert abs(worst_m_cos - worst_cos) <= 2e-3 and worst_m_cos >= min(0.99, worst_cos - 2e-3), (worst_m_cos, worst_cos)
         if W0 is not None:
             assert m["master_moved_frac"] >= 0.9
     return m
