@@ -124,6 +124,11 @@ int rv_gemm_tn_bf16_ws(const void* P, long ldp, const void* Q, long ldq, void* C
                        float* workspace, long workspace_floats, void* stream);
 int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                            int variant, void* stream);
+/* C (fp32) = sum_k A[m][k] B[n][k] + bias[n] + residual[m][n] (fp32; may alias C): the out_proj / fc2 products of the frozen CLIP
+ * tower (llava/model/multimodal_encoder/clip_encoder.py:46-58, HF CLIPEncoderLayer) with the tower's residual stream carried in fp32
+ * (RV_CLIP_FP32_RESID).  bias / residual may be NULL. */
+int rv_gemm_nt_bf16_f32res(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                           const void* bias, const float* residual, long ldr, int variant, void* stream);
 
 /* ---- fused LM head + log-softmax + label gather (replaces lm_head + get_batch_logps,
  *      muffin/eval/muffin_inference_logp.py:82-115; logits [rows, V] never reach HBM).
@@ -201,6 +206,9 @@ int rv_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const int
                    void* dw, int dw_accumulate, int rows, int d, void* stream);
 int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int d,
                      float eps, void* stream);
+/* the same LayerNorm reading an fp32 input (the fp32 residual stream above); output bf16 (it feeds a bf16 MFMA operand) */
+int rv_layernorm_fwd_f32in(const float* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int d,
+                           float eps, void* stream);
 /* LayerNorm backward for the OmniLMM Resampler's trainable ln_q / ln_kv / ln_post (omnilmm/model/resampler.py:127-129,
  * autograd of F.layer_norm): dx (NULL = not wanted), dw / db written or accumulated.  x_period > 0: rows r and r + x_period
  * share the x row r % x_period (the learned queries, identical for every image).  partial: fp32 scratch

@@ -16,6 +16,10 @@ CPU before anything is built on the device:
     G  gate / up projection outputs and silu(gate) * up (bf16 stores)
     F  the final norm's output in front of the LM head
     V  the vision front: CLIP tower, projector and embedding rows evaluated in bf16 (``emulate_bf16`` style)
+       ... or, resolved further (lower-case letters, explicit roundings in an fp32 evaluation like the decoder's):
+    c  the CLIP tower's residual stream (x after pre_layrnorm and after each of the 2 x 23 residual adds)
+    o  the CLIP tower's other bf16 stores (patch embedding, LayerNorm outputs, q / k / v, attention output, quick_gelu(fc1))
+    j  the projector's stores (first linear, GELU, output features)
 
 Weights are bf16-representable in every variant (they are on both sides of every parity test), accumulation is fp32
 everywhere, softmax / norm statistics / log-softmax are fp32 - exactly the HIP path's arithmetic.  ``tools/rounding_attribution.py``
@@ -32,6 +36,7 @@ import torch.nn.functional as F
 from . import dpo_oracle as O
 
 ALL_POINTS = "RNQPAGFV"
+VISION_RESOLVED = "coj"          # V resolved: never combined with V itself
 
 
 def _bf(x: torch.Tensor, on: bool) -> torch.Tensor:
@@ -101,6 +106,54 @@ class RoundedLlavaFront:
                 x, labels = O.prepare_inputs_labels_for_multimodal(batch["concatenated_input_ids"], batch["concatenated_labels"], feats,
                                                                    W["model.embed_tokens.weight"], cfg.model_max_length)
                 self.out = (x, labels, feats)
+        self.names = []
+
+    def __call__(self, W):
+        return self.out
+
+
+def clip_features_rounded(pixels: torch.Tensor, W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, points: str) -> torch.Tensor:
+    """``dpo_oracle.clip_vision_features`` (llava/model/multimodal_encoder/clip_encoder.py:36-58 over HF CLIPVisionModel) in fp32 with
+    bf16 roundings at the HIP tower's store points (rlaif-v_amd/model.py ``clip_features``): ``c`` residual stream, ``o`` the rest."""
+    c, o = "c" in points, "o" in points
+    VT = O.VT
+    B = pixels.shape[0]
+    cd, H, hd = cfg.clip_hidden, cfg.clip_heads, cfg.clip_head_dim
+    x = _bf(F.conv2d(pixels, W[VT + "embeddings.patch_embedding.weight"], None, stride=cfg.patch), o)
+    x = x.flatten(2).transpose(1, 2)
+    x = _bf(torch.cat([W[VT + "embeddings.class_embedding"].expand(B, 1, cd), x], 1) + W[VT + "embeddings.position_embedding.weight"][None], o)
+    x = _bf(O._ln(x, W[VT + "pre_layrnorm.weight"], W[VT + "pre_layrnorm.bias"], cfg.clip_eps), c)
+    T = x.shape[1]
+    for i in range(cfg.clip_layers_used):
+        p = VT + f"encoder.layers.{i}."
+        h = _bf(O._ln(x, W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], cfg.clip_eps), o)
+        q = _bf(F.linear(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"]), o).view(B, T, H, hd).transpose(1, 2)
+        k = _bf(F.linear(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"]), o).view(B, T, H, hd).transpose(1, 2)
+        v = _bf(F.linear(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"]), o).view(B, T, H, hd).transpose(1, 2)
+        a = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1) @ v
+        a = _bf(a.transpose(1, 2).reshape(B, T, cd), o)
+        x = _bf(x + F.linear(a, W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"]), c)
+        h = _bf(O._ln(x, W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], cfg.clip_eps), o)
+        h = F.linear(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])
+        h = _bf(h * torch.sigmoid(1.702 * h), o)
+        x = _bf(x + F.linear(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"]), c)
+    return _bf(x[:, 1:], c or o)          # the features handed to the projector are a bf16 GEMM operand either way
+
+
+class ResolvedLlavaFront:
+    """``streamed.LlavaFront`` with the vision front's rounding points resolved (c / o / j, see the module docstring)."""
+
+    def __init__(self, batch, cfg: O.LlavaCfg, W: Dict[str, torch.Tensor], points: str):
+        j = "j" in points
+        images = batch["images"]
+        with torch.no_grad():
+            tower = clip_features_rounded(torch.cat([images, images], 0), W, cfg, points)
+            h = _bf(F.linear(tower, W["model.mm_projector.0.weight"], W["model.mm_projector.0.bias"]), j)
+            h = _bf(F.gelu(h), j)
+            feats = _bf(F.linear(h, W["model.mm_projector.2.weight"], W["model.mm_projector.2.bias"]), j)
+            x, labels = O.prepare_inputs_labels_for_multimodal(batch["concatenated_input_ids"], batch["concatenated_labels"], feats,
+                                                               W["model.embed_tokens.weight"], cfg.model_max_length)
+        self.out = (x, labels, feats)
         self.names = []
 
     def __call__(self, W):

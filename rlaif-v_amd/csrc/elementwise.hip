@@ -168,17 +168,25 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ LayerNorm (CLIP, forward only)
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx,
+// XT = bf16_t: the tower's bf16 residual stream; XT = float: the fp32 residual stream of RV_CLIP_FP32_RESID (round 5: the frozen tower's
+// residual stream carried in fp32 - 84 % of the vision front's share of the per-token error, DESIGN section 2 - output stays bf16)
+__device__ __forceinline__ void ln_load8(const bf16_t* p, float (&f)[8]) { unpack8(*(const uint4*)p, f); }
+__device__ __forceinline__ void ln_load8(const float* p, float (&f)[8]) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <typename XT>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const XT* __restrict__ x, long ldx,
                                                             const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
                                                             long ldy, int rows, int d, float eps) {
   __shared__ float red[16];
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-    const bf16_t* xr = x + (long)r * ldx;
+    const XT* xr = x + (long)r * ldx;
     float s = 0.f;
     for (int c = threadIdx.x * 8; c < d; c += 2048) {
       float f[8];
-      unpack8(*(const uint4*)(xr + c), f);
+      ln_load8(xr + c, f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += f[j];
     }
@@ -186,14 +194,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     float v = 0.f;
     for (int c = threadIdx.x * 8; c < d; c += 2048) {
       float f[8];
-      unpack8(*(const uint4*)(xr + c), f);
+      ln_load8(xr + c, f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v += (f[j] - mean) * (f[j] - mean);
     }
     const float rs = rsqrtf(block_sum(v, red) / (float)d + eps);
     for (int c = threadIdx.x * 8; c < d; c += 2048) {
       float f[8], g[8], h[8];
-      unpack8(*(const uint4*)(xr + c), f);
+      ln_load8(xr + c, f);
       unpack8(*(const uint4*)(w + c), g);
       unpack8(*(const uint4*)(b + c), h);
 #pragma unroll
@@ -1026,7 +1034,17 @@ int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void
                      float eps, void* stream) {
   RV_REQUIRE(d % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "rv_layernorm_fwd: alignment");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx,
+  hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), (const bf16_t*)x, ldx,
+                     (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, rows, d, eps);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_layernorm_fwd_f32in(const float* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int d,
+                           float eps, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0, "rv_layernorm_fwd_f32in: alignment");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), x, ldx,
                      (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, rows, d, eps);
   RV_CHECK_LAUNCH();
   return 0;

@@ -611,6 +611,16 @@ int rv_gemm_nt_bf16_f32out(const void* A, long lda, const void* B, long ldb, flo
   return dispatch(g, epi, variant, stream);
 }
 
+int rv_gemm_nt_bf16_f32res(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                           const void* bias, const float* residual, long ldr, int variant, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
+  if (check_shape(g, "rv_gemm_nt_bf16_f32res")) return 1;
+  RV_REQUIRE(ldc % 4 == 0 && ldr % 4 == 0, "rv_gemm_nt_bf16_f32res: ldc / ldr must be multiples of 4");
+  EpiStoreF32 epi{C, ldc, (const bf16_t*)bias, residual, ldr};
+  return dispatch(g, epi, variant, stream);
+}
+
 int rv_lmhead_logp_fwd(const void* h, long ldh, const void* W, long ldw, const int* tgt, int M, int V, int V_valid, int K,
                        float* pmax, float* psum, float* tgt_logit, int variant, void* stream) {
   if (M == 0) return 0;

@@ -1932,6 +1932,10 @@ struct EpiSwiGLUBwd {
 // fp32 output (used where a downstream reduction wants full precision).
 struct EpiStoreF32 {
   float* C; long ldc;
+  // optional (rv_gemm_nt_bf16_f32res): C = acc + bias[n] + R[m][n] with an fp32 residual - the fp32 residual stream of the frozen
+  // CLIP tower (RV_CLIP_FP32_RESID).  R may alias C (every element is read and written by the same lane).
+  const bf16_t* bias = nullptr;
+  const float* R = nullptr; long ldr = 0;
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -1945,6 +1949,15 @@ struct EpiStoreF32 {
           if (n >= N) continue;
           float4 o = make_float4(acc[tm][tn][rg * 4], acc[tm][tn][rg * 4 + 1], acc[tm][tn][rg * 4 + 2],
                                  acc[tm][tn][rg * 4 + 3]);
+          if (bias) {
+            const uint2 bb = *(const uint2*)(bias + n);
+            o.x += bf2f((bf16_t)(bb.x & 0xffff)); o.y += bf2f((bf16_t)(bb.x >> 16));
+            o.z += bf2f((bf16_t)(bb.y & 0xffff)); o.w += bf2f((bf16_t)(bb.y >> 16));
+          }
+          if (R) {
+            const float4 rr = *(const float4*)(R + (long)m * ldr + n);
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+          }
           *(float4*)(C + (long)m * ldc + n) = o;
         }
     }

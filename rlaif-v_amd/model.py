@@ -363,6 +363,7 @@ class LlavaDPOModel:
         # packed rows are concatenated without inter-row padding (splice.build_packed_plan pad_free; RV_PAD_FREE=0: every packed
         # row right-padded to the longest, the round-1..4 layout).  Log-probs are bit-identical either way (SURVEY 8a property (i))
         self.pad_free = os.environ.get("RV_PAD_FREE", "1") != "0"
+        self.clip_fp32_resid = os.environ.get("RV_CLIP_FP32_RESID", "0") != "0"      # see clip_features
         self.fuse_rope_bwd = os.environ.get("RV_FUSE_ROPE_BWD", "1") != "0"
 
     # ------------------------------------------------------------------ weights
@@ -561,6 +562,23 @@ class LlavaDPOModel:
         pe = ops.gemm_nt(cols, c["patch_w"])
         x = ops.clip_assemble(pe, c["cls"], c["pos"], B, P)
         x = ops.layernorm_fwd(x, c["pre_ln_w"], c["pre_ln_b"], cfg.clip_eps)
+        if self.clip_fp32_resid:
+            # The frozen tower's RESIDUAL STREAM in fp32 (RV_CLIP_FP32_RESID=1, opt-in, round 5): the 47 bf16 roundings of x on the way
+            # through 23 layers are 84 % of the vision front's share - 27 % of the whole - of the per-token log-prob error variance
+            # (profiles/r05_rounding_attribution.json), and the tower is 0.6 % of the step.  Every MFMA operand stays
+            # bf16 (LayerNorm outputs, q / k / v, attention output, quick_gelu(fc1)); only out_proj / fc2 accumulate into an fp32 x.
+            x32 = ops.cast_bf16_to_f32(x)
+            for i in range(cfg.clip_layers_used):
+                h = ops.layernorm_fwd_f32in(x32, c[f"{i}.layer_norm1.w"], c[f"{i}.layer_norm1.b"], cfg.clip_eps)
+                qkv = ops.gemm_nt(h, c[f"{i}.wqkv"], bias=c[f"{i}.bqkv"])
+                a, _ = ops.attn_fwd(qkv, B, T, H, hd, False, 0, cd, 2 * cd)
+                ops.gemm_nt_f32res(a, c[f"{i}.wo"], c[f"{i}.bo"], x32)
+                h = ops.layernorm_fwd_f32in(x32, c[f"{i}.layer_norm2.w"], c[f"{i}.layer_norm2.b"], cfg.clip_eps)
+                h = ops.gemm_nt(h, c[f"{i}.fc1.w"], bias=c[f"{i}.fc1.b"], act=ops.ACT_QUICK_GELU)
+                ops.gemm_nt_f32res(h, c[f"{i}.fc2.w"], c[f"{i}.fc2.b"], x32)
+            x = ops.cast_f32_to_bf16(x32)            # hidden_states[-2] as the projector's bf16 GEMM operand: one rounding
+            idx = (torch.arange(B, device=self.device)[:, None] * T + 1 + torch.arange(P, device=self.device)[None]).reshape(-1)
+            return ops.gather_rows(x, idx.to(torch.int32))
         for i in range(cfg.clip_layers_used):
             h = ops.layernorm_fwd(x, c[f"{i}.layer_norm1.w"], c[f"{i}.layer_norm1.b"], cfg.clip_eps)
             qkv = ops.gemm_nt(h, c[f"{i}.wqkv"], bias=c[f"{i}.bqkv"])

@@ -321,6 +321,25 @@ def layernorm_fwd(x, w, b, eps: float, out=None):
     return out
 
 
+def layernorm_fwd_f32in(x: torch.Tensor, w, b, eps: float):
+    """LayerNorm of an fp32 [rows, d] input -> bf16 (rv_layernorm_fwd_f32in)."""
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("layernorm_fwd_f32in: fp32 [rows, d] input with unit inner stride required")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    hip.call("rv_layernorm_fwd_f32in", x, x.stride(0), w, b, out, out.stride(0), x.shape[0], x.shape[1], float(eps))
+    return out
+
+
+def gemm_nt_f32res(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor], residual: torch.Tensor, variant: int = -1):
+    """residual (fp32 [M, N]) += a @ b^T + bias, IN PLACE (rv_gemm_nt_bf16_f32res with C aliasing the residual); returns it."""
+    _chk2d(a, "a"), _chk2d(b, "b")
+    if residual.dtype != torch.float32 or residual.shape != (a.shape[0], b.shape[0]) or residual.stride(1) != 1:
+        raise ValueError("gemm_nt_f32res: fp32 residual [M, N] required")
+    hip.call("rv_gemm_nt_bf16_f32res", a, a.stride(0), b, b.stride(0), residual, residual.stride(0), a.shape[0], b.shape[0],
+             a.shape[1], bias, residual, residual.stride(0), variant)
+    return residual
+
+
 def layernorm_bwd(dy, x, w, eps: float, dw: torch.Tensor, db: torch.Tensor, want_dx: bool = True, x_period: int = 0,
                   accumulate: bool = False) -> Optional[torch.Tensor]:
     """F.layer_norm backward: returns dx [rows, d] (None if not wanted); dw / db (bf16 [d]) written or accumulated.
@@ -596,6 +615,12 @@ def clip_assemble(patch_emb, cls, pos, B: int, P: int):
     d = patch_emb.shape[1]
     out = torch.empty(B * (P + 1), d, dtype=BF16, device=patch_emb.device)
     hip.call("rv_clip_assemble", patch_emb, cls, pos, out, B, P, d)
+    return out
+
+
+def cast_bf16_to_f32(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    hip.call("rv_cast_bf16_to_f32", x.contiguous(), out, x.numel())
     return out
 
 

@@ -775,6 +775,30 @@ def test_clip_front_end(ops):
     close(x, refx.reshape(B * 17, cd), rel=1e-2, what="clip assemble")
 
 
+@pytest.mark.parametrize("M,N,K", [(1154, 1024, 1024), (1154, 1024, 4096), (300, 256, 128), (4617, 1024, 1024)])
+def test_gemm_nt_f32_residual_and_layernorm_f32in(ops, M, N, K):
+    """The two kernels of the CLIP tower's fp32 residual stream (RV_CLIP_FP32_RESID): x32 += a @ w^T + bias in place
+    (rv_gemm_nt_bf16_f32res, residual aliasing the output, every GEMM variant the dispatcher may pick) and LayerNorm of an fp32
+    input with bf16 output (rv_layernorm_fwd_f32in), against fp32 torch."""
+    dev = _dev()
+    a, w, bias = rnd(M, K, seed=1, dev=dev, scale=0.5), rnd(N, K, seed=2, dev=dev, scale=0.05), rnd(N, seed=3, dev=dev)
+    x32 = torch.randn(M, N, generator=torch.Generator().manual_seed(4)).to(dev) * 3.0
+    ref = x32 + a.float() @ w.float().t() + bias.float()
+    for variant in (-1, 0, 1, 2):
+        got = ops.gemm_nt_f32res(a, w, bias, x32.clone(), variant=variant)
+        assert got.dtype == torch.float32
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-3)
+    got = ops.gemm_nt_f32res(a, w, None, x32.clone())
+    torch.testing.assert_close(got, ref - bias.float(), rtol=1e-4, atol=2e-3)
+    g, b = rnd(N, seed=5, dev=dev, scale=0.3) + 1, rnd(N, seed=6, dev=dev, scale=0.1)
+    y = ops.layernorm_fwd_f32in(ref, g, b, 1e-5)
+    yr = F.layer_norm(ref, (N,), g.float(), b.float(), 1e-5)
+    close(y, yr, rel=1e-2, what="layernorm fp32 in")
+    # and it is the bf16-input kernel's arithmetic: identical output on an input that IS bf16-representable
+    xb = ref.to(BF)
+    assert torch.equal(ops.layernorm_fwd_f32in(xb.float(), g, b, 1e-5), ops.layernorm_fwd(xb, g, b, 1e-5))
+
+
 # ------------------------------------------------------------------------------------------- optimizer
 def test_adamw_and_gradnorm(ops):
     dev = _dev()

@@ -329,6 +329,30 @@ def test_pad_free_layout_equals_rectangular_packed_layout(width, monkeypatch):
     assert worst_c >= 1 - 1e-6 and worst_n <= 1e-4
 
 
+def test_clip_tower_fp32_residual_stream_is_closer_to_fp32(monkeypatch):
+    """RV_CLIP_FP32_RESID=1 (opt-in, round 5): the frozen CLIP tower with its residual stream carried in fp32 - every MFMA operand
+    still bf16.  At the production tower (CLIP-ViT-L/14-336: 24 layers, 577 tokens, width 1024) the features handed to the projector
+    must sit CLOSER to the fp32 oracle's (dpo_oracle.clip_vision_features, clip_encoder.py:36-58) than the default bf16 stream's do,
+    and by a clear factor (the rounding-point study prices the stream at 84 % of the vision front's error variance)."""
+    _need_gpu()
+    from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
+    cfg_o = O.LlavaCfg(layers=1, hidden=256, heads=2, ffn=512, vocab=512, model_max_length=1024)      # full CLIP tower, toy decoder
+    W = O.make_weights(cfg_o, seed=12)
+    px = torch.randn(2, 3, 336, 336, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = O.clip_vision_features(px, W, cfg_o).reshape(-1, cfg_o.clip_hidden)
+    errs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RV_CLIP_FP32_RESID", flag)
+        model = LlavaDPOModel(LlavaConfig(**O.asdict(cfg_o)), with_optimizer=False)
+        model.load_state_dict(W)
+        assert model.clip_fp32_resid == (flag == "1")
+        got = model.clip_features(px).float().cpu()
+        errs[flag] = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"CLIP features vs fp32 oracle, relative RMS error: bf16 residual stream {errs['0']:.3e}, fp32 residual stream {errs['1']:.3e}")
+    assert errs["1"] < 0.7 * errs["0"] and errs["0"] < 3e-2
+
+
 def test_full_size_7b_properties():
     """BASELINE config 2 at FULL size (32 layers, 7B widths, L = 2048, CLIP-L/14-336): the oracle cannot run it in
     seconds, so parity is checked through size-independent properties of the reference (SURVEY.md section 8a [probe]):

@@ -41,6 +41,8 @@ def points_of(v: str) -> str:
         return "".join(c for c in RD.ALL_POINTS if c not in v[1:])
     if v.startswith("+"):
         return v[1:]
+    if v.startswith("="):          # explicit point string, e.g. =RNQPAGFoj (everything but the CLIP residual stream)
+        return v[1:]
     raise SystemExit(f"bad variant {v!r}")
 
 
@@ -76,8 +78,10 @@ def main():
     for v in args.variants.split(","):
         pts = points_of(v)
         t0 = time.time()
+        resolved = any(ch in pts for ch in RD.VISION_RESOLVED)
+        front = RD.ResolvedLlavaFront(batch, cfg, W, pts) if resolved else RD.RoundedLlavaFront(batch, cfg, W, pts)
         res = S.dpo_step_streamed(batch, W, cfg, backward=False, layer_fn=RD.make_layer_fn(pts), hidden_fn=RD.make_hidden_fn(pts),
-                                  front=RD.RoundedLlavaFront(batch, cfg, W, pts), row_chunk=2)
+                                  front=front, row_chunk=2)
         mask = res["labels"][:, 1:] != O.IGNORE_INDEX
         cur = dict(per_token=res["per_token_logps"].float()[mask], log_prob=res["log_prob"].float(), loss=float(res["loss"]),
                    labels=res["labels"])
