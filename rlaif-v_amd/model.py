@@ -363,7 +363,7 @@ class LlavaDPOModel:
         # packed rows are concatenated without inter-row padding (splice.build_packed_plan pad_free; RV_PAD_FREE=0: every packed
         # row right-padded to the longest, the round-1..4 layout).  Log-probs are bit-identical either way (SURVEY 8a property (i))
         self.pad_free = os.environ.get("RV_PAD_FREE", "1") != "0"
-        self.clip_fp32_resid = os.environ.get("RV_CLIP_FP32_RESID", "0") != "0"      # see clip_features
+        self.clip_fp32_resid = os.environ.get("RV_CLIP_FP32_RESID", "1") != "0"      # default ON since round 5, see clip_features
         self.fuse_rope_bwd = os.environ.get("RV_FUSE_ROPE_BWD", "1") != "0"
 
     # ------------------------------------------------------------------ weights
@@ -563,7 +563,7 @@ class LlavaDPOModel:
         x = ops.clip_assemble(pe, c["cls"], c["pos"], B, P)
         x = ops.layernorm_fwd(x, c["pre_ln_w"], c["pre_ln_b"], cfg.clip_eps)
         if self.clip_fp32_resid:
-            # The frozen tower's RESIDUAL STREAM in fp32 (RV_CLIP_FP32_RESID=1, opt-in, round 5): the 47 bf16 roundings of x on the way
+            # The frozen tower's RESIDUAL STREAM in fp32 (default since round 5; RV_CLIP_FP32_RESID=0 = the bf16 stream): the 47 bf16 roundings of x on the way
             # through 23 layers are 84 % of the vision front's share - 27 % of the whole - of the per-token log-prob error variance
             # (profiles/r05_rounding_attribution.json), and the tower is 0.6 % of the step.  Every MFMA operand stays
             # bf16 (LayerNorm outputs, q / k / v, attention output, quick_gelu(fc1)); only out_proj / fc2 accumulate into an fp32 x.

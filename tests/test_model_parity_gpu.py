@@ -330,7 +330,7 @@ def test_pad_free_layout_equals_rectangular_packed_layout(width, monkeypatch):
 
 
 def test_clip_tower_fp32_residual_stream_is_closer_to_fp32(monkeypatch):
-    """RV_CLIP_FP32_RESID=1 (opt-in, round 5): the frozen CLIP tower with its residual stream carried in fp32 - every MFMA operand
+    """RV_CLIP_FP32_RESID (default 1 since round 5): the frozen CLIP tower with its residual stream carried in fp32 - every MFMA operand
     still bf16.  At the production tower (CLIP-ViT-L/14-336: 24 layers, 577 tokens, width 1024) the features handed to the projector
     must sit CLOSER to the fp32 oracle's (dpo_oracle.clip_vision_features, clip_encoder.py:36-58) than the default bf16 stream's do,
     and by a clear factor (the rounding-point study prices the stream at 84 % of the vision front's error variance)."""
