@@ -152,7 +152,10 @@ def test_full_width_shallow_vs_oracle():
     cfg = O.LlavaCfg(layers=2, clip_layers=3, image_size=112, model_max_length=256)   # 64 patches
     model, W = _build(O.asdict(cfg), seed=7)
     tr = _trainer(model)
-    batch = O.make_synthetic_batch(cfg, 1, 48, 16, seed=3)
+    # chosen answer 20 tokens longer than the rejected one: the saturated loss is beta x ~200 nats, so its 1e-3 bar (0.02 absolute)
+    # is several sigma of the two-layer bf16 noise (~0.07 nats on the log-ratio).  The ragged draw used before gave beta x 46 nats:
+    # the bar sat at half a sigma, and the round-5 fp32 CLIP residual stream - a strict numerics IMPROVEMENT - flipped that coin.
+    batch = O.make_synthetic_batch(cfg, 1, 48, 16, seed=3, ragged=False, answer_lens=[(32, 12)])
     loss = tr.compute_loss(model, dict(batch))
     torch.set_num_threads(min(64, os.cpu_count() or 8))
     for k in O.trainable_names(cfg):

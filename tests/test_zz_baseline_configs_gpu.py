@@ -201,6 +201,8 @@ def _stepping_case(fd, golden_dir, case, key):
     fx = _fixture(FD, case, golden_dir)
     if "snap" not in fd:
         fd["snap"] = FD.snapshot(fd["model"])
+    else:
+        FD.restore(fd["model"], fd["trainer"], fd["snap"])       # a case that stepped without restoring (config1_step) ran before
     try:
         hip = FD.hip_case(case, fd["model"], fd["trainer"], fd["cfg"], fx=fx)
     finally:
