@@ -154,7 +154,8 @@ def full_depth():
     W = O.make_weights(cfg, seed=FD.WEIGHT_SEED)
     model, trainer = FD.build_model(cfg, W, with_optimizer=True)
     print(f"  full-depth weights + model: {time.time() - t0:.0f} s")
-    yield dict(FD=FD, cfg=cfg, W=W, model=model, trainer=trainer, live=live)
+    # the pristine parameters, taken BEFORE any case runs: every stepping case starts from (and returns to) them
+    yield dict(FD=FD, cfg=cfg, W=W, model=model, trainer=trainer, live=live, snap=FD.snapshot(model))
     del model, trainer
     torch.cuda.empty_cache()
 
@@ -199,10 +200,7 @@ def _stepping_case(fd, golden_dir, case, key):
     """One stepping case (forward, backward, clip, AdamW) from the shared starting weights; the weights are put back after."""
     FD = fd["FD"]
     fx = _fixture(FD, case, golden_dir)
-    if "snap" not in fd:
-        fd["snap"] = FD.snapshot(fd["model"])
-    else:
-        FD.restore(fd["model"], fd["trainer"], fd["snap"])       # a case that stepped without restoring (config1_step) ran before
+    FD.restore(fd["model"], fd["trainer"], fd["snap"])
     try:
         hip = FD.hip_case(case, fd["model"], fd["trainer"], fd["cfg"], fx=fx)
     finally:
@@ -291,7 +289,11 @@ def test_full_depth_config1_step(full_depth, golden_dir):
     W0 = full_depth["W"]             # the HIP side never touches the CPU dict; only a LIVE oracle run moves it (AdamW in place)
     if full_depth["live"]:
         W0 = {k: v.clone() for k, v in full_depth["W"].items() if not k.startswith(O.VT)}
-    hip = FD.hip_case("cfg1_step", full_depth["model"], full_depth["trainer"], full_depth["cfg"], full_grads=full_depth["live"])
+    FD.restore(full_depth["model"], full_depth["trainer"], full_depth["snap"])
+    try:
+        hip = FD.hip_case("cfg1_step", full_depth["model"], full_depth["trainer"], full_depth["cfg"], full_grads=full_depth["live"])
+    finally:
+        FD.restore(full_depth["model"], full_depth["trainer"], full_depth["snap"])
     fx = _fixture_or_oracle(full_depth, "cfg1_step", golden_dir)
     assert fx["labels"].shape == (8, 1087)
     m = FD.compare("cfg1_step", hip, fx, W0=W0, check=True)
