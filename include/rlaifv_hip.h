@@ -204,6 +204,19 @@ int rv_rmsnorm_bwd_nblocks(int rows);   /* rows of the fp32 dw_partial scratch [
 int rv_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const int* row_idx, const void* w,
                    const float* rstd, const void* dres, long lddres, void* dx, long lddx, float* dw_partial,
                    void* dw, int dw_accumulate, int rows, int d, void* stream);
+/* Opt-in fp32 RESIDUAL STREAM of the decoder (RV_RESID_FP32=1, round 5; HF's LlamaDecoderLayer keeps hidden_states in the model dtype,
+ * llava_llama.py:91-102).  The projection GEMMs write their branch in bf16 WITHOUT the residual operand; these kernels carry the stream:
+ *   rv_rmsnorm_fwd_f32:  add != NULL: xout = x + add (fp32 rows, same row indexing), y = rmsnorm(xout) * w (bf16), rstd;
+ *                        add == NULL: y = rmsnorm(x) * w on the fp32 rows (row_idx gathers rows like rv_rmsnorm_fwd);
+ *                        y == NULL with add: only the sum is written (no norm).
+ *   rv_rmsnorm_bwd_f32x: rv_rmsnorm_bwd reading an fp32 x (gradients stay bf16);
+ *   rv_add_f32_bf16:     out = x + b for the last branch of the stack. */
+int rv_rmsnorm_fwd_f32(const float* x, long ldx, const int* row_idx, const void* add, long ldadd, float* xout, long ldxout,
+                       const void* w, void* y, long ldy, float* rstd, int rows, int d, float eps, void* stream);
+int rv_rmsnorm_bwd_f32x(const void* dy, long lddy, const float* x, long ldx, const int* row_idx, const void* w,
+                        const float* rstd, const void* dres, long lddres, void* dx, long lddx, float* dw_partial,
+                        void* dw, int dw_accumulate, int rows, int d, void* stream);
+int rv_add_f32_bf16(const float* x, const void* b, float* out, long n, void* stream);
 int rv_layernorm_fwd(const void* x, long ldx, const void* w, const void* b, void* y, long ldy, int rows, int d,
                      float eps, void* stream);
 /* the same LayerNorm reading an fp32 input (the fp32 residual stream above); output bf16 (it feeds a bf16 MFMA operand) */

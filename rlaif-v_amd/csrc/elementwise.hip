@@ -39,6 +39,13 @@ __device__ __forceinline__ uint4 dropout_chunk(const uint4 v, long i8, uint32_t 
   return pack8(f);
 }
 
+// 8 consecutive elements of a bf16 or an fp32 row as floats (the fp32 forms carry the opt-in fp32 residual streams)
+__device__ __forceinline__ void ln_load8(const bf16_t* p, float (&f)[8]) { unpack8(*(const uint4*)p, f); }
+__device__ __forceinline__ void ln_load8(const float* p, float (&f)[8]) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
 // ------------------------------------------------------------------ RMSNorm
 // DROP: also writes yd = rv_dropout(y) (contiguous [rows][d], mask index r * d + c): the LoRA branch input of the projection that
 // follows, without a second pass over y
@@ -75,10 +82,77 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   }
 }
 
-// dx = rstd * (g - xhat * mean(g * xhat)) [+ dres], g = dy * w;  dw_partial[block] += dy * xhat
 #define RMS_MAX_ITERS 4
+// The decoder's residual stream in fp32 (RV_RESID_FP32=1, opt-in, round 5: the stream's 64 bf16 roundings are 43 % of the per-token
+// log-prob error variance).  The projection GEMMs keep writing their BRANCH output in bf16 (o_proj / down_proj
+// without the residual operand: the rounding is relative to the small branch, not to the large stream); this kernel adds the branch to
+// the fp32 stream and normalises the sum in one pass:   xout = x + add (fp32, ADD only);   y = rmsnorm(xout or x) * w (bf16).
+// The row's values stay in registers between the two passes (d <= 8192).
+template <bool ADD>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_f32_kernel(const float* __restrict__ x, long ldx,
+                                                              const int* __restrict__ row_idx,
+                                                              const bf16_t* __restrict__ add, long ldadd,
+                                                              float* __restrict__ xout, long ldxout,
+                                                              const bf16_t* __restrict__ w, bf16_t* __restrict__ y, long ldy,
+                                                              float* __restrict__ rstd_out, int rows, int d, float eps) {
+  __shared__ float red[16];
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const long xrow = row_idx ? row_idx[r] : r;
+    const float* xr = x + xrow * ldx;
+    float v[RMS_MAX_ITERS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+      const int c = threadIdx.x * 8 + i * 2048;
+      if (c < d) {
+        ln_load8(xr + c, v[i]);
+        if (ADD) {
+          float a[8];
+          unpack8(*(const uint4*)(add + xrow * ldadd + c), a);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] += a[j];
+          float* o = xout + xrow * ldxout + c;
+          *(float4*)o = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+          *(float4*)(o + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+      }
+    }
+    ss = block_sum(ss, red);
+    const float rs = rsqrtf(ss / (float)d + eps);
+    if (rstd_out && threadIdx.x == 0) rstd_out[r] = rs;
+    if (y) {
+#pragma unroll
+      for (int i = 0; i < RMS_MAX_ITERS; ++i) {
+        const int c = threadIdx.x * 8 + i * 2048;
+        if (c < d) {
+          float g[8], f[8];
+          unpack8(*(const uint4*)(w + c), g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = v[i][j] * rs * g[j];
+          *(uint4*)(y + (long)r * ldy + c) = pack8(f);
+        }
+      }
+    }
+  }
+}
+
+// out (fp32) = x (fp32) + b (bf16): the last branch of the stack joins the fp32 stream (no norm follows it in the layer loop)
+__global__ void add_f32_bf16_kernel(const float* __restrict__ x, const bf16_t* __restrict__ b, float* __restrict__ out, long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8], a[8];
+    ln_load8(x + 8 * i, f);
+    unpack8(((const uint4*)b)[i], a);
+    *(float4*)(out + 8 * i) = make_float4(f[0] + a[0], f[1] + a[1], f[2] + a[2], f[3] + a[3]);
+    *(float4*)(out + 8 * i + 4) = make_float4(f[4] + a[4], f[5] + a[5], f[6] + a[6], f[7] + a[7]);
+  }
+}
+
+// dx = rstd * (g - xhat * mean(g * xhat)) [+ dres], g = dy * w;  dw_partial[block] += dy * xhat
+template <typename XT>      // XT = float: the fp32 residual stream (RV_RESID_FP32); gradients stay bf16
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, long lddy,
-                                                          const bf16_t* __restrict__ x, long ldx,
+                                                          const XT* __restrict__ x, long ldx,
                                                           const int* __restrict__ row_idx,
                                                           const bf16_t* __restrict__ w,
                                                           const float* __restrict__ rstd,
@@ -95,7 +169,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   const int r0 = blockIdx.x * rows_per, r1 = min(rows, r0 + rows_per);
   for (int r = r0; r < r1; ++r) {
     const long xrow = row_idx ? row_idx[r] : r;
-    const bf16_t* xr = x + xrow * ldx;
+    const XT* xr = x + xrow * ldx;
     const bf16_t* dyr = dy + (long)r * lddy;
     const float rs = rstd[r];
     float dot = 0.f;
@@ -104,7 +178,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       const int c = threadIdx.x * 8 + i * 2048;
       if (c < d) {
         float fx[8], fy[8], fw[8];
-        unpack8(*(const uint4*)(xr + c), fx);
+        ln_load8(xr + c, fx);
         unpack8(*(const uint4*)(dyr + c), fy);
         unpack8(*(const uint4*)(w + c), fw);
 #pragma unroll
@@ -122,7 +196,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       const int c = threadIdx.x * 8 + i * 2048;
       if (c < d) {
         float fx[8], fy[8], fw[8], o[8];
-        unpack8(*(const uint4*)(xr + c), fx);
+        ln_load8(xr + c, fx);
         unpack8(*(const uint4*)(dyr + c), fy);
         unpack8(*(const uint4*)(w + c), fw);
 #pragma unroll
@@ -170,11 +244,6 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // ------------------------------------------------------------------ LayerNorm (CLIP, forward only)
 // XT = bf16_t: the tower's bf16 residual stream; XT = float: the fp32 residual stream of RV_CLIP_FP32_RESID (round 5: the frozen tower's
 // residual stream carried in fp32 - 84 % of the vision front's share of the per-token error, DESIGN section 2 - output stays bf16)
-__device__ __forceinline__ void ln_load8(const bf16_t* p, float (&f)[8]) { unpack8(*(const uint4*)p, f); }
-__device__ __forceinline__ void ln_load8(const float* p, float (&f)[8]) {
-  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
-  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-}
 template <typename XT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const XT* __restrict__ x, long ldx,
                                                             const bf16_t* __restrict__ w,
@@ -1020,12 +1089,52 @@ int rv_rmsnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const int
   RV_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && lddres % 8 == 0, "rv_rmsnorm_bwd: ld alignment");
   if (rows == 0) return 0;
   const int nb = rv_rmsnorm_bwd_nblocks(rows);
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, lddy,
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, lddy,
                      (const bf16_t*)x, ldx, row_idx, (const bf16_t*)w, rstd, (const bf16_t*)dres, lddres,
                      (bf16_t*)dx, lddx, dw_partial, rows, d);
   RV_CHECK_LAUNCH();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, STREAM(stream), dw_partial, nb, d,
                      (bf16_t*)dw, dw_accumulate);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_rmsnorm_bwd_f32x(const void* dy, long lddy, const float* x, long ldx, const int* row_idx, const void* w,
+                        const float* rstd, const void* dres, long lddres, void* dx, long lddx, float* dw_partial,
+                        void* dw, int dw_accumulate, int rows, int d, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && d <= 2048 * RMS_MAX_ITERS, "rv_rmsnorm_bwd_f32x: d must be a multiple of 8 and <= 8192");
+  RV_REQUIRE(lddy % 8 == 0 && ldx % 4 == 0 && lddx % 8 == 0 && lddres % 8 == 0, "rv_rmsnorm_bwd_f32x: ld alignment");
+  if (rows == 0) return 0;
+  const int nb = rv_rmsnorm_bwd_nblocks(rows);
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel<float>, dim3(nb), dim3(256), 0, STREAM(stream), (const bf16_t*)dy, lddy, x, ldx, row_idx,
+                     (const bf16_t*)w, rstd, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dw_partial, rows, d);
+  RV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, STREAM(stream), dw_partial, nb, d,
+                     (bf16_t*)dw, dw_accumulate);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_rmsnorm_fwd_f32(const float* x, long ldx, const int* row_idx, const void* add, long ldadd, float* xout, long ldxout,
+                       const void* w, void* y, long ldy, float* rstd, int rows, int d, float eps, void* stream) {
+  RV_REQUIRE(d % 8 == 0 && d <= 2048 * RMS_MAX_ITERS && ldx % 4 == 0 && ldy % 8 == 0, "rv_rmsnorm_fwd_f32: d % 8, d <= 8192, ld alignment");
+  RV_REQUIRE(add == nullptr || (xout != nullptr && ldadd % 8 == 0 && ldxout % 4 == 0), "rv_rmsnorm_fwd_f32: add needs xout (fp32) and aligned strides");
+  RV_REQUIRE(y != nullptr || add != nullptr, "rv_rmsnorm_fwd_f32: nothing to write");
+  if (rows == 0) return 0;
+  if (add)
+    hipLaunchKernelGGL(rmsnorm_fwd_f32_kernel<true>, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), x, ldx, row_idx,
+                       (const bf16_t*)add, ldadd, xout, ldxout, (const bf16_t*)w, (bf16_t*)y, ldy, rstd, rows, d, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_fwd_f32_kernel<false>, dim3(min(rows, 8192)), dim3(256), 0, STREAM(stream), x, ldx, row_idx,
+                       (const bf16_t*)nullptr, 0L, (float*)nullptr, 0L, (const bf16_t*)w, (bf16_t*)y, ldy, rstd, rows, d, eps);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+int rv_add_f32_bf16(const float* x, const void* b, float* out, long n, void* stream) {
+  RV_REQUIRE(n % 8 == 0, "rv_add_f32_bf16: n%8");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_f32_bf16_kernel, dim3(grid_for(n / 8, 256, 8192)), dim3(256), 0, STREAM(stream), x, (const bf16_t*)b, out, n / 8);
   RV_CHECK_LAUNCH();
   return 0;
 }

@@ -363,6 +363,10 @@ class LlavaDPOModel:
         # packed rows are concatenated without inter-row padding (splice.build_packed_plan pad_free; RV_PAD_FREE=0: every packed
         # row right-padded to the longest, the round-1..4 layout).  Log-probs are bit-identical either way (SURVEY 8a property (i))
         self.pad_free = os.environ.get("RV_PAD_FREE", "1") != "0"
+        # OPT-IN: the DECODER's residual stream in fp32 (RV_RESID_FP32=1).  o_proj / down_proj write their branch in bf16 without the
+        # residual operand; rv_rmsnorm_fwd_f32 adds it to the fp32 stream and normalises in one pass.  -25 % per-token RMS error for
+        # ~ +1.3 % step time: below the adoption line VERDICT r4 drew (sigma < 1.5e-3 for <= 1 %), so it stays off
+        self.resid_fp32 = os.environ.get("RV_RESID_FP32", "0") != "0"
         self.clip_fp32_resid = os.environ.get("RV_CLIP_FP32_RESID", "1") != "0"      # default ON since round 5, see clip_features
         self.fuse_rope_bwd = os.environ.get("RV_FUSE_ROPE_BWD", "1") != "0"
 
@@ -698,11 +702,18 @@ class LlavaDPOModel:
         qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0, xd=xnd)
         ops.rope_inplace(qkv, cos, sin, L, H + cfg.n_kv_heads, hd, pos=plan.pos)      # q heads then k heads
         attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, d + cfg.kv_dim, seg=plan.seg, kv_group=cfg.kv_group, rows=plan.rows)
-        x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
-        if drop:
-            xn2, rstd2, xn2d = ops.rmsnorm_fwd_dropout(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps, p_drop, self._dropout_seed(i, 2))
+        if self.resid_fp32:
+            if drop:
+                raise NotImplementedError("RV_RESID_FP32 with the producer-side LoRA dropout kernels (set RV_LORA_FUSED_DROPOUT=0)")
+            o, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=None, drop_slot=1)          # the BRANCH, bf16
+            x_mid, xn2, rstd2 = ops.add_rmsnorm_fwd(x, o, st.p(f"layers.{i}.ln2"), cfg.rms_eps)   # fp32 stream + norm, one pass
+            del o
         else:
-            xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
+            x_mid, t_o, xd_o = self._proj_fwd(attn, i, "o", residual=x, drop_slot=1)
+            if drop:
+                xn2, rstd2, xn2d = ops.rmsnorm_fwd_dropout(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps, p_drop, self._dropout_seed(i, 2))
+            else:
+                xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
         if st.interleave_gu:          # full fine-tune: SwiGLU in the epilogue of the gate|up GEMM (interleaved weight rows)
             gu, act = ops.linear_swiglu(xn2, st.pT(f"layers.{i}.wgu"))
             t_gu = xd_gu = None
@@ -712,7 +723,12 @@ class LlavaDPOModel:
                 act, actd = ops.swiglu_fwd_dropout(gu, p_drop, self._dropout_seed(i, 3))
             else:
                 act = ops.swiglu_fwd(gu)
-        x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3, xd=actd)
+        if self.resid_fp32:
+            dwn, t_down, xd_down = self._proj_fwd(act, i, "down", residual=None, drop_slot=3, xd=actd)
+            x_next = ops.add_f32_bf16(x_mid, dwn)
+            del dwn
+        else:
+            x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3, xd=actd)
         if not save:
             return x_next, None
         keep = self.keep_recomputable
@@ -765,6 +781,8 @@ class LlavaDPOModel:
         N = plan.n_tokens                # S * L in the rectangular layouts, the sum of the packed rows' lengths when pad-free
         feats = self.encode_images(images, ctx if save_for_backward else None)
         x = ops.splice_fwd(plan.src, st.p("model.embed_tokens.weight"), feats, d)
+        if self.resid_fp32:
+            x = ops.cast_bf16_to_f32(x)          # embedding / feature rows are bf16 values: exact
         cos, sin = self._rope(L)
         layers_ctx = []
         for i in range(cfg.layers):
@@ -904,6 +922,8 @@ class LlavaDPOModel:
         if S * L * cfg.vocab * 2 > (16 << 30):
             raise ValueError("forward(): logits would exceed 16 GB - use forward_logps (fused LM head) for training shapes")
         x = inputs_embeds.to(self.device, BF16).reshape(S * L, d).contiguous()
+        if self.resid_fp32:
+            x = ops.cast_bf16_to_f32(x)
         plan = SimpleNamespace(S=S, L=L, pos=None, seg=None, rows=None)
         cos, sin = self._rope(L)
         for i in range(cfg.layers):

@@ -281,8 +281,25 @@ def rmsnorm_fwd(x, w, eps: float, row_idx: Optional[torch.Tensor] = None, out=No
     if out is None:
         out = torch.empty(rows, d, dtype=BF16, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_rstd else None
+    if x.dtype == torch.float32:       # the opt-in fp32 residual stream (RV_RESID_FP32): same call, fp32 rows in
+        hip.call("rv_rmsnorm_fwd_f32", x, x.stride(0), row_idx, None, 0, None, 0, w, out, out.stride(0), rstd, rows, d, float(eps))
+        return out, rstd
     hip.call("rv_rmsnorm_fwd", x, x.stride(0), row_idx, w, out, out.stride(0), rstd, rows, d, float(eps))
     return out, rstd
+
+
+def add_rmsnorm_fwd(x32: torch.Tensor, branch: torch.Tensor, w, eps: float, want_norm: bool = True):
+    """fp32 residual stream: (x32 + branch [fp32, new buffer], rmsnorm(sum) * w [bf16], rstd) in one pass (rv_rmsnorm_fwd_f32 with
+    ``add``).  ``branch``: the bf16 output of o_proj / down_proj WITHOUT the residual operand.  want_norm=False: only the sum."""
+    if x32.dtype != torch.float32 or branch.dtype != BF16 or x32.shape != branch.shape:
+        raise ValueError("add_rmsnorm_fwd: fp32 stream and bf16 branch of equal shape required")
+    rows, d = x32.shape
+    xout = torch.empty_like(x32)
+    y = torch.empty(rows, d, dtype=BF16, device=x32.device) if want_norm else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x32.device) if want_norm else None
+    hip.call("rv_rmsnorm_fwd_f32", x32, x32.stride(0), None, branch, branch.stride(0), xout, xout.stride(0), w, y,
+             y.stride(0) if y is not None else 0, rstd, rows, d, float(eps))
+    return xout, y, rstd
 
 
 def rmsnorm_fwd_dropout(x, w, eps: float, p: float, seed: int, row_idx: Optional[torch.Tensor] = None, want_rstd: bool = True):
@@ -304,10 +321,14 @@ def rmsnorm_bwd(dy, x, w, rstd, dw: torch.Tensor, dres: Optional[torch.Tensor] =
     """dx (same row indexing as x) = rmsnorm backward (+ dres); dw (bf16 [d]) written or accumulated."""
     _chk2d(dy, "dy"), _chk2d(x, "x")
     rows, d = dy.shape
-    if dx is None:
-        dx = torch.empty_like(x) if row_idx is None else torch.zeros_like(x)
+    if dx is None:      # (bf16 whatever the stream's dtype: gradients stay bf16 under the fp32 residual stream)
+        dx = (torch.empty if row_idx is None else torch.zeros)(x.shape, dtype=BF16, device=x.device)
     nb = hip.lib().lib.rv_rmsnorm_bwd_nblocks(rows)
     partial = torch.empty(nb, d, dtype=torch.float32, device=x.device)
+    if x.dtype == torch.float32:       # fp32 residual stream: x is fp32, the gradient stream stays bf16
+        hip.call("rv_rmsnorm_bwd_f32x", dy, dy.stride(0), x, x.stride(0), row_idx, w, rstd, dres,
+                 dres.stride(0) if dres is not None else 0, dx, dx.stride(0), partial, dw, int(dw_accumulate), rows, d)
+        return dx
     hip.call("rv_rmsnorm_bwd", dy, dy.stride(0), x, x.stride(0), row_idx, w, rstd, dres,
              dres.stride(0) if dres is not None else 0, dx, dx.stride(0), partial, dw, int(dw_accumulate), rows, d)
     return dx
@@ -651,6 +672,13 @@ def grad_norm(g: torch.Tensor, max_norm: float, out2: Optional[torch.Tensor] = N
         out2 = torch.empty(2, dtype=torch.float32, device=g.device)
     hip.call("rv_grad_norm", g, g.numel(), partial, float(max_norm), float(pre_scale), out2)
     return out2
+
+
+def add_f32_bf16(x32: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """x32 + b (fp32 stream + bf16 branch) -> new fp32 buffer (rv_add_f32_bf16)."""
+    out = torch.empty_like(x32)
+    hip.call("rv_add_f32_bf16", x32, b, out, x32.numel())
+    return out
 
 
 def grad_sumsq(g: torch.Tensor, out1: torch.Tensor, accumulate: bool = False):

@@ -356,6 +356,61 @@ def test_clip_tower_fp32_residual_stream_is_closer_to_fp32(monkeypatch):
     assert errs["1"] < 0.7 * errs["0"] and errs["0"] < 3e-2
 
 
+@pytest.mark.parametrize("width", ["tiny", "full"])
+def test_fp32_residual_stream_option(width, monkeypatch):
+    """RV_RESID_FP32=1 (opt-in, round 5): the decoder's residual stream carried in fp32 - o_proj / down_proj write their branch in
+    bf16 without the residual operand, rv_rmsnorm_fwd_f32 adds it to the stream and normalises in one pass, rv_rmsnorm_bwd_f32x
+    reads the fp32 stream in backward.  Same function, fewer roundings: against the fp32 oracle the option must meet the default
+    path's bars AND sit closer (per-token log-prob error), forward and backward, packed layout; gradient checkpointing recomputes
+    bit-identically under it."""
+    _need_gpu()
+    monkeypatch.setenv("SFT_weight", "0.0")
+    monkeypatch.setenv("DPO_weight", "1.0")
+    if width == "full":
+        if torch.cuda.get_device_properties(0).total_memory < 100 * 2**30:
+            pytest.skip("needs the 288 GB part")
+        cfg = O.LlavaCfg(layers=4, clip_layers=3, image_size=112, model_max_length=1024)
+        batch = O.make_synthetic_batch(cfg, 2, 300, 24, seed=29, ragged=False, answer_lens=[(276, 120), (200, 90)])
+    else:
+        cfg = O.tiny_cfg()
+        cfg.layers = 4
+        batch = O.make_synthetic_batch(cfg, 2, 60, 12, seed=29, ragged=False, answer_lens=[(48, 20), (40, 16)])
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    W = O.make_weights(cfg, seed=14)
+    for k in O.trainable_names(cfg):
+        W[k].requires_grad_(True)
+    ref = O.dpo_step_forward(batch, W, cfg, sft_weight=0.0, dpo_weight=1.0)
+    ref["loss"].backward()
+    mask = ref["labels"][:, 1:] != -100
+    tok_ref = ref["per_token_logps"].detach()[mask]
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RV_RESID_FP32", flag)
+        model, _ = _build(O.asdict(cfg), seed=14)
+        assert model.resid_fp32 == (flag == "1")
+        tr = _trainer(model)
+        model.train()
+        loss = tr.compute_loss(model, dict(batch))
+        out = model.last_out
+        model.backward(out, model.last_coef)
+        g = model.grads_state_dict()
+        tok = (out.per_token_logp.cpu() - tok_ref)
+        worst_c = min(_cos(g[k], W[k].grad) for k in g if float(W[k].grad.norm()) > 1e-9)
+        res[flag] = dict(loss=float(loss), rms=float(tok.pow(2).mean().sqrt()), seq=out.seq_logp.cpu().clone(), cos=worst_c, flat=model.store.flat_g.clone())
+        if flag == "1":        # --gradient_checkpointing under the fp32 stream: the re-run layer reproduces the kept activations exactly
+            tr2 = _trainer(model, gradient_checkpointing=True)
+            tr2.compute_loss(model, dict(batch))
+            model.backward(model.last_out, model.last_coef)
+            assert torch.equal(model.store.flat_g, res["1"]["flat"])
+    lp_ref = ref["log_prob"].detach()
+    for flag, r in res.items():
+        assert bool(((r["seq"] - lp_ref).abs() <= 1e-3 * lp_ref.abs()).all()) and abs(r["loss"] - float(ref["loss"])) <= 1e-3 * abs(float(ref["loss"]))
+        assert r["cos"] >= 0.99
+    print(f"fp32 residual stream ({width}, 4 layers): per-token RMS error {res['0']['rms']:.3e} -> {res['1']['rms']:.3e}; worst gradient cosine "
+          f"{res['0']['cos']:.5f} -> {res['1']['cos']:.5f}")
+    assert res["1"]["rms"] < res["0"]["rms"]
+
+
 def test_full_size_7b_properties():
     """BASELINE config 2 at FULL size (32 layers, 7B widths, L = 2048, CLIP-L/14-336): the oracle cannot run it in
     seconds, so parity is checked through size-independent properties of the reference (SURVEY.md section 8a [probe]):
