@@ -274,8 +274,17 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
 
 
 # ------------------------------------------------------------------------------------- norms etc.
+def _chk_stream(x, name):
+    """a residual-stream operand: 2-D bf16, or 2-D fp32 with unit inner stride (the opt-in fp32 stream)"""
+    if x.dtype == torch.float32:
+        if not (x.is_cuda and x.dim() == 2 and x.stride(1) == 1):
+            raise ValueError(f"{name}: expected a 2-D fp32 CUDA tensor with unit column stride")
+    else:
+        _chk2d(x, name)
+
+
 def rmsnorm_fwd(x, w, eps: float, row_idx: Optional[torch.Tensor] = None, out=None, want_rstd: bool = True):
-    _chk2d(x, "x")
+    _chk_stream(x, "x")
     rows = x.shape[0] if row_idx is None else row_idx.numel()
     d = x.shape[1]
     if out is None:
@@ -319,7 +328,7 @@ def rmsnorm_bwd(dy, x, w, rstd, dw: torch.Tensor, dres: Optional[torch.Tensor] =
                 row_idx: Optional[torch.Tensor] = None, dx: Optional[torch.Tensor] = None,
                 dw_accumulate: bool = False) -> torch.Tensor:
     """dx (same row indexing as x) = rmsnorm backward (+ dres); dw (bf16 [d]) written or accumulated."""
-    _chk2d(dy, "dy"), _chk2d(x, "x")
+    _chk2d(dy, "dy"), _chk_stream(x, "x")
     rows, d = dy.shape
     if dx is None:      # (bf16 whatever the stream's dtype: gradients stay bf16 under the fp32 residual stream)
         dx = (torch.empty if row_idx is None else torch.zeros)(x.shape, dtype=BF16, device=x.device)
