@@ -317,6 +317,47 @@ def test_rmsnorm_fwd_bwd(ops, rows, d):
     close(dw2, 2 * wf.grad, rel=3e-2, what="rmsnorm dw accumulate")
 
 
+@pytest.mark.parametrize("rows,d", [(333, 512), (1000, 4096), (5, 8192)])
+def test_rmsnorm_fp32_stream_kernels(ops, rows, d):
+    """The kernels of the opt-in fp32 residual stream (RV_RESID_FP32): on a bf16-representable stream they are bit-identical to the
+    bf16 kernels (same arithmetic, wider load); the fused add + norm equals add then norm; row gather; backward with fp32 x."""
+    dev = _dev()
+    xb = rnd(rows, d, seed=1, dev=dev)
+    w = rnd(d, seed=2, dev=dev, scale=0.3) + 1
+    y_b, r_b = ops.rmsnorm_fwd(xb, w, 1e-5)
+    y_f, r_f = ops.rmsnorm_fwd(xb.float(), w, 1e-5)
+    assert torch.equal(y_b, y_f) and torch.equal(r_b, r_f)
+    # fused add + norm on a genuinely fp32 stream
+    x32 = torch.randn(rows, d, generator=torch.Generator().manual_seed(3)).to(dev) * 2.0
+    br = rnd(rows, d, seed=4, dev=dev, scale=0.2)
+    xo, y, rstd = ops.add_rmsnorm_fwd(x32, br, w, 1e-5)
+    ref_sum = x32 + br.float()
+    assert torch.equal(xo, ref_sum) and torch.equal(ops.add_f32_bf16(x32, br), ref_sum)
+    y2, rstd2 = ops.rmsnorm_fwd(ref_sum, w, 1e-5)
+    assert torch.equal(y, y2) and torch.equal(rstd, rstd2)
+    xh = ref_sum * torch.rsqrt(ref_sum.pow(2).mean(-1, keepdim=True) + 1e-5)
+    close(y, xh * w.float(), rel=1e-2, what="add + rmsnorm fp32 stream")
+    xo3, none_y, none_r = ops.add_rmsnorm_fwd(x32, br, w, 1e-5, want_norm=False)
+    assert none_y is None and none_r is None and torch.equal(xo3, ref_sum)
+    # row gather (the final norm on the selected rows)
+    idx = torch.randperm(rows, generator=torch.Generator().manual_seed(5))[: max(1, rows // 3)].to(torch.int32).to(dev)
+    yg, rg = ops.rmsnorm_fwd(ref_sum, w, 1e-5, row_idx=idx)
+    assert torch.equal(yg, y2[idx.long()]) and torch.equal(rg, rstd2[idx.long()])
+    # backward: fp32 x == bf16 x when the stream is bf16-representable; and against torch on a genuinely fp32 stream
+    dy, dres = rnd(rows, d, seed=6, dev=dev), rnd(rows, d, seed=7, dev=dev)
+    dw_b, dw_f = torch.empty(d, dtype=BF, device=dev), torch.empty(d, dtype=BF, device=dev)
+    dx_b = ops.rmsnorm_bwd(dy, xb, w, r_b, dw_b, dres=dres)
+    dx_f = ops.rmsnorm_bwd(dy, xb.float(), w, r_b, dw_f, dres=dres)
+    assert dx_f.dtype == BF and torch.equal(dx_b, dx_f) and torch.equal(dw_b, dw_f)
+    xr = ref_sum.clone().requires_grad_(True)
+    wr = w.float().clone().requires_grad_(True)
+    (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * wr).backward(dy.float())
+    dw = torch.empty(d, dtype=BF, device=dev)
+    dx = ops.rmsnorm_bwd(dy, ref_sum, w, rstd2, dw)
+    close(dx, xr.grad, rel=2e-2, what="rmsnorm bwd fp32 x")
+    close(dw, wr.grad, rel=2e-2, what="rmsnorm bwd fp32 x: dw")
+
+
 def test_rmsnorm_row_gather_scatter(ops):
     dev = _dev()
     rows, d = 64, 256
