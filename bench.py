@@ -590,7 +590,7 @@ def main():
             # any other workload reports traffic = null instead of a constant that does not describe it
             pmc_config_matches = (not args.lora and not args.omnilmm and not args.ragged and args.layers == 32 and L == 2048 and B == 8
                                   and not args.gradient_checkpointing)        # per GPU: weak scaling keeps it
-            for name in (() if not pmc_config_matches else ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")):   # newest committed PMC passes first
+            for name in (() if not pmc_config_matches else ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")):   # newest committed PMC passes first
                 try:   # HBM bytes per GEMM launch (profiles/, separate rocprofv3 --pmc runs of this same command)
                     with open(os.path.join(REPO, "profiles", name)) as fh:
                         traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]

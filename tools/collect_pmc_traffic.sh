@@ -10,7 +10,7 @@ cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf "/tmp/pmc_$C"
   timeout 900 rocprofv3 --pmc $C --kernel-trace -d "/tmp/pmc_$C" -- python "$R/bench.py" --steps 1 --warmup 1 \
-      --no-cpu-baseline --no-gemm-timer > "$R/gpurun_out/pmc_$C.log" 2>&1
+      --no-cpu-baseline --no-gemm-timer --no-dp-probe > "$R/gpurun_out/pmc_$C.log" 2>&1
 done
 cd "$R"
 python tools/rocpd_pmc.py --json "$(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1)" \

@@ -15,6 +15,7 @@
 #   lora          bench.py --lora --seq-len 4096 --pairs-per-gpu 4
 #   omnilmm       bench.py --omnilmm (config 4 from pixels)
 #   prof          rocprofv3 --kernel-trace --stats of the headline bench (3 steps)
+#   pmc           HBM traffic per GEMM launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
 #   smoke         __graft_entry__.smoke()
 R=${RV_ROUND:-r05}
 export RV_ROUND=$R
@@ -37,6 +38,7 @@ for st in "$@"; do
     lora)      timeout 600 python bench.py --lora --seq-len 4096 --pairs-per-gpu 4 --no-dp-probe > $OUT/bench_line_lora.json 2> $OUT/bench_lora_err.log; head -c 600 $OUT/bench_line_lora.json; echo ;;
     omnilmm)   timeout 900 python bench.py --omnilmm --no-dp-probe > $OUT/bench_line_omnilmm_pixels.json 2> $OUT/bench_omnilmm_err.log; head -c 600 $OUT/bench_line_omnilmm_pixels.json; echo ;;
     prof)      bash tools/profile_bench.sh $R/bench_kernel python $PWD/bench.py --steps 3 --no-cpu-baseline --no-dp-probe --no-gemm-timer; head -25 gpurun_out/$R/bench_kernel_stats.csv ;;
+    pmc)       bash tools/collect_pmc_traffic.sh > $OUT/pmc_collect.log 2>&1; cp gpurun_out/pmc_hbm_traffic.json $OUT/pmc_hbm_traffic.json; tail -c 400 $OUT/pmc_hbm_traffic.json; echo ;;
     smoke)     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log ;;
     *)         echo "unknown stage $st" ;;
   esac
