@@ -564,18 +564,25 @@ def test_full_depth_harness_compare_logic():
     names = ["model.layers.0.mlp.down_proj.weight", "model.norm.weight"]
     gs = {k: torch.randn(FD.N_SAMPLE, generator=g) * 1e-2 for k in names}
     w0 = {k: torch.randn(4096, generator=g) * 0.02 for k in names}
-    post = {k: w0[k][FD.sample_index(k, 4096)] - lr * torch.sign(gs[k]) for k in names}
+    def adam1(k, grad, c):          # AdamW step 1 on the sampled elements (decay on the projection, none on the norm gain)
+        p0, gc = w0[k][FD.sample_index(k, 4096)].double(), grad.double() * c
+        return (p0 * ((1 - lr * 0.01) if O.is_decay_param(k) else 1.0) - lr * gc / (gc.abs() + 1e-8)).float()
+
+    post = {k: adam1(k, gs[k], clip) for k in names}
     fx = dict(case="cfg1_step", layers=32, labels=labels, per_token=per_tok, log_prob=seq, loss=13.78,
               emu_per_token=per_tok + 0.04 * torch.randn(per_tok.shape, generator=g), emu_log_prob=seq * 1.0002, emu_loss=13.79,
               grad_norms={k: float(v.norm()) for k, v in gs.items()}, grad_samples=gs, post_samples=post,
               grad_norm_total=811.0, clip_coef=clip, lr=lr)
     noise = lambda t, s: t + s * torch.randn(t.shape, generator=g)                      # noqa: E731
+    hip_gs = {k: noise(v, 3e-4) for k, v in gs.items()}
     hip = dict(tgt=labels[:, 1:][mask], seq_cnt=mask.sum(1).float(), log_prob=seq * (1 + 1e-4), per_token=noise(per_tok, 0.02),
                loss=13.78 * (1 + 2e-4), grad_norms={k: v * 1.002 for k, v in fx["grad_norms"].items()},
-               grad_samples={k: noise(v, 3e-4) for k, v in gs.items()}, grad_norm_total=811.5, clip_coef=clip * 0.9995,
-               post_samples={k: v.clone() for k, v in post.items()}, m_samples={k: 0.1 * clip * v for k, v in gs.items()})
+               grad_samples=hip_gs, grad_norm_total=811.5, clip_coef=clip * 0.9995,
+               post_samples={k: adam1(k, hip_gs[k], clip * 0.9995) for k in names},      # the path's OWN gradient through AdamW
+               m_samples={k: 0.1 * clip * v for k, v in hip_gs.items()})
     m = FD.compare("cfg1_step", hip, fx, W0=w0, check=True)
-    assert m["indexing_bit_exact"] and m["master_update_agree_frac"] == 1.0 and m["grad_worst_sample_cosine"] > 0.999
+    assert m["indexing_bit_exact"] and m["master_update_agree_frac_large_grads"] > 0.99 and m["grad_worst_sample_cosine"] > 0.999
+    assert m["optimizer_self_consistency_frac"] == 1.0
     bad = copy.deepcopy(hip); bad["tgt"] = hip["tgt"].clone(); bad["tgt"][3] += 1
     with pytest.raises(AssertionError, match="indexing"):
         FD.compare("cfg1_step", bad, fx, W0=w0)
