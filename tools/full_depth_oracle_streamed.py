@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--no-emulation", action="store_true")
     ap.add_argument("--emu-backward", action="store_true", help="fresh run: also produce the bf16-emulated backward yardstick")
     ap.add_argument("--add-emu-backward", action="store_true",
-                    help="load the base's existing fixtures and ADD the bf16-emulated oracle's backward (emu_grad_norms / emu_grad_samples: "
+                    help="load the base's existing fixtures and ADD the bf16-emulated oracle's backward (emu_grad_norms / emu_grad_cos: "
                          "the yardstick of the per-tensor gradient bars); the fp32 run is not repeated")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
