@@ -111,3 +111,30 @@ def test_streamed_omnilmm_front_equals_one_graph():
     for k in got:
         gr = Wg[k].grad
         assert torch.allclose(got[k], gr, rtol=1e-4, atol=1e-6 * float(gr.abs().max()) + 1e-12), k
+
+
+def test_rounding_study_layer_is_the_oracle_layer_when_no_point_is_selected():
+    """oracle/rounding.py (the rounding-point attribution of round 5): with no point selected its decoder layer, its CLIP tower and its
+    front ARE the oracle's (bit for bit), with every point selected the log-probs move by a bf16-sized amount, and the streamed runner
+    accepts the hooks (layer_fn / hidden_fn / front) forward-only."""
+    from oracle import rounding as RD
+    cfg = O.tiny_cfg()
+    cfg.layers = 2
+    W = O.make_weights(cfg, seed=31)
+    batch = O.make_synthetic_batch(cfg, 2, 40, prompt_len=12, seed=5, image_pos=5)
+    base = S.dpo_step_streamed(batch, W, cfg, backward=False)
+    none = S.dpo_step_streamed(batch, W, cfg, backward=False, layer_fn=RD.make_layer_fn(""), hidden_fn=RD.make_hidden_fn(""),
+                               front=RD.RoundedLlavaFront(batch, cfg, W, ""))
+    assert torch.equal(none["per_token_logps"], base["per_token_logps"])
+    res_none = S.dpo_step_streamed(batch, W, cfg, backward=False, layer_fn=RD.make_layer_fn(""), front=RD.ResolvedLlavaFront(batch, cfg, W, ""))
+    assert torch.allclose(res_none["per_token_logps"], base["per_token_logps"], rtol=0, atol=1e-5)
+    px = torch.cat([batch["images"], batch["images"]], 0)
+    assert torch.equal(RD.clip_features_rounded(px, W, cfg, ""), O.clip_vision_features(px, W, cfg))
+    allp = S.dpo_step_streamed(batch, W, cfg, backward=False, layer_fn=RD.make_layer_fn(RD.ALL_POINTS),
+                               hidden_fn=RD.make_hidden_fn(RD.ALL_POINTS), front=RD.RoundedLlavaFront(batch, cfg, W, RD.ALL_POINTS))
+    mask = base["labels"][:, 1:] != O.IGNORE_INDEX
+    d = (allp["per_token_logps"] - base["per_token_logps"])[mask].abs()
+    assert 1e-5 < float(d.mean()) < 5e-2
+    only_r = S.dpo_step_streamed(batch, W, cfg, backward=False, layer_fn=RD.make_layer_fn("R"))
+    d_r = (only_r["per_token_logps"] - base["per_token_logps"])[mask].abs()
+    assert 0 < float(d_r.mean()) < float(d.mean())
