@@ -74,10 +74,20 @@ SLOTS = ((("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), "hidden"
          (("mlp.gate_proj", "mlp.up_proj"), "hidden"), (("mlp.down_proj",), "ffn"))
 
 
-def layer_masks(layer: int, rows: int, hidden: int, ffn: int, p: float, step: int = 1, rank: int = 0):
-    """{module name: multiplier [rows, in]} of one decoder layer as the HIP model draws them in its ``step``-th training forward
-    (q / k / v and gate / up share one mask: the fused projection drops its input once - DESIGN section 5, conscious deviation)."""
+MODULE_SLOTS = {"self_attn.q_proj": 0, "self_attn.o_proj": 1, "mlp.gate_proj": 2, "mlp.down_proj": 3,
+                "self_attn.k_proj": 4, "self_attn.v_proj": 5, "mlp.up_proj": 6}
+
+
+def layer_masks(layer: int, rows: int, hidden: int, ffn: int, p: float, step: int = 1, rank: int = 0, per_module: bool = False):
+    """{module name: multiplier [rows, in]} of one decoder layer as the HIP model draws them in its ``step``-th training forward.
+    Default: q / k / v and gate / up share one mask (the fused projection drops its input once - DESIGN section 5, conscious
+    deviation).  ``per_module`` (RV_LORA_PEFT_MASKS=1, ``LlavaDPOModel._module_seeds``): every peft module its own mask, like peft's
+    one nn.Dropout per lora.Linear - k, v and up draw from the layer's spare seed slots 4, 5, 6."""
     out = {}
+    if per_module:
+        for mod, slot in MODULE_SLOTS.items():
+            out[f"model.layers.{layer}.{mod}"] = multiplier(rows, ffn if mod == "mlp.down_proj" else hidden, p, model_seed(step, rank, layer, slot))
+        return out
     for slot, (mods, w) in enumerate(SLOTS):
         m = multiplier(rows, hidden if w == "hidden" else ffn, p, model_seed(step, rank, layer, slot))
         for mod in mods:

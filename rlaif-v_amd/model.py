@@ -367,6 +367,10 @@ class LlavaDPOModel:
         # residual operand; rv_rmsnorm_fwd_f32 adds it to the fp32 stream and normalises in one pass.  -25 % per-token RMS error for
         # ~ +1.3 % step time: below the adoption line VERDICT r4 drew (sigma < 1.5e-3 for <= 1 %), so it stays off
         self.resid_fp32 = os.environ.get("RV_RESID_FP32", "0") != "0"
+        # OPT-IN: peft's dropout semantics to the letter (RV_LORA_PEFT_MASKS=1): peft wraps every nn.Linear in its own lora.Linear with
+        # its OWN nn.Dropout, so q / k / v (and gate / up) draw INDEPENDENT masks of the same input.  The default fuses them: one
+        # dropped input per fused projection (same marginals, one pass over the activation instead of three).  See _module_seeds.
+        self.lora_peft_masks = os.environ.get("RV_LORA_PEFT_MASKS", "0") != "0"
         self.clip_fp32_resid = os.environ.get("RV_CLIP_FP32_RESID", "1") != "0"      # default ON since round 5, see clip_features
         self.fuse_rope_bwd = os.environ.get("RV_FUSE_ROPE_BWD", "1") != "0"
 
@@ -637,6 +641,20 @@ class LlavaDPOModel:
         W = st.p(f"layers.{i}.w{grp}")
         if self.lora is None:
             return ops.linear(x, W, st.pT(f"layers.{i}.w{grp}"), residual=residual), None, None
+        if self.lora_peft_masks and self._lora_drop():
+            # one independent mask per peft module: t_g = (alpha / r) dropout_g(x) A_g^T, a skinny GEMM per module (the dropped
+            # copies are regenerated from their seeds in backward)
+            rp, A = self.lora.r_pad, st.p(f"layers.{i}.lora_{grp}.A")
+            seeds = self._module_seeds(i, grp, drop_slot)
+            t = torch.empty(x.shape[0], len(seeds) * rp, dtype=BF16, device=self.device)
+            for g, seed in enumerate(seeds):
+                xg = ops.dropout(x, self.lora.lora_dropout, seed)
+                ops.gemm_nt(xg, A[g * rp:(g + 1) * rp], out=t[:, g * rp:(g + 1) * rp], alpha=self.lora.scaling)
+                del xg
+            gc, g0 = self._lora_grouping(grp)
+            y = ops.linear_lora(x, W, st.pT(f"layers.{i}.w{grp}"), t, st.p(f"layers.{i}.lora_{grp}.B"),
+                                st.pT(f"layers.{i}.lora_{grp}.B"), group_cols=gc, residual=residual, group0=g0)
+            return y, t, None
         if xd is None and self._lora_drop():
             xd = ops.dropout(x, self.lora.lora_dropout, self._dropout_seed(i, drop_slot))
         t = ops.gemm_nt(x if xd is None else xd, st.p(f"layers.{i}.lora_{grp}.A"), alpha=self.lora.scaling)
@@ -651,6 +669,12 @@ class LlavaDPOModel:
 
     def _dropout_seed(self, layer: int, slot: int) -> int:
         return (self._cur_drop_step * 1000003 + self.dropout_rank * 7919 + layer * 8 + slot) & 0x7FFFFFFF
+
+    def _module_seeds(self, layer: int, grp: str, slot: int) -> List[int]:
+        """RV_LORA_PEFT_MASKS: the seed of every peft module of a fused projection.  The first module keeps the fused slot's seed
+        (q: 0, o: 1, gate: 2, down: 3), the others take the layer's spare slots (k: 4, v: 5, up: 6)."""
+        extra = {"qkv": (4, 5), "gu": (6,)}.get(grp, ())
+        return [self._dropout_seed(layer, sl) for sl in (slot,) + extra]
 
     def _proj_bwd(self, dy: torch.Tensor, xin: torch.Tensor, t: Optional[torch.Tensor], i: int, grp: str,
                   drop_slot: int = 0, xd: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -670,6 +694,20 @@ class LlavaDPOModel:
         dt = torch.empty(dy.shape[0], G * rp, dtype=BF16, device=self.device)
         for g, (c0, og) in enumerate(groups):                         # dt_g = (alpha/r) dy_g B_g
             ops.gemm_nt(dy[:, c0:c0 + og], BT[:, c0:c0 + og], out=dt[:, g * rp:(g + 1) * rp], alpha=sc)
+        if self.training and self.lora.lora_dropout > 0.0 and self.lora_peft_masks:
+            # per-module masks: dx = dy W + sum_g mask_g * (dt_g A_g) / (1 - p); dA_g = dt_g^T dropout_g(x)
+            p_, A, AT, gA = self.lora.lora_dropout, st.p(akey), st.pT(akey), st.g(akey)
+            dx = ops.linear(dy, st.pT(wkey), st.p(wkey))
+            for g, seed in enumerate(self._module_seeds(i, grp, drop_slot)):
+                dtg = dt[:, g * rp:(g + 1) * rp]
+                ops.gemm_nt_dropout(dtg, AT[:, g * rp:(g + 1) * rp], p_, seed, out=dx, residual=dx)
+                xg = ops.dropout(xin, p_, seed)
+                ops.gemm_tn_skinny(dtg, xg, out=gA[g * rp:(g + 1) * rp])
+                del xg
+            gB = st.g(bkey)
+            for g, (c0, og) in enumerate(groups):
+                ops.gemm_tn_skinny(dy[:, c0:c0 + og], t[:, g * rp:(g + 1) * rp], out=gB[c0:c0 + og])
+            return dx
         if self.training and self.lora.lora_dropout > 0.0:
             # dropout sits on the adapter branch only: dx = dy W + mask * (dt A) / (1 - p)
             dx = ops.lora_dgrad_dropout(dy, st.p(wkey), st.pT(wkey), dt, st.p(akey), st.pT(akey), self.lora.lora_dropout,
@@ -692,7 +730,7 @@ class LlavaDPOModel:
         S, L = plan.S, plan.L
         # LoRA under adapter dropout: the kernels that produce a projection's input also write its dropped copy (one pass less over
         # the activation per projection; the attention output keeps the stand-alone rv_dropout)
-        drop = self._lora_drop() and os.environ.get("RV_LORA_FUSED_DROPOUT", "1") != "0"
+        drop = self._lora_drop() and os.environ.get("RV_LORA_FUSED_DROPOUT", "1") != "0" and not self.lora_peft_masks
         p_drop = self.lora.lora_dropout if drop else 0.0
         xnd = xn2d = actd = None
         if drop:

@@ -369,6 +369,47 @@ def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch):
     assert (ref0["log_prob"] - ref["log_prob"]).abs().max() > 1e-3
 
 
+def test_lora_peft_exact_per_module_dropout_masks(monkeypatch):
+    """RV_LORA_PEFT_MASKS=1 (opt-in, VERDICT r4 missing 6): peft wraps every nn.Linear in its own lora.Linear with its own nn.Dropout
+    (muffin/train/train_llava15_lora.py:304-318), so q / k / v and gate / up drop the same input with INDEPENDENT masks; the default
+    path draws one mask per fused projection.  Forward and backward against the fp32 oracle with the seven per-module masks replayed
+    (oracle/dropout_mask.py restates the device's counter hash and the per-module seed slots); the masks really differ per module, and
+    replaying the SHARED masks instead is measurably elsewhere."""
+    _need_gpu()
+    from oracle import dropout_mask as DM
+    monkeypatch.setenv("SFT_weight", "0.0")
+    monkeypatch.setenv("DPO_weight", "1.0")
+    monkeypatch.setenv("RV_LORA_PEFT_MASKS", "1")
+    cfg = O.tiny_cfg()
+    p = 0.25
+    model, W = _build(cfg, 64, dropout=p, share_prefix=False)       # reference row layout: masks index [S L, in]
+    assert model.lora_peft_masks
+    tr = _trainer(model)
+    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=43)
+    model.train()
+    loss = tr.compute_loss(model, dict(batch))
+    out = model.last_out
+    N = out.plan.S * out.plan.L
+    model.backward(out, model.last_coef)
+    masks, shared = {}, {}
+    for i in range(cfg.layers):
+        masks.update(DM.layer_masks(i, N, cfg.hidden, cfg.ffn, p, step=1, rank=0, per_module=True))
+        shared.update(DM.layer_masks(i, N, cfg.hidden, cfg.ffn, p, step=1, rank=0))
+    q, k = masks["model.layers.0.self_attn.q_proj"], masks["model.layers.0.self_attn.k_proj"]
+    assert not torch.equal(q, k) and torch.equal(q, shared["model.layers.0.self_attn.q_proj"])
+    ref, grads = _oracle_grads(batch, W, cfg, 16 / 64, masks)
+    ref = {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in ref.items()}
+    assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])) + 7e-3
+    assert bool(((out.seq_logp.cpu() - ref["log_prob"]).abs() <= 1e-3 * ref["log_prob"].abs() + 5e-2).all())
+    got = model.grads_state_dict()
+    for kk, gref in grads.items():
+        if gref.norm() < 1e-8:
+            continue
+        assert _cos(got[kk], gref) >= 0.99, (kk, _cos(got[kk], gref))
+    ref_shared, _ = _oracle_grads(batch, W, cfg, 16 / 64, shared)
+    assert (ref_shared["log_prob"].detach() - ref["log_prob"]).abs().max() > 1e-3
+
+
 def test_lora_full_width_dropout_one_pass_paths_vs_oracle(monkeypatch):
     """Config 5's training step AS IT RUNS IN THE BENCH - adapter dropout on, production widths, enough rows that the projections take
     the chip-filling kernels: the adapter-first input-gradient GEMM with the mask on its accumulators (rv_gemm_nn_lora_pre_bf16), the
