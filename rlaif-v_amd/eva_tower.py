@@ -21,6 +21,7 @@ factor sqrt(128 / 112) so that the kernels' 1 / sqrt(128) becomes 1 / sqrt(112).
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict
 
@@ -179,6 +180,23 @@ class EvaTower:
         cols = ops.im2col_patches(px, c.patch, w["patch_w"].shape[1])
         pe = ops.gemm_nt(cols, w["patch_w"], bias=w["patch_b"])
         x = ops.clip_assemble(pe, w["cls"], self.pos(grid), B, P)                  # [cls | patches] + positions
+        if os.environ.get("RV_EVA_FP32_RESID", "1") != "0":
+            # The frozen tower's residual stream in fp32 (round 5, like the CLIP tower's: DESIGN section 2): 2 x 63 bf16 roundings of
+            # x become roundings of the (small) post-norm branch outputs; the GEMM operands are bf16 casts of the stream.
+            x32 = ops.cast_bf16_to_f32(x)
+            for i in range(c.blocks_used):
+                qkv = ops.gemm_nt(x, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"])
+                a, _ = ops.attn_fwd(qkv, B, T, H, 128, False, 0, H * 128, 2 * H * 128)
+                o = ops.gemm_nt(a, w[f"{i}.wo"], bias=w[f"{i}.bo"])
+                x32 = ops.add_f32_bf16(x32, ops.layernorm_fwd(o, w[f"{i}.norm1.w"], w[f"{i}.norm1.b"], c.eps))
+                x = ops.cast_f32_to_bf16(x32)
+                h = ops.gemm_nt(x, w[f"{i}.fc1.w"], bias=w[f"{i}.fc1.b"], act=ops.ACT_GELU)
+                m = ops.gemm_nt(h, w[f"{i}.fc2.w"], bias=w[f"{i}.fc2.b"])
+                x32 = ops.add_f32_bf16(x32, ops.layernorm_fwd(m, w[f"{i}.norm2.w"], w[f"{i}.norm2.b"], c.eps))
+                x = ops.cast_f32_to_bf16(x32)
+            x = ops.layernorm_fwd_f32in(x32, w["norm.w"], w["norm.b"], c.eps)
+            idx = (torch.arange(B, device=self.device)[:, None] * T + 1 + torch.arange(P, device=self.device)[None]).reshape(-1)
+            return ops.gather_rows(x, idx.to(torch.int32)).view(B, P, d)
         for i in range(c.blocks_used):
             qkv = ops.gemm_nt(x, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"])
             a, _ = ops.attn_fwd(qkv, B, T, H, 128, False, 0, H * 128, 2 * H * 128)
