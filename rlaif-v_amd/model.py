@@ -733,7 +733,13 @@ class LlavaDPOModel:
         drop = self._lora_drop() and os.environ.get("RV_LORA_FUSED_DROPOUT", "1") != "0" and not self.lora_peft_masks
         p_drop = self.lora.lora_dropout if drop else 0.0
         xnd = xn2d = actd = None
-        if drop:
+        pending = None
+        if isinstance(x, tuple):      # RV_RESID_FP32: (fp32 stream, the previous layer's bf16 down-projection branch not yet added to it)
+            x, pending = x
+        if pending is not None:       # the add rides in this layer's first norm: x = stream + branch, xn = rmsnorm(x), one pass
+            x, xn, rstd1 = ops.add_rmsnorm_fwd(x, pending, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
+            del pending
+        elif drop:
             xn, rstd1, xnd = ops.rmsnorm_fwd_dropout(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps, p_drop, self._dropout_seed(i, 0))
         else:
             xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
@@ -763,8 +769,7 @@ class LlavaDPOModel:
                 act = ops.swiglu_fwd(gu)
         if self.resid_fp32:
             dwn, t_down, xd_down = self._proj_fwd(act, i, "down", residual=None, drop_slot=3, xd=actd)
-            x_next = ops.add_f32_bf16(x_mid, dwn)
-            del dwn
+            x_next = (x_mid, dwn)     # the NEXT layer's first norm (or the caller, after the last layer) adds the branch to the stream
         else:
             x_next, t_down, xd_down = self._proj_fwd(act, i, "down", residual=x_mid, drop_slot=3, xd=actd)
         if not save:
@@ -826,8 +831,12 @@ class LlavaDPOModel:
         for i in range(cfg.layers):
             x_next, lctx = self._layer_fwd(i, x, plan, cos, sin, save_for_backward and not self.gradient_checkpointing)
             if save_for_backward:
-                layers_ctx.append(lctx if lctx is not None else dict(x=x, recompute=True))
+                if lctx is None:      # --gradient_checkpointing: keep the layer's INPUT (fp32 stream: with its pending branch added)
+                    lctx = dict(x=x if not isinstance(x, tuple) else ops.add_f32_bf16(*x), recompute=True)
+                layers_ctx.append(lctx)
             x = x_next
+        if isinstance(x, tuple):
+            x = ops.add_f32_bf16(*x)          # the last layer's branch joins the fp32 stream
         n_sel = plan.n_sel
         n_pad = max(64, ops.round_up(n_sel, 64))
         hsel = torch.zeros(n_pad, d, dtype=BF16, device=self.device)
@@ -966,6 +975,8 @@ class LlavaDPOModel:
         cos, sin = self._rope(L)
         for i in range(cfg.layers):
             x, _ = self._layer_fwd(i, x, plan, cos, sin, False)
+        if isinstance(x, tuple):
+            x = ops.add_f32_bf16(*x)
         h, _ = ops.rmsnorm_fwd(x, st.p("model.norm.weight"), cfg.rms_eps, want_rstd=False)
         logits = ops.gemm_nt(h, st.p("lm_head.weight"))[:, :cfg.vocab]          # drop the vocabulary padding columns
         return SimpleNamespace(logits=logits.reshape(S, L, cfg.vocab), loss=None)
