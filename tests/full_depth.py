@@ -461,10 +461,10 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
     coefficients the HIP loss kernel derived from it are asserted separately.
     Bars: token indexing bit exact; sequence log-prob sums and loss 1e-3 relative (north_star); per-token log-probs no
     further from the fp32 oracle than the bf16-EMULATED oracle is (mean; worst token within 1.5 x the emulation's worst);
-    gradients: every tensor's norm within 3 %, direction cosine >= 0.99; total norm / clip factor within 1 %; post-step
-    fp32 masters: the AdamW update (master - initial weight) agrees with the oracle's on >= 93 % of the sampled elements
-    to 5 % of lr (+ 2 fp32 ulps of the value) - measured 95.1 %, the rest are sign flips of noise-level gradient elements -
-    and the first-moment sample has cosine >= 0.99."""
+    gradients: every tensor's norm within 3 %, direction cosine >= 0.99 (or, with an ``emu_grad_cos`` yardstick in the fixture, no
+    worse than the bf16-emulated oracle's backward where that sits below 0.99); total norm / clip factor within 1 %; the optimizer:
+    every sampled post-step master equals AdamW step 1 evaluated in float64 on the HIP path's own gradient, clip factor and initial
+    weight (round 5; rounds 3-4 compared the masters with the oracle's through a fitted agreement fraction, now logged only)."""
     c = CASES[case]
     labels = fx["labels"]
     mask = labels[:, 1:] != O.IGNORE_INDEX

@@ -14,7 +14,9 @@ container (oracle/streamed.py through tools/full_depth_oracle_streamed.py --base
 tests/golden/fulldepth_cfg{5_step,5_cond,5_drop,4_step,4_cond}.pt).  Same harness and the same bars as configs 1 / 2
 (tests/full_depth.py ``compare``): indexing bit exact, log-prob sums 1e-3, the saturated loss 1e-3, logit error within 3 sigma
 of the bf16-emulated oracle's spread, per-token error no larger than the emulation's, per-tensor gradient norms 3 % /
-cosine 0.99, total norm and clip factor 1 %, post-step masters.  Everything goes through the C ABI.
+cosine 0.99 - or, where the bf16-EMULATED oracle's own backward sits below 0.99 on a tensor (config 4's late q / k projections), no
+worse than that emulation -, total norm and clip factor 1 %, the optimizer checked exactly against its own inputs.  Everything goes
+through the C ABI.
 (Sorts after test_zz_*: the 7B full-fine-tune model of that module must be gone from HBM before these are built.)
 """
 import json
