@@ -26,12 +26,20 @@ of dpo_oracle.py, which cite their own lines.
 from __future__ import annotations
 
 import time
+from collections import ChainMap
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
 
 from . import dpo_oracle as O
+
+
+def _overlay(W):
+    """A writable view of the weight mapping: the few tensors a stage differentiates are overridden in the front map, every other
+    name is read THROUGH ``W`` (its own ``__getitem__`` - the mixed-precision runs hand in a mapping that rounds the fp32 masters to
+    bf16 on access, tests/full_depth.py ``ComputeView``).  For a plain dict this is what ``dict(W)`` was, without the copy."""
+    return ChainMap({}, W)
 
 
 def _layer_weight_names(i: int, lora: bool = False) -> List[str]:
@@ -199,7 +207,7 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
     tail_acc = [[None] * len(tail_names) for _ in range(nv)]
     for r0 in range(0, S, rc):
         xc = xL[r0:r0 + rc].detach().requires_grad_(True)
-        Wt = dict(W)
+        Wt = _overlay(W)
         leaves = []
         for n in tail_names:
             Wt[n] = W[n].detach().requires_grad_(True)
@@ -225,7 +233,7 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
         acc = [[None] * len(names) for _ in range(nv)]
         for r0 in range(0, S, rc):
             x_in = x_all[r0:r0 + rc].detach().requires_grad_(True)
-            Wl = dict(W)
+            Wl = _overlay(W)
             leaves = []
             for n in names:
                 Wl[n] = W[n].detach().requires_grad_(True)
@@ -246,7 +254,7 @@ def dpo_step_streamed(batch: Dict[str, object], W: Dict[str, torch.Tensor], cfg:
             log(f"backward: layer {i}, {time.time() - t1:.0f} s")
     # ---- front (the vision tower is frozen)
     fnames = list(front.names)
-    Wf = dict(W)
+    Wf = _overlay(W)
     leaves = []
     for n in fnames:
         Wf[n] = W[n].detach().requires_grad_(True)

@@ -76,7 +76,24 @@ CASES = {
     # north_star bar is a >= 4-sigma statement on this batch, as it is on the config-2 / 4 / 5 batches.  Both batches are config 1.
     "cfg1m_step": dict(seed=48, pairs=4, text_len=512, prompt_len=64, ragged=False,
                        answer_lens=[(448, 150), (400, 120), (448, 200), (350, 100)], lr=5e-7, step=True),
+    # round 6 (VERDICT r5 missing 3 / next 3a): THREE optimisation steps of config 1 at full depth, a different batch per step (the
+    # cfg1m shape, seeds below), lr 5e-7 constant - the first time Adam's second moment, the bias corrections at t >= 2, the fp32
+    # master accumulation and the bf16 parameter refresh are checked at 7B.  The oracle runs the REFERENCE's precision arrangement
+    # (--bf16 True + ZeRO-2, script/train/llava15_train.sh:17, script/zero2.json:11-13: bf16 model parameters, fp32 master weights in
+    # the optimizer): forward / backward in fp32 arithmetic on bf16(master) (``ComputeView``), AdamW on the fp32 masters
+    # (``oracle_multistep``).  An all-fp32 oracle would move every weight by lr x sign(g) = 5e-7 at step 1 - 1/240 of a bf16 ulp of
+    # a typical weight - and its step-2 loss would answer a question neither the reference nor this build asks.
+    "cfg1m_3step": dict(base="cfg1m_step", multistep=True, seeds=[48, 148, 248], lr=5e-7, step=True),
+    # round 6 (VERDICT r5 missing 6 / next 3b): config 1's batch on weights whose residual stream carries OUTLIER CHANNELS, the
+    # regime of every real Llama checkpoint (none exists offline): from layer 2 on, six channels hold ~ +-1400 at every
+    # token ("massive activations": constant sign, +-7 % from token to token) against 3.5 - 13 RMS elsewhere (>= 100 x at every depth;
+    # written by layer 1's down_proj), with the matching norm gains of a trained model in every later norm (``apply_outlier_channels``).  bf16 keeps 8 significant bits: a
+    # stream value of 1400 is stored to +-4 while the branch a layer adds to it is ~2.3 - a bf16 stream cannot even see it.
+    "cfg1_outlier": dict(seed=48, pairs=4, text_len=512, prompt_len=64, ragged=False,
+                         answer_lens=[(448, 150), (400, 120), (448, 200), (350, 100)], lr=5e-7, step=True,
+                         outlier=dict(channels=[77, 1415, 2533, 3011, 3500, 4000], layer=1, o_val=1400.0, n_feat=512, r2=(6.9, 5.3))),
 }
+OUTLIER_STATS: Dict[str, Dict[int, Dict[str, float]]] = {}       # filled by the oracle's forward sweep of an outlier case
 OMNI = dict(hidden=4096, heads=32, kv_heads=8, ffn=14336, vocab=32009, num_query=64, vision_width=1792, tower_tokens=1024,
             resampler_heads=32, tokens=(32000, 32001, 32002))
 
@@ -112,7 +129,47 @@ def make_case_weights(case: str, cfg: O.LlavaCfg) -> Dict[str, torch.Tensor]:
         from oracle import omnilmm_oracle as OO
         W = {n: v for n, v in W.items() if "vision_tower" not in n and "mm_projector" not in n}
         W.update(OO.make_resampler_weights(OMNI["hidden"], OMNI["vision_width"], OMNI["num_query"], seed=WEIGHT_SEED + 2))
+    o = CASES[base_case(case)].get("outlier")
+    if o is not None:
+        apply_outlier_channels(W, cfg, **o)
     return W
+
+
+def apply_outlier_channels(W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, channels, layer: int, o_val: float, n_feat: int, r2):
+    """Residual-stream outlier channels - "massive activations" - for case ``cfg1_outlier``: constant-sign values of ~``o_val`` in
+    ``channels`` at EVERY token from layer ``layer`` + 1 on, acting as the fixed bias they are in trained Llama checkpoints.
+    Llama has no bias terms, so the constant is built from the one token-independent quantity an RMS-normalised row offers, its
+    second moment: the first ``n_feat`` MLP features of layer ``layer`` get up_proj row = gate_proj row, so that feature j emits
+    silu(z) z = z^2 sigma(z) >= 0 with mean E[z^2] / 2 for every token, and down_proj sums those features into each outlier
+    channel with weight +-s (512 features: +-7 % from token to token).  The residual stream then carries the value to the last layer.
+    Every norm that reads the stream afterwards gets the MATCHING gains a trained model has: the outlier channels are turned down to
+    O(1) after normalisation, the others turned UP by the factor by which the outliers inflate a row's RMS,
+    kappa = sqrt(n_c o_val^2 / d + r^2) / r with r^2 = r2[0] + r2[1] x depth (the un-modified model's stream RMS, measured once: 2.63
+    after layer 0 ... 13.08 after layer 31) - so the decoder stays as active as without outliers instead of being normalised away.
+    All values stay bf16-representable."""
+    ch = torch.tensor(channels)
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    rest = torch.ones(cfg.hidden, dtype=torch.bool)
+    rest[ch] = False
+    p = f"model.layers.{layer}.mlp."
+    W[p + "up_proj.weight"][:n_feat] = W[p + "gate_proj.weight"][:n_feat]
+    z2 = float((W[p + "gate_proj.weight"][:n_feat].pow(2).sum(1) * 1.0).mean())          # E[z^2] for a unit-RMS input (gains ~ 1)
+    s = o_val / (n_feat * 0.5 * z2)
+    sign = torch.tensor([1.0 if j % 2 == 0 else -1.0 for j in range(len(channels))])
+    W[p + "down_proj.weight"][ch, :n_feat] = rnd(sign[:, None] * s).expand(-1, n_feat)
+    o2 = len(channels) * o_val ** 2 / cfg.hidden
+
+    def retune(name, depth):
+        r = math.sqrt(r2[0] + r2[1] * depth)
+        tot = math.sqrt(o2 + r * r)
+        g = W[name]
+        g[rest] = rnd(g[rest] * (tot / r))
+        g[ch] = rnd(g[ch] * (tot / o_val))
+
+    for i in range(layer + 1, cfg.layers):
+        retune(f"model.layers.{i}.input_layernorm.weight", i - 1)
+        retune(f"model.layers.{i}.post_attention_layernorm.weight", i - 0.5)
+    retune("model.norm.weight", cfg.layers - 1)
 
 
 def tower_tokens(case: str) -> torch.Tensor:
@@ -125,6 +182,8 @@ def tower_tokens(case: str) -> torch.Tensor:
 def make_batch(case: str, cfg: O.LlavaCfg, fx: Optional[Dict[str, object]] = None):
     """The case's synthetic batch; a conditioned case takes its reference log-probs from the oracle fixture ``fx``."""
     c = CASES[base_case(case)]
+    if CASES[case].get("multistep"):
+        raise ValueError("multi-step case: use make_step_batches")
     if "beta_z" in CASES[case]:
         batch = make_batch(base_case(case), cfg)
         batch["ref_win_logp"], batch["ref_rej_logp"] = fx["ref_win_logp"].clone(), fx["ref_rej_logp"].clone()
@@ -136,6 +195,13 @@ def make_batch(case: str, cfg: O.LlavaCfg, fx: Optional[Dict[str, object]] = Non
                                      answer_lens=c["answer_lens"])
     return O.make_synthetic_batch(cfg, c["pairs"], c["text_len"], c["prompt_len"], seed=c["seed"], ragged=c["ragged"],
                                   answer_lens=c["answer_lens"])
+
+
+def make_step_batches(case: str, cfg: O.LlavaCfg):
+    """The batches of a multi-step case: the base case's shape, one seed per step (step 1 IS the base case's batch)."""
+    c = CASES[base_case(case)]
+    return [O.make_synthetic_batch(cfg, c["pairs"], c["text_len"], c["prompt_len"], seed=sd, ragged=c["ragged"], answer_lens=c["answer_lens"])
+            for sd in CASES[case]["seeds"]]
 
 
 def sample_index(name: str, numel: int, n: int = N_SAMPLE) -> torch.Tensor:
@@ -277,6 +343,81 @@ def oracle_streamed(base: str, W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, cond
     return out
 
 
+class ComputeView(dict):
+    """The weights a mixed-precision step COMPUTES with: bf16(fp32 master), upcast to fp32, rounded on access - the reference's
+    arrangement under ``--bf16 True`` + ZeRO-2 (script/train/llava15_train.sh:17, script/zero2.json:11-13: bf16 model parameters,
+    fp32 masters inside the optimizer).  Holds the masters themselves (no second copy of 27 GB)."""
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self, k).to(torch.bfloat16).to(torch.float32)
+
+    def master(self, k):
+        return dict.__getitem__(self, k)
+
+
+def oracle_multistep(case: str, W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, workdir: str, log=print) -> Dict[str, object]:
+    """T optimisation steps of ``case`` by the layer-streamed oracle in the reference's mixed-precision arrangement: per step one
+    forward / backward of the oracle's own functions on ``ComputeView(W)`` (fp32 arithmetic on bf16-rounded parameters), the global
+    gradient norm and clip factor, then torch.optim.AdamW's update (``dpo_oracle.adamw_reference``, tensor by tensor) on the fp32
+    masters ``W`` IN PLACE.  Gradients and both Adam moments of all 6.76 B parameters live in three disk-backed arrays under
+    ``workdir`` (27 GB each); the masters stay in RAM.  The fixture keeps, per step: loss, log-probs, per-token log-probs, gradient
+    norms, clip factor and the sampled gradient elements; after EVERY step the sampled m, v and masters."""
+    import numpy as np
+    from oracle import streamed as S
+    c = CASES[case]
+    batches = make_step_batches(case, cfg)
+    names = [k for k in O.trainable_names(cfg) if k in W]
+    off, n = {}, 0
+    for k in names:
+        off[k] = (n, W[k].numel())
+        n += W[k].numel()
+    os.makedirs(workdir, exist_ok=True)
+    mm = {nm: np.memmap(os.path.join(workdir, f"{nm}.f32"), dtype=np.float32, mode="w+", shape=(n,)) for nm in ("g", "m", "v")}
+
+    def view(nm, k):
+        o, cnt = off[k]
+        return torch.from_numpy(mm[nm][o:o + cnt]).view(W[k].shape)
+
+    Wc = ComputeView(W)
+    fx: Dict[str, object] = dict(case=case, layers=cfg.layers, weight_seed=WEIGHT_SEED, torch=torch.__version__, threads=torch.get_num_threads(),
+                                 oracle="oracle/streamed.py on bf16(master) + adamw_reference on fp32 masters", lr=c["lr"], steps=[])
+    for t, batch in enumerate(batches, start=1):
+        acc = dict(sumsq=0.0, gnorm={}, gsamp={})
+
+        def sink(v, name, g, acc=acc):
+            ss = float(g.double().pow(2).sum())
+            acc["sumsq"] += ss
+            acc["gnorm"][name] = math.sqrt(ss)
+            acc["gsamp"][name] = g.flatten()[sample_index(name, g.numel())].float().clone()
+            view("g", name).copy_(g)
+
+        ph: Dict[str, float] = {}
+        res = S.dpo_step_streamed(batch, Wc, cfg, grad_sink=sink, timings=ph, log=lambda m_, t=t: log(f"[{case} step {t}] {m_}"))
+        gn = math.sqrt(acc["sumsq"])
+        clip = min(1.0, 1.0 / (gn + 1e-6))
+        t0 = time.time()
+        msamp, vsamp, psamp = {}, {}, {}
+        for k in names:
+            if k not in acc["gnorm"]:
+                continue
+            st = {k: dict(m=view("m", k), v=view("v", k))}
+            O.adamw_reference({k: W[k]}, {k: view("g", k) * clip}, st, c["lr"], t, max_grad_norm=None)
+            idx = sample_index(k, W[k].numel())
+            msamp[k], vsamp[k] = st[k]["m"].flatten()[idx].clone(), st[k]["v"].flatten()[idx].clone()
+            psamp[k] = W[k].flatten()[idx].clone()
+        ph["opt_s"] = time.time() - t0
+        stp = dict(_fwd_summary(res), timings=dict(ph), grad_norm_total=gn, clip_coef=clip, grad_norms=acc["gnorm"],
+                   grad_samples=acc["gsamp"], m_samples=msamp, v_samples=vsamp, post_samples=psamp)
+        fx["steps"].append(stp)
+        log(f"[{case} step {t}] loss {stp['loss']:.6f}, |g| {gn:.4f}, clip {clip:.3e}; fwd {ph['fwd_s']:.0f} s, bwd {ph['bwd_s']:.0f} s, "
+            f"AdamW {ph['opt_s']:.0f} s")
+    for a in mm.values():
+        a._mmap.close()
+    for nm in mm:
+        os.remove(os.path.join(workdir, f"{nm}.f32"))
+    return fx
+
+
 def _case_stream_kwargs(base: str, batch, cfg: O.LlavaCfg):
     """(streamed-oracle keyword arguments, front factory) of a base case: LoRA scale / replayed masks, row chunks, OmniLMM front."""
     from oracle import streamed as S
@@ -290,6 +431,19 @@ def _case_stream_kwargs(base: str, batch, cfg: O.LlavaCfg):
             S_rows = batch["concatenated_input_ids"].shape[0]
             L_sp = batch["concatenated_input_ids"].shape[1] - 1 + cfg.n_patches
             skw["lora_masks_fn"] = lambda i: DM.layer_masks(i, S_rows * L_sp, cfg.hidden, cfg.ffn, c["dropout"], step=1, rank=0)
+    if c.get("outlier") is not None:
+        ch = torch.tensor(c["outlier"]["channels"])
+
+        def layer_fn(x, Wl, cfg_, i, *a, **kw):
+            y = O.llama_layer(x, Wl, cfg_, i, *a, **kw)
+            if not torch.is_grad_enabled():           # the forward sweep: how large the outlier channels of layer i's OUTPUT stream are
+                yy = y.detach().float()
+                rest = torch.ones(yy.shape[-1], dtype=torch.bool)
+                rest[ch] = False
+                OUTLIER_STATS.setdefault(base, {})[i] = dict(outlier_rms=float(yy[..., ch].pow(2).mean().sqrt()), outlier_max=float(yy[..., ch].abs().max()),
+                                                            rest_rms=float(yy[..., rest].pow(2).mean().sqrt()))
+            return y
+        skw["layer_fn"] = layer_fn
     make_front = None
     if kind == "omnilmm":
         tok = tower_tokens(base)
@@ -451,6 +605,144 @@ def hip_case(case: str, model, trainer, cfg: O.LlavaCfg, full_grads: bool = Fals
     res.update(grad_norms=gnorm, grad_samples=gsamp, grad_norm_total=clip[0], clip_coef=clip[1], post_samples=psamp,
                m_samples=msamp)
     return res
+
+
+def outlier_weights(W: Dict[str, torch.Tensor], cfg: O.LlavaCfg, case: str) -> Dict[str, torch.Tensor]:
+    """``W`` with the outlier channels of ``case`` applied, sharing every untouched tensor with ``W`` (no second 27 GB)."""
+    o = CASES[case]["outlier"]
+    W2 = dict(W)
+    p = f"model.layers.{o['layer']}.mlp."
+    touched = [p + "up_proj.weight", p + "down_proj.weight", "model.norm.weight"] + \
+              [f"model.layers.{i}.{n}.weight" for i in range(o["layer"] + 1, cfg.layers) for n in ("input_layernorm", "post_attention_layernorm")]
+    for k in touched:
+        W2[k] = W[k].clone()
+    apply_outlier_channels(W2, cfg, **o)
+    return W2
+
+
+def hip_multistep(case: str, model, trainer, cfg: O.LlavaCfg) -> Dict[str, object]:
+    """The HIP path over the batches of a multi-step case: compute_loss + backward + clip + AdamW per step (through the C ABI), with
+    the sampled gradient elements of every step and the sampled m / v / fp32 masters / bf16 parameters after every step."""
+    c = CASES[case]
+    st = model.store
+    steps = []
+    model.train(True)
+    for batch in make_step_batches(case, cfg):
+        loss = trainer.compute_loss(model, dict(batch))
+        out = model.last_out
+        res: Dict[str, object] = dict(tgt=out.plan.tgt.cpu().long(), seq_cnt=out.seq_cnt.cpu(), log_prob=out.seq_logp.float().cpu(),
+                                      per_token=out.per_token_logp.float().cpu(), loss=float(loss))
+        model.backward(out, model.last_coef)
+        gnorm, gsamp = {}, {}
+        for name, v in _trainable_views(model, st.flat_g):
+            gnorm[name] = float(v.double().norm())
+            gsamp[name] = _take(v, sample_index(name, v.numel()))
+        trainer.optimizer_step(lr=c["lr"])
+        torch.cuda.synchronize()
+        clip = trainer._clip.cpu().tolist()
+        samp = lambda flat: {name: _take(v, sample_index(name, v.numel())) for name, v in _trainable_views(model, flat)}
+        res.update(grad_norms=gnorm, grad_samples=gsamp, grad_norm_total=clip[0], clip_coef=clip[1], post_samples=samp(st.flat_master),
+                   m_samples=samp(st.flat_m), v_samples=samp(st.flat_v), param_samples=samp(st.train_p),
+                   global_step=int(trainer.state["global_step"]))
+        steps.append(res)
+    return dict(steps=steps)
+
+
+def compare_multistep(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Dict[str, torch.Tensor], check: bool = True):
+    """T optimisation steps, HIP vs the mixed-precision oracle (``oracle_multistep``).  Per step: token indexing bit exact, log-prob
+    sums and loss 1e-3, per-tensor gradient norms 3 % / cosine 0.99, total norm and clip factor 1 %.  After the LAST step:
+      * THE OPTIMIZER, EXACTLY: every sampled m, v and fp32 master of the HIP path equals torch.optim.AdamW iterated in float64
+        over the HIP path's OWN T sampled gradients, clip factors and the initial weight (bias corrections at t = 1 .. T, decoupled
+        decay, HF decay groups) - second moment, bias correction and master accumulation have no other slack than fp32 rounding;
+      * the bf16 parameter the next forward reads is bf16(master), bit for bit;
+      * against the ORACLE's state (which saw the oracle's gradients): first-moment cosine, second-moment ratio and the direction
+        of the accumulated update (master - initial weight) per tensor."""
+    c = CASES[case]
+    lr, T = c["lr"], len(fx["steps"])
+    assert len(hip["steps"]) == T
+    b1, b2, eps_, wd_ = 0.9, 0.999, 1e-8, 0.01
+    m: Dict[str, object] = dict(case=case, layers=fx["layers"], steps=[])
+    for t, (h, f) in enumerate(zip(hip["steps"], fx["steps"]), start=1):
+        mask = f["labels"][:, 1:] != O.IGNORE_INDEX
+        idx_ok = bool(torch.equal(h["tgt"], f["labels"][:, 1:][mask])) and h["seq_cnt"].tolist() == mask.sum(1).float().tolist()
+        lp_rel = float(((h["log_prob"] - f["log_prob"]).abs() / f["log_prob"].abs()).max())
+        loss_rel = abs(h["loss"] - f["loss"]) / abs(f["loss"])
+        worst_norm, worst_cos = 0.0, 1.0
+        for k, n_ref in f["grad_norms"].items():
+            if n_ref < 1e-9:
+                continue
+            worst_norm = max(worst_norm, abs(h["grad_norms"][k] - n_ref) / n_ref)
+            worst_cos = min(worst_cos, _cos(h["grad_samples"][k], f["grad_samples"][k]))
+        gn_rel = abs(h["grad_norm_total"] - f["grad_norm_total"]) / f["grad_norm_total"]
+        clip_rel = abs(h["clip_coef"] - f["clip_coef"]) / f["clip_coef"]
+        sd = h["per_token"] - f["per_token"]
+        m["steps"].append(dict(step=t, indexing_bit_exact=idx_ok, loss=h["loss"], loss_oracle=f["loss"], loss_rel_err=loss_rel,
+                               seq_logp_max_rel_err=lp_rel, per_token_rms_err=float(sd.pow(2).mean().sqrt()),
+                               grad_worst_norm_rel_err=worst_norm, grad_worst_sample_cosine=worst_cos,
+                               grad_norm_total=h["grad_norm_total"], grad_norm_total_oracle=f["grad_norm_total"], grad_norm_total_rel_err=gn_rel,
+                               clip_coef=h["clip_coef"], clip_coef_oracle=f["clip_coef"], clip_coef_rel_err=clip_rel, global_step=h["global_step"]))
+        if check:
+            assert idx_ok and h["global_step"] == t
+            assert lp_rel <= 1e-3 and loss_rel <= 1e-3, (t, lp_rel, loss_rel)
+            assert worst_norm <= 3e-2 and worst_cos >= 0.99, (t, worst_norm, worst_cos)
+            assert gn_rel <= 1e-2 and clip_rel <= 1e-2, (t, gn_rel, clip_rel)
+    # ---- the optimizer after T steps, exactly, on the HIP path's own inputs (float64)
+    last_h, last_f = hip["steps"][-1], fx["steps"][-1]
+    n_ok = {"m": 0, "v": 0, "p": 0}
+    n_all = 0
+    worst = {"m": 0.0, "v": 0.0, "p": 0.0}
+    bf16_ok = bf16_all = 0
+    m_cos, v_ratio, upd_cos, moved = 1.0, [], 1.0, 0
+    for k in last_f["post_samples"]:
+        idx = sample_index(k, W0[k].numel())
+        p = W0[k].flatten()[idx].double()
+        p0 = p.clone()
+        mm_, vv_ = torch.zeros_like(p), torch.zeros_like(p)
+        for t, h in enumerate(hip["steps"], start=1):
+            g = h["grad_samples"][k].double() * float(h["clip_coef"])
+            if O.is_decay_param(k):
+                p = p * (1.0 - lr * wd_)
+            mm_ = b1 * mm_ + (1 - b1) * g
+            vv_ = b2 * vv_ + (1 - b2) * g * g
+            p = p - (lr / (1 - b1 ** t)) * mm_ / ((vv_ / (1 - b2 ** t)).sqrt() + eps_)
+        hm, hv, hp = last_h["m_samples"][k].double(), last_h["v_samples"][k].double(), last_h["post_samples"][k].double()
+        em, ev, ep = (hm - mm_).abs(), (hv - vv_).abs(), (hp - p).abs()
+        tm = 1e-5 * mm_.abs() + 1e-30
+        tv = 1e-5 * vv_.abs() + 1e-38
+        tp = 1e-3 * lr + T * 2.4e-7 * p0.abs()             # 0.1 % of one step + 2 fp32 ulps of the weight per step
+        n_ok["m"] += int((em <= tm).sum()); n_ok["v"] += int((ev <= tv).sum()); n_ok["p"] += int((ep <= tp).sum())
+        n_all += p.numel()
+        worst["m"] = max(worst["m"], float((em / (mm_.abs() + 1e-30)).max()))
+        worst["v"] = max(worst["v"], float((ev / (vv_.abs() + 1e-38)).max()))
+        worst["p"] = max(worst["p"], float((ep / lr).max()))
+        moved += int(((hp - p0).abs() > 0).sum())
+        # the parameter the next forward reads
+        bf = last_h["post_samples"][k].to(torch.bfloat16).float()
+        bf16_ok += int((bf == last_h["param_samples"][k]).sum())
+        bf16_all += bf.numel()
+        # against the oracle's state
+        fm, fv, fp_ = last_f["m_samples"][k].double(), last_f["v_samples"][k].double(), last_f["post_samples"][k].double()
+        if float(fm.norm()) > 0:
+            m_cos = min(m_cos, _cos(hm, fm))
+            v_ratio.append(float(hv.sum() / fv.sum()))
+            big = fm.abs() >= 0.25 * fm.pow(2).mean().sqrt()
+            if int(big.sum()) > 8:
+                upd_cos = min(upd_cos, _cos((hp - p0)[big], (fp_ - p0)[big]))
+    m.update(optimizer_exact=dict(frac_m=n_ok["m"] / n_all, frac_v=n_ok["v"] / n_all, frac_master=n_ok["p"] / n_all, samples=n_all,
+                                  worst_rel_m=worst["m"], worst_rel_v=worst["v"], worst_master_err_over_lr=worst["p"]),
+             bf16_param_is_rounded_master_frac=bf16_ok / max(bf16_all, 1), master_moved_frac=moved / max(n_all, 1),
+             vs_oracle=dict(adam_m_worst_sample_cosine=m_cos, adam_v_sum_ratio_min=min(v_ratio), adam_v_sum_ratio_max=max(v_ratio),
+                            accumulated_update_worst_cosine_large_m=upd_cos))
+    if check:
+        ex = m["optimizer_exact"]
+        assert ex["frac_m"] >= 0.9999 and ex["frac_v"] >= 0.9999 and ex["frac_master"] >= 0.9999, ex
+        assert m["bf16_param_is_rounded_master_frac"] == 1.0
+        assert m["master_moved_frac"] >= 0.9
+        worst_g = min(s_["grad_worst_sample_cosine"] for s_ in m["steps"])
+        assert m_cos >= min(0.99, worst_g - 2e-3), (m_cos, worst_g)
+        assert 0.94 <= min(v_ratio) and max(v_ratio) <= 1.06, (min(v_ratio), max(v_ratio))       # norms within 3 % -> squares within 6 %
+        assert upd_cos >= 0.9, upd_cos
+    return m
 
 
 # ------------------------------------------------------------------------------------------------ comparison

@@ -138,3 +138,42 @@ def test_rounding_study_layer_is_the_oracle_layer_when_no_point_is_selected():
     only_r = S.dpo_step_streamed(batch, W, cfg, backward=False, layer_fn=RD.make_layer_fn("R"))
     d_r = (only_r["per_token_logps"] - base["per_token_logps"])[mask].abs()
     assert 0 < float(d_r.mean()) < float(d.mean())
+
+
+def test_multistep_mixed_precision_oracle_equals_one_graph_steps(tmp_path):
+    """tests/full_depth.py ``oracle_multistep`` (round 6: T optimisation steps in the reference's --bf16 + ZeRO-2 arrangement - fp32
+    arithmetic on bf16(master), AdamW on fp32 masters held on disk-backed arrays, the streamed evaluation reading the parameters
+    THROUGH a rounding view) == the same three steps done the plain way: one autograd graph per step on explicitly rounded copies
+    and dpo_oracle.adamw_reference over the whole state.  Also pins the outlier-channel construction's contract at tiny size."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import full_depth as FD
+    cfg = O.tiny_cfg()
+    FD.CASES["_tiny_base"] = dict(seed=1, pairs=2, text_len=40, prompt_len=12, ragged=False, answer_lens=[(20, 10), (15, 8)], lr=1e-3, step=True)
+    FD.CASES["_tiny_ms"] = dict(base="_tiny_base", multistep=True, seeds=[1, 2, 3], lr=1e-3, step=True)
+    try:
+        W = O.make_weights(cfg, seed=3)
+        W2 = {k: v.clone() for k, v in W.items()}
+        fx = FD.oracle_multistep("_tiny_ms", W, cfg, str(tmp_path), log=lambda *a: None)
+        assert not os.listdir(tmp_path)                         # the 3 x 27 GB scratch arrays of a real run are removed
+        state = {}
+        for t, batch in enumerate(FD.make_step_batches("_tiny_ms", cfg), start=1):
+            Wc = {k: v.to(torch.bfloat16).float() for k, v in W2.items()}
+            leaves = {k: Wc[k].clone().requires_grad_(True) for k in O.trainable_names(cfg)}
+            out = O.dpo_step_forward(batch, dict(Wc, **leaves), cfg, sft_weight=0.0, dpo_weight=1.0)
+            out["loss"].backward()
+            grads = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+            tot = O.adamw_reference({k: W2[k] for k in grads}, grads, state, 1e-3, t)
+            s = fx["steps"][t - 1]
+            assert abs(float(out["loss"]) - s["loss"]) <= 1e-6 * abs(s["loss"]) and abs(tot - s["grad_norm_total"]) <= 1e-5 * tot
+            for k in s["post_samples"]:
+                idx = FD.sample_index(k, W2[k].numel())
+                assert torch.allclose(W2[k].flatten()[idx], s["post_samples"][k], rtol=0, atol=1e-7), (t, k)
+                assert torch.allclose(state[k]["m"].flatten()[idx], s["m_samples"][k], rtol=1e-4, atol=1e-12), (t, k)
+                assert torch.allclose(state[k]["v"].flatten()[idx], s["v_samples"][k], rtol=1e-4, atol=1e-16), (t, k)
+        # the masters moved off the bf16 grid (otherwise the rounding view would be vacuous)
+        k = "model.layers.0.mlp.down_proj.weight"
+        assert not torch.equal(W[k], W[k].to(torch.bfloat16).float())
+    finally:
+        del FD.CASES["_tiny_base"], FD.CASES["_tiny_ms"]

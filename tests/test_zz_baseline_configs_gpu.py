@@ -12,7 +12,7 @@ per-token log-probs (bf16 activations through the whole stack against an fp32 or
 from the fp32 oracle than the oracle evaluated the way HF runs under --bf16 (oracle.emulate_bf16) - and at 4 layers mean |err|
 within 5e-3 of the mean |log-prob|, worst token within 2e-2; gradients: per-tensor norm within 3 %, direction cosine >= 0.99.
 (The file sorts last on purpose: these cases spend minutes in the CPU oracle.)  The measured numbers are written to
-gpurun_out/parity_<round>.json (RV_ROUND, default r05; copied to profiles/).
+gpurun_out/parity_<round>.json (RV_ROUND, default r06; copied to profiles/).
 """
 import json
 import os
@@ -48,7 +48,7 @@ def _host_ram_gb():
 
 
 def _record(key, value):
-    path = os.path.join(REPO, "gpurun_out", f"parity_{os.environ.get('RV_ROUND', 'r05')}.json")
+    path = os.path.join(REPO, "gpurun_out", f"parity_{os.environ.get('RV_ROUND', 'r06')}.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     blob = {}
     if os.path.exists(path):
@@ -309,6 +309,64 @@ def test_full_depth_config1_step_with_margin(full_depth, golden_dir):
     m, hip, fx = _stepping_case(full_depth, golden_dir, "cfg1m_step", "config1_full_depth_step_with_margin")
     assert fx["labels"].shape == (8, 1087)
     assert m["loss_one_sigma_rel"] <= 2.5e-4, m["loss_one_sigma_rel"]          # the bar really has >= 4 sigma of margin on this batch
+
+
+@pytest.mark.timeout(2400)
+def test_full_depth_config1_three_steps(full_depth, golden_dir):
+    """THREE optimisation steps of config 1 at full depth (VERDICT r5 missing 3): a different batch per step, lr 5e-7 constant,
+    against the layer-streamed oracle run in the reference's precision arrangement (bf16 model parameters, fp32 masters:
+    script/train/llava15_train.sh:17 + script/zero2.json:11-13; tests/full_depth.py ``oracle_multistep``).  Per step the forward /
+    backward bars of the one-step cases; after step 3 Adam's second moment, the bias corrections at t = 2, 3, the fp32 master
+    accumulation (exact, float64 on the HIP path's own gradients) and the bf16 parameter refresh (bit exact)."""
+    FD = full_depth["FD"]
+    fx = _fixture(FD, "cfg1m_3step", golden_dir)
+    assert len(fx["steps"]) == 3
+    FD.restore(full_depth["model"], full_depth["trainer"], full_depth["snap"])
+    try:
+        hip = FD.hip_multistep("cfg1m_3step", full_depth["model"], full_depth["trainer"], full_depth["cfg"])
+    finally:
+        FD.restore(full_depth["model"], full_depth["trainer"], full_depth["snap"])
+    m = FD.compare_multistep("cfg1m_3step", hip, fx, W0=full_depth["W"], check=False)
+    print("  " + json.dumps(m))
+    _record("config1_full_depth_three_steps", m)
+    FD.compare_multistep("cfg1m_3step", hip, fx, W0=full_depth["W"], check=True)
+
+
+@pytest.mark.timeout(2400)
+def test_full_depth_config1_outlier_channels(full_depth, golden_dir):
+    """Config 1's batch on weights whose residual stream carries OUTLIER CHANNELS >= 100 x the rest from layer 2 on (VERDICT r5
+    missing 6: every real Llama checkpoint does; the N(0, 0.02) fixtures do not) - the regime in which a bf16 residual stream
+    loses the most: a stream value of ~1400 is stored to +-4 while a layer's branch adds ~2.  Whole optimisation step against the
+    fp32 oracle (tests/golden/fulldepth_cfg1_outlier.pt), once per residual-stream precision (``model.resid_fp32``); BOTH are
+    recorded, the bars are asserted on the SHIPPED default (DESIGN section 2 records the decision taken on these numbers)."""
+    FD = full_depth["FD"]
+    model, trainer, cfg = full_depth["model"], full_depth["trainer"], full_depth["cfg"]
+    fx = _fixture(FD, "cfg1_outlier", golden_dir)
+    st = fx["outlier_stats"]
+    assert all(st[i]["outlier_rms"] >= 100 * st[i]["rest_rms"] for i in st if int(i) >= 1), st       # the stream really carries them
+    W2 = FD.outlier_weights(full_depth["W"], cfg, "cfg1_outlier")
+    default = model.resid_fp32
+    rec = {}
+    try:
+        model.load_state_dict(W2)
+        snap2 = FD.snapshot(model)
+        for flag in (False, True):
+            model.resid_fp32 = flag
+            FD.restore(model, trainer, snap2)
+            hip = FD.hip_case("cfg1_outlier", model, trainer, cfg, fx=fx)
+            m = FD.compare("cfg1_outlier", hip, fx, W0=W2, check=False)
+            rec[f"resid_fp32_{int(flag)}"] = m
+            print(f"  resid_fp32={int(flag)}: " + json.dumps({k: v for k, v in m.items() if not isinstance(v, dict)}))
+            if flag == default:
+                hip_default = hip
+        del snap2
+    finally:
+        model.resid_fp32 = default
+        model.load_state_dict(full_depth["W"])
+        FD.restore(model, trainer, full_depth["snap"])
+    rec["shipped_default_resid_fp32"] = bool(default)
+    _record("config1_full_depth_outlier_channels", rec)
+    FD.compare("cfg1_outlier", hip_default, fx, W0=W2, check=True)
 
 
 @pytest.mark.parametrize("share_prefix,mi16", [(False, 1), (True, 1), (True, 0)])

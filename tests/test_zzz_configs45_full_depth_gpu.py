@@ -34,7 +34,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))      # tests/full
 
 
 def _record(key, value):
-    path = os.path.join(REPO, "gpurun_out", f"parity_{os.environ.get('RV_ROUND', 'r05')}.json")
+    path = os.path.join(REPO, "gpurun_out", f"parity_{os.environ.get('RV_ROUND', 'r06')}.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     blob = {}
     if os.path.exists(path):

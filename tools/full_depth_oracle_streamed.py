@@ -39,11 +39,12 @@ def log(*a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--base", choices=["cfg1", "cfg1m", "cfg2", "cfg5", "cfg5_drop", "cfg4"], required=True)
+    ap.add_argument("--base", choices=["cfg1", "cfg1m", "cfg2", "cfg5", "cfg5_drop", "cfg4", "cfg1_outlier", "cfg1m_3step"], required=True)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--no-emulation", action="store_true")
+    ap.add_argument("--workdir", default="/tmp/rv_oracle_multistep", help="cfg1m_3step: where the disk-backed g / m / v arrays live (81 GB)")
     ap.add_argument("--emu-backward", action="store_true", help="fresh run: also produce the bf16-emulated backward yardstick")
     ap.add_argument("--add-emu-backward", action="store_true",
                     help="load the base's existing fixtures and ADD the bf16-emulated oracle's backward (emu_grad_norms / emu_grad_cos: "
@@ -51,12 +52,23 @@ def main():
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     base, cond = {"cfg1": ("cfg1_step", "cfg1_cond"), "cfg2": ("cfg2_step", "cfg2_cond"), "cfg5": ("cfg5_step", "cfg5_cond"),
-                  "cfg5_drop": ("cfg5_drop_base", "cfg5_drop"), "cfg4": ("cfg4_step", "cfg4_cond"), "cfg1m": ("cfg1m_step", None)}[args.base]
+                  "cfg5_drop": ("cfg5_drop_base", "cfg5_drop"), "cfg4": ("cfg4_step", "cfg4_cond"), "cfg1m": ("cfg1m_step", None),
+                  "cfg1_outlier": ("cfg1_outlier", None), "cfg1m_3step": ("cfg1m_3step", None)}[args.base]
     cfg = FD.make_cfg(args.layers, base)
     t0 = time.time()
     W = FD.make_case_weights(base, cfg)
     log(f"weights ({args.layers} layers): {time.time() - t0:.0f} s")
     report = dict(host=dict(cpus=os.cpu_count(), threads=args.threads, torch=torch.__version__), layers=args.layers)
+    if args.base == "cfg1m_3step":
+        # round 6: T optimisation steps in the reference's mixed-precision arrangement (tests/full_depth.py oracle_multistep)
+        suffix = "" if args.layers == 32 else f"_l{args.layers}"
+        fx = FD.oracle_multistep(base, W, cfg, args.workdir, log=log)
+        FD.save_fixture(fx, os.path.join(args.out, f"fulldepth_{base}{suffix}.pt"))
+        report["steps"] = [dict(loss=s_["loss"], log_prob=s_["log_prob"].tolist(), grad_norm_total=s_["grad_norm_total"], clip_coef=s_["clip_coef"],
+                                timings=s_["timings"]) for s_ in fx["steps"]]
+        json.dump(report, open(os.path.join(REPO, "profiles", f"r06_oracle_streamed_{args.base}{suffix}.json"), "w"), indent=1)
+        log("done")
+        return
     if args.add_emu_backward:
         suffix = "" if args.layers == 32 else f"_l{args.layers}"
         names = [cs for cs in (base, cond) if os.path.exists(os.path.join(args.out, f"fulldepth_{cs}{suffix}.pt"))]
@@ -98,11 +110,14 @@ def main():
             log("cfg1_step streamed vs one-graph fixture:", json.dumps(x))
             continue                                           # the committed one-graph fixture stays the reference
         FD.save_fixture(fx, os.path.join(args.out, f"fulldepth_{cs}{suffix}.pt"))
+        if cs in FD.OUTLIER_STATS:
+            fx["outlier_stats"] = report["outlier_stats"] = FD.OUTLIER_STATS[cs]
+            FD.save_fixture(fx, os.path.join(args.out, f"fulldepth_{cs}{suffix}.pt"))
         report[cs] = dict(loss=fx["loss"], losses=fx["losses"].tolist(), log_prob=fx["log_prob"].tolist(), grad_norm_total=fx["grad_norm_total"],
                           clip_coef=fx["clip_coef"], timings=fx["timings"], beta_z=fx.get("beta_z"), n_variants=fx["n_variants"],
                           emu_s=fx.get("emu_s"))
     os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
-    with open(os.path.join(REPO, "profiles", f"{'r04' if args.base in ('cfg1', 'cfg2') else 'r05'}_oracle_streamed_{args.base}{suffix}.json"), "w") as fh:
+    with open(os.path.join(REPO, "profiles", f"{'r04' if args.base in ('cfg1', 'cfg2') else 'r06' if args.base in ('cfg1_outlier',) else 'r05'}_oracle_streamed_{args.base}{suffix}.json"), "w") as fh:
         json.dump(report, fh, indent=1)
     log("done")
 

@@ -17,7 +17,7 @@
 #   prof          rocprofv3 --kernel-trace --stats of the headline bench (3 steps)
 #   pmc           HBM traffic per GEMM launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
 #   smoke         __graft_entry__.smoke()
-R=${RV_ROUND:-r05}
+R=${RV_ROUND:-r06}
 export RV_ROUND=$R
 OUT=gpurun_out/$R
 mkdir -p $OUT
