@@ -243,7 +243,7 @@ def spawn_ranks(n: int) -> int:
     fewer than N GPUs - a line with n_gpus < N is never printed."""
     import subprocess
     have = torch.cuda.device_count()
-    if have < n and os.environ.get("RV_DIST_BACKEND") != "gloo":      # (gloo rehearsal: ranks may share a device; never a bench number)
+    if have < n and (os.environ.get("RV_DIST_BACKEND") or "nccl") != "gloo":      # (gloo rehearsal: ranks may share a device; never a bench number)
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node; refusing to measure fewer ranks")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -300,7 +300,7 @@ def main():
     rank, local, world = init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
-    backend = os.environ.get("RV_DIST_BACKEND", "nccl")
+    backend = os.environ.get("RV_DIST_BACKEND") or "nccl"        # (an EMPTY variable selects nccl, as in init_process_group_from_env)
     devices_visible = torch.cuda.device_count()
     # A REHEARSAL is any run whose ranks do not each own a GPU and talk RCCL: it exercises the N-rank code path and must never
     # be read as a measurement: the line is tagged, its metric string suffixed and value / n_gpus are nulled below.

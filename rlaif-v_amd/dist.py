@@ -73,8 +73,12 @@ class BucketedAllReduce(GradReducer):
       buffer dtype (bf16 on the device)  the collective sums the bf16 gradients as they lie: RCCL's ring adds in bf16, i.e. the
                sum of N ranks is rounded N - 1 times (DeepSpeed ZeRO-2 under --bf16 reduces bf16 gradients the same way);
       fp32     every bucket is widened to an fp32 staging buffer (a dtype-converting copy), summed in fp32 by the collective, and
-               rounded ONCE when it is copied back in finish(): twice the bytes on the wire and 2 x the bucket in staging memory
-               while a bucket is in flight, for a sum that equals the exact one rounded to bf16 up to fp32 accumulation.  The
+               rounded ONCE when it is copied back: twice the bytes on the wire, and the fp32 staging buffer of a bucket (2 x the
+               bucket) lives until its collective has completed - completed buckets are copied back and freed at the next
+               launch (``_drain``), and at most ``max_staged`` (RV_GRAD_STAGE_MAX, default 4) buffers are ever in flight: the
+               compute stream waits for the oldest collective before a fifth is staged (<= 4 x 800 MB at the default bucket
+               size instead of 2 x the whole 13.5 GB gradient) - for a sum that equals the exact one rounded to bf16 up to fp32
+               accumulation.  The
                two agree bit for bit at world size 2 (one addition, one rounding either way) and differ from 3 ranks on
                (tests/test_dist_gloo.py::test_fp32_gradient_sum_world3 measures both against the float64 sum)."""
 
@@ -94,6 +98,8 @@ class BucketedAllReduce(GradReducer):
             raise ValueError(f"RV_GRAD_REDUCE_DTYPE must be bf16 | fp32, got {rd!r}")
         self.widen = rd == "fp32" and flat_grad.dtype != torch.float32
         self._staged: List = []                        # (start, end, fp32 staging tensor) of the buckets in flight (widen only)
+        self.max_staged = max(1, int(os.environ.get("RV_GRAD_STAGE_MAX", "4")))
+        self._n_drained = 0                            # collectives of the current step already waited for (widen + overlap)
         self._pending: Optional[Tuple[int, int]] = None
         self._works: List = []
         self._events: List = []                        # (bytes, enqueue event, completion event) per collective
@@ -112,7 +118,9 @@ class BucketedAllReduce(GradReducer):
             ev[0].record()                              # compute stream: the bucket's gradients are final here
             self._events.append(((end - start) * self.flat.element_size(), ev[0], ev[1]))
         buf = self.flat[start:end]
-        if self.widen:                                  # fp32 sum: widen -> all-reduce fp32 -> round once on the way back (finish)
+        if self.widen:                                  # fp32 sum: widen -> all-reduce fp32 -> round once on the way back
+            if self.mode != "serial":
+                self._drain(block=len(self._staged) >= self.max_staged)
             buf = torch.empty(end - start, dtype=torch.float32, device=self.flat.device)
             buf.copy_(self.flat[start:end])
             self._staged.append((start, end, buf))
@@ -126,6 +134,19 @@ class BucketedAllReduce(GradReducer):
                 self.flat[a:b].copy_(t)
         else:
             self._works.append(w)
+
+    def _drain(self, block: bool = False):
+        """widen + overlap: copy back (one rounding to bf16) and FREE the staging buffers of the collectives that have completed,
+        oldest first (collectives of one communicator complete in order); ``block`` waits for the oldest one regardless."""
+        while self._works and (block or self._works[0].is_completed()):
+            w = self._works.pop(0)
+            w.wait()                                    # stream-ordered: the copy below runs behind the collective
+            if self.timeline and self._n_drained < len(self._events):
+                self._events[self._n_drained][2].record()
+            self._n_drained += 1
+            a, b, t = self._staged.pop(0)
+            self.flat[a:b].copy_(t)
+            block = False
 
     def on_bucket_ready(self, name: str, start: int, end: int):
         """Called by backward when flat[start:end] holds final local gradients."""
@@ -150,11 +171,12 @@ class BucketedAllReduce(GradReducer):
         for i, w in enumerate(self._works):
             w.wait()                                    # collectives of one communicator complete in order
             if self.timeline:
-                self._events[i][2].record()
+                self._events[self._n_drained + i][2].record()
         for a, b, t in self._staged:                    # (overlap mode) stream-ordered behind the waits above: one rounding to bf16
             self.flat[a:b].copy_(t)
         self._staged = []
         self._works = []
+        self._n_drained = 0
         if self.timeline and self._events:
             self._timeline_pending = (self._events, t_end)
         self._events = []
@@ -210,7 +232,9 @@ class ShardedGradReducer(BucketedAllReduce):
     sharded = True
 
     def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 400 << 20, force: bool = False,
-                 mode: Optional[str] = None):
+                 mode: Optional[str] = None, timeline: bool = False):
+        # ``timeline`` is accepted (make_reducer forwards one keyword set to either reducer) and ignored: the per-bucket device
+        # events belong to the all-reduce path's diagnosis (bench.py dp_diag)
         super().__init__(flat_grad, group=group, bucket_bytes=bucket_bytes, force=force, mode=mode, reduce_dtype=None)
         if self.widen:
             raise ValueError("RV_GRAD_REDUCE_DTYPE=fp32 is implemented for the replicated all-reduce only")
@@ -233,6 +257,8 @@ class ShardedGradReducer(BucketedAllReduce):
 
         def launch(a, b):
             nonlocal off
+            if b <= a:                                  # _launch() returns early on an empty range: the plan must not list it either
+                return
             c = self.split(a, b)
             out.append((a, b, c, off))
             off += c
@@ -339,6 +365,14 @@ class ShardedAdamW:
         self.W, self.rank = reducer.world_size, reducer.rank
         self.ranges = reducer.plan(schedule)
         W = self.W
+        if self.k is _DeviceOptKernels:
+            # rv_grad_sumsq / rv_adamw_step process 8 elements per lane and require n % 8 == 0: every chunk (c is a multiple of 8 by
+            # construction), every remainder span and both sides of the weight-decay split are multiples of 8 exactly when every
+            # range boundary and n_decay are.  True for every layout the store produces today; a future one fails HERE, by name.
+            bad = [(a, b) for a, b, _, _ in self.ranges if a % 8 or (b - a) % 8]
+            if bad or n_decay % 8:
+                raise ValueError(f"ZeRO-1 needs bucket boundaries and n_decay at multiples of 8 elements (kernel vector width): "
+                                 f"ranges {bad[:4]}, n_decay {n_decay}")
         self.rem_spans = [(a + W * c, b) for a, b, c, _ in self.ranges if b > a + W * c]
         n_shard = sum(c for _, _, c, _ in self.ranges)
         n_rem = sum(y - x for x, y in self.rem_spans)
@@ -411,12 +445,16 @@ class ShardedAdamW:
             w.wait()
 
     # ---- checkpoints keep the REPLICATED format (full master / m / v in flat order): a sharded run resumes a replicated one and back
-    def gather_full_state(self):
-        """(master, m, v) as full fp32 CPU tensors [n_train] on every rank (collective: all ranks must call)."""
+    def gather_full_state(self, all_ranks: bool = False):
+        """(master, m, v) as full fp32 CPU tensors [n_train].  Collective: EVERY rank must call (the shards travel by all-gather);
+        only rank 0 - the rank that writes the checkpoint - materialises the three host tensors (3 x 27 GB for the 7B full
+        fine-tune; eight ranks of one node doing so would ask for 650 GB of host RAM and seven useless device-to-host copies),
+        the other ranks return None.  ``all_ranks`` (tests) materialises them everywhere."""
         W, n = self.W, self.p.numel()
+        keep = all_ranks or self.rank == 0
         out = []
         for shard, rem in ((self.master, self.rem_master), (self.m, self.rem_m), (self.v, self.rem_v)):
-            full = torch.zeros(n, dtype=torch.float32)
+            full = torch.zeros(n, dtype=torch.float32) if keep else None
             for a, b, c, off in self.ranges:
                 if c == 0:
                     continue
@@ -425,13 +463,15 @@ class ShardedAdamW:
                     dist.all_gather_into_tensor(tmp, shard[off:off + c].contiguous(), group=self.red.group)
                 else:
                     tmp.copy_(shard[off:off + c])
-                full[a:a + W * c] = tmp.cpu()
+                if keep:
+                    full[a:a + W * c] = tmp.cpu()
             o = 0
             for x, y in self.rem_spans:
-                full[x:y] = rem[o:o + y - x].cpu()
+                if keep:
+                    full[x:y] = rem[o:o + y - x].cpu()
                 o += y - x
             out.append(full)
-        return tuple(out)
+        return tuple(out) if keep else None
 
     def load_full_state(self, master, m, v):
         for shard, rem, full in ((self.master, self.rem_master, master), (self.m, self.rem_m, m), (self.v, self.rem_v, v)):

@@ -493,8 +493,9 @@ class LLaVA15DPOTrainer:
         if getattr(self.reducer, "sharded", False):
             # ZeRO-1: the file keeps the REPLICATED layout (full fp32 master / m / v in flat order), so a sharded run resumes a
             # replicated one and back.  Collective: every rank takes part in the gather, rank 0 writes.
-            master, m_, v_ = self._sharded_optimizer().gather_full_state()
+            full = self._sharded_optimizer().gather_full_state()        # host tensors on rank 0 only (None elsewhere)
             if int(os.environ.get("RANK", "0")) == 0:
+                master, m_, v_ = full
                 os.makedirs(path, exist_ok=True)
                 torch.save(dict(master=master, m=m_, v=v_, state=self.state, dropout_step=int(self.model._dropout_step),
                                 layout=self._optimizer_layout()), os.path.join(path, "optimizer.pt"))

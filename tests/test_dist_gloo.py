@@ -47,7 +47,7 @@ def _worker(rank, world, port, q, lora=False):
     expect = sum(others)
     ok_sum = torch.allclose(st.flat_g, expect, rtol=1e-6, atol=1e-6)
     m = red.reduce_metrics(torch.tensor([float(rank), 1.0, -2.0 * rank]))
-    ok_metric = torch.allclose(m, torch.tensor([0.5, 1.0, -1.0]))
+    ok_metric = torch.allclose(m, torch.tensor([(world - 1) / 2, 1.0, -float(world - 1)]))
     # second step reuses the reducer (state fully reset by finish)
     st.flat_g.copy_(local)
     for name, a, b in st.bucket_schedule():
@@ -73,28 +73,35 @@ def _worker(rank, world, port, q, lora=False):
     tr = LLaVA15DPOTrainer.__new__(LLaVA15DPOTrainer)
     from rlaif_v_amd.trainer import TrainingArguments
     tr.args, tr.reducer, tr.train_dataset, tr.data_collator = TrainingArguments(per_device_train_batch_size=1), red, \
-        list(range(10)), (lambda x: x)
+        list(range(5 * world)), (lambda x: x)
     tr.state = dict(global_step=0, epoch=0, batches_in_epoch=0)
     idx = [b[0] for b in tr.get_train_dataloader()]
     gathered = [None] * world
     dist.all_gather_object(gathered, idx)
-    ok_shard = sorted(sum(gathered, [])) == list(range(10))
+    ok_shard = sorted(sum(gathered, [])) == list(range(5 * world)) and all(len(g_) == 5 for g_ in gathered)   # every sample once, equal shares
+    # a set that does not divide: the same number of batches on every rank, no sample twice
+    tr.train_dataset = list(range(5 * world + world - 1))
+    idx = [b[0] for b in tr.get_train_dataloader()]
+    dist.all_gather_object(gathered, idx)
+    flat_idx = sum(gathered, [])
+    ok_shard = ok_shard and len(set(flat_idx)) == len(flat_idx) == 5 * world and all(len(g_) == 5 for g_ in gathered)
     q.put((rank, ok_sum, ok_metric, ok_again, ok_shard, len(launched)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("lora", [False, True])
-def test_bucketed_allreduce_gloo_world2(lora):
-    world = 2
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("lora,world", [(False, 2), (True, 2), (False, 8), (True, 8)])
+def test_bucketed_allreduce_gloo_world2(lora, world):
+    """world 2, and world 8 = the target node (full fine-tune and LoRA bucket schedules, the fused metric
+    reduce and the rank-strided sampler at the world size the machine has)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, lora)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=500) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -232,7 +239,7 @@ def _worker_zero1(rank, world, port, q, lora, grad_scale):
         opt.step(hp["lr"], hp["b1"], hp["b2"], hp["eps"], hp["wd"], step, 1.0, clip_b)
     n_shard, n_rem = opt.master.numel(), opt.rem_master.numel()
     covers = launched[0][0] == 0 and launched[-1][1] == b.n_train and world * n_shard + n_rem == b.n_train
-    master, m_, v_ = opt.gather_full_state()
+    master, m_, v_ = opt.gather_full_state(all_ranks=True)
     same_p = bool(torch.equal(a.train_p, b.train_p))
     same_state = bool(torch.equal(master, a.flat_master) and torch.equal(m_, a.flat_m) and torch.equal(v_, a.flat_v))
     close_p = float((a.train_p.float() - b.train_p.float()).abs().max())
@@ -244,8 +251,9 @@ def _worker_zero1(rank, world, port, q, lora, grad_scale):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("lora,world,grad_scale", [(False, 2, 1e-3), (True, 2, 1e-3), (False, 2, 1.0), (False, 3, 1e-3)])
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("lora,world,grad_scale", [(False, 2, 1e-3), (True, 2, 1e-3), (False, 2, 1.0), (False, 3, 1e-3),
+                                                   (False, 8, 1e-3), (True, 8, 1e-3)])
 def test_zero1_sharded_optimizer_equals_replicated(lora, world, grad_scale):
     """Opt-in ZeRO-1 (dist.ShardedGradReducer + ShardedAdamW; VERDICT r4 next 6b, script/zero2.json:16-22): reduce-scatter of the
     gradient ranges, clip + AdamW on 1 / W of the parameters, in-place all-gather of the updated bf16 parameters - against the
@@ -260,7 +268,7 @@ def test_zero1_sharded_optimizer_equals_replicated(lora, world, grad_scale):
     procs = [ctx.Process(target=_worker_zero1, args=(r, world, port, q, lora, grad_scale)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=500) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -272,3 +280,85 @@ def test_zero1_sharded_optimizer_equals_replicated(lora, world, grad_scale):
             assert same_p and same_state, (rank, same_p, same_state, close_p)
         else:
             assert close_p <= 2e-3, close_p
+
+
+def _worker_chunks(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from rlaif_v_amd.dist import ShardedAdamW, ShardedGradReducer, init_process_group_from_env
+    init_process_group_from_env("gloo")
+    K = _CpuOptKernels
+    # ranges launched one by one (1-element buckets): widths below 8 W (no chunk at all: c = 0, everything is remainder), exactly
+    # 8 W (one 8-element chunk per rank, no remainder), 8 W + 8 W - 8 (the largest remainder) and a long one; an EMPTY range in
+    # the schedule (plan() must skip it like _launch() does); the weight-decay boundary inside a chunk and inside a remainder
+    W8 = 8 * world
+    widths = [40, W8, 2 * W8 - 8, 0, 24, 5 * W8 + 16, 8]
+    sched, a = [], 0
+    for i, w in enumerate(widths):
+        sched.append((f"r{i}", a, a + w))
+        a += w
+    n = a
+    n_decay = 40 + W8 + W8 + 8                     # inside the third range: in rank 1's chunk for W = 8 ... and below, inside a remainder
+    out = []
+    for nd in (n_decay, 40 + W8 + 2 * W8 - 4, n):
+        p0 = (torch.randn(n, generator=torch.Generator().manual_seed(3)) * 0.05).to(torch.bfloat16)
+        # small integers x 2^-12: every partial sum of W <= 8 of them is exact in bf16, so the ring all-reduce and the reduce-scatter
+        # agree bit for bit whatever their summation orders (random bf16 values differ from 3 ranks on, see the test above)
+        grads = [(torch.randint(-8, 9, (n,), generator=torch.Generator().manual_seed(50 + r)).float() * 2.0 ** -12).to(torch.bfloat16)
+                 for r in range(world)]
+        # replicated reference: the sum every rank would hold after an all-reduce, one AdamW step over everything
+        g_sum = grads[0].clone()
+        dist.all_reduce(g_sum := grads[rank].clone(), op=dist.ReduceOp.SUM)
+        pa = p0.clone()
+        ma, m_, v_ = pa.float(), torch.zeros(n), torch.zeros(n)
+        ss, clip = torch.zeros(1), torch.zeros(2)
+        K.sumsq(g_sum, ss, False)
+        K.clip(ss, 1.0, clip, 1.0 / world)
+        K.adamw(pa[:nd], ma[:nd], m_[:nd], v_[:nd], g_sum[:nd], 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, clip)
+        K.adamw(pa[nd:], ma[nd:], m_[nd:], v_[nd:], g_sum[nd:], 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, clip)
+        # sharded
+        pb = p0.clone()
+        flat = grads[rank].clone()
+        red = ShardedGradReducer(flat, bucket_bytes=1)
+        opt = ShardedAdamW(pb, nd, red, sched, kernels=K)
+        for name, x, y in sched:
+            red.on_bucket_ready(name, x, y)
+        launched = red.finish()
+        clip_b = torch.zeros(2)
+        opt.step(1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, clip_b)
+        cs = [c for _, _, c, _ in opt.ranges]
+        covered = sum(world * c for c in cs) + sum(y - x for x, y in opt.rem_spans) == n and all(b > a_ for a_, b, _, _ in opt.ranges)
+        full = opt.gather_full_state(all_ranks=True)
+        out.append((bool(torch.equal(pa, pb)), bool(torch.equal(full[0], ma) and torch.equal(full[2], v_)), covered, cs, len(launched),
+                    opt.gather_full_state() is None))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 8])
+def test_zero1_chunking_rule_small_ranges(world):
+    """The chunking rule c = floor((b - a) / 8 W) * 8 at the world size of the target node (exercised at W = 2, 3
+    only before), on ranges NARROWER than 8 W, exactly 8 W wide and with the largest possible remainder, with an empty range in
+    the schedule and the weight-decay boundary inside a chunk, inside a remainder and at the end: parameters and gathered state
+    bit-identical to the replicated step (clipping inactive); gather_full_state() hands host tensors to rank 0 only."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chunks, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for same_p, same_state, covered, cs, n_launch, none_elsewhere in out:
+            assert same_p and same_state and covered, (rank, same_p, same_state, covered, cs)
+            W8 = 8 * world
+            widths = [40, W8, 2 * W8 - 8, 24, 5 * W8 + 16, 8]                            # the schedule's non-empty ranges
+            assert cs == [(w // W8) * 8 for w in widths] and n_launch == 6, (cs, n_launch)    # the empty range is neither planned nor launched
+            if world == 8:
+                assert cs == [0, 8, 8, 0, 40, 0]
+            assert none_elsewhere == (rank != 0)
