@@ -25,9 +25,9 @@ extern "C" {
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
-/* ---- TEST-ONLY knobs (the three rv_set_* below).  They write process-global state without synchronisation: call them from ONE
+/* ---- TEST-ONLY knobs (the four rv_set_* below).  They write process-global state without synchronisation: call them from ONE
  * thread, with no launch of this library in flight on another thread, and never from production code - the product path
- * (rlaif-v_amd/*.py) does not call them; tests use them to run two kernel generations against each other inside one process.
+ * (the rlaif-v_amd Python modules) does not call them; tests use them to run two kernel generations against each other inside one process.
  * Everything else in this library is stateless (per-call arguments only).
  * A/B and test knob: 1 (default, also RV_GEMM_MI16) = the NN-A64 / fused-LoRA NN / TN main loops issue 16x16x32 MFMAs
  * (more flops per joule under the package power cap, profiles/r02_mfma_shape_power_probe.log); 0 = the 32x32x16 loops.
@@ -36,6 +36,10 @@ int rv_set_gemm_mi16(int on);
 /* dK/dV kernel of rv_attn_bwd: 5 = the round-4 kernel (default), 3 = the round-2/3 kernel, 0 = back to the default / RV_ATTN_DKV.
  * A/B and test knob (both kernels against each other in one process); replaces nothing in the reference. */
 int rv_set_attn_dkv_version(int version);
+/* forward kernel of rv_attn_fwd at head dim 128: 3 = the round-6 kernel (one wave per SIMD, two 32-query blocks per wave
+ * software-pipelined across key tiles, lazy rescale; csrc/attn_fwd3.inc), 2 = the round-2..5 kernel, 0 = back to the default /
+ * RV_ATTN_FWD.  A/B and test knob; replaces nothing in the reference. */
+int rv_set_attn_fwd_version(int version);
 /* GEMM kernel selection: -1 = auto (default), 0 = 128x128x64 register-staged, 1 = 128x128x64 global_load_lds,
  * 2 = 256x256x32 ping-pong (two wave groups alternating MFMA / load segments). */
 int rv_set_gemm_variant(int variant);

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "librlaifv_hip.so")
 SOURCES = ["gemm.hip", "elementwise.hip", "attention.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm.hpp"), os.path.join(CSRC, "attn_agpr.inc"), os.path.join(CSRC, "attn_dkv5_body.inc"), os.path.join(CSRC, "attn_dkv5_skip.inc"), os.path.join(CSRC, "attn_dkv5_prefetch.inc"), os.path.join(INCLUDE, "rlaifv_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm.hpp"), os.path.join(CSRC, "attn_agpr.inc"), os.path.join(CSRC, "attn_fwd3.inc"), os.path.join(CSRC, "attn_dkv5_body.inc"), os.path.join(CSRC, "attn_dkv5_skip.inc"), os.path.join(CSRC, "attn_dkv5_prefetch.inc"), os.path.join(INCLUDE, "rlaifv_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 

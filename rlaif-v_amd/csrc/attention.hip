@@ -55,6 +55,9 @@ __device__ __forceinline__ void mfma_agpr_zero(f32x16_t& acc) {
 #ifndef RV_ATTN_FWD_NW_DEFAULT
 #define RV_ATTN_FWD_NW_DEFAULT 4
 #endif
+#ifndef RV_ATTN_FWD_DEFAULT
+#define RV_ATTN_FWD_DEFAULT 2      // forward kernel at head dim 128: 2 = attn_fwd2_kernel, 3 = attn_fwd3_kernel (attn_fwd3.inc)
+#endif
 __device__ __forceinline__ void xhalf_pair(float x, float& a, float& b) {
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
   const unsigned u = __builtin_bit_cast(unsigned, x);
@@ -272,6 +275,23 @@ struct TileDma {
     for (int i = 0; i < NP; ++i) {
       const int row = piece_row(wave, lane, i);
       voff[i] = (uint32_t)row * ldb + (uint32_t)piece_col(row, lane) * 2u;
+    }
+  }
+  // piece I of the NP pieces of this wave (the forward kernel of round 6 spreads a tile's pieces over its MFMA gaps)
+  template <int I>
+  __device__ __forceinline__ void issue_piece(const bf16_t* base, long ld, long tok0, int r0, int L, uint8_t* dst, int wave) const {
+    const char* seq = (const char*)(base + tok0 * ld);     // wave-uniform
+    if (r0 + 64 <= L) {
+      const char* b = seq + (size_t)(uint32_t)r0 * ldb;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + voff[I]),
+                                       (__attribute__((address_space(3))) void*)(dst + (wave * NP + I) * 1024), 16, 0, 0);
+    } else {
+      const int lane = threadIdx.x & 63;
+      const int row = piece_row(wave, lane, I);
+      const uint32_t r = (uint32_t)min(r0 + row, L - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(seq + (r * ldb + (uint32_t)piece_col(row, lane) * 2u)),
+          (__attribute__((address_space(3))) void*)(dst + (wave * NP + I) * 1024), 16, 0, 0);
     }
   }
   __device__ __forceinline__ void issue(const bf16_t* base, long ld, long tok0, int r0, int L, uint8_t* dst, int wave) const {
@@ -1541,15 +1561,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(const bf16_t* __r
 #undef BF
 #undef PROF
 
+#include "attn_fwd3.inc"
+
 }  // namespace
 
 static int g_dkv_override = 0;
+static int g_fwd_override = 0;
 
 extern "C" {
 
 int rv_set_attn_dkv_version(int version) {
   RV_REQUIRE(version == 0 || version == 3 || version == 5, "rv_set_attn_dkv_version: 0 (environment / default), 3 or 5");
   g_dkv_override = version;
+  return 0;
+}
+
+int rv_set_attn_fwd_version(int version) {
+  RV_REQUIRE(version == 0 || version == 2 || version == 3, "rv_set_attn_fwd_version: 0 (environment / default), 2 or 3");
+  g_fwd_override = version;
   return 0;
 }
 
@@ -1587,7 +1616,11 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   hipStream_t st = (hipStream_t)stream;
   static int fwd_nw = -1;         // RV_ATTN_FWD_NW: 4 = 128-query workgroups (two per CU), 8 = 256-query workgroups on one K / V ring (hd 128)
   if (fwd_nw < 0) { const char* e = getenv("RV_ATTN_FWD_NW"); fwd_nw = (e && atoi(e) == 8) ? 8 : RV_ATTN_FWD_NW_DEFAULT; }
-  const int nw = (hd == 128) ? fwd_nw : 4;
+  static int fwd_env = -1;        // RV_ATTN_FWD: 3 = attn_fwd3_kernel (hd 128; csrc/attn_fwd3.inc), 2 = attn_fwd2_kernel
+  if (fwd_env < 0) { const char* e = getenv("RV_ATTN_FWD"); fwd_env = (e && (atoi(e) == 2 || atoi(e) == 3)) ? atoi(e) : RV_ATTN_FWD_DEFAULT; }
+  const int fwd_ver = g_fwd_override ? g_fwd_override : fwd_env;
+  const bool v3 = hd == 128 && fwd_ver == 3;
+  const int nw = v3 ? 8 : (hd == 128) ? fwd_nw : 4;             // version 3: 256-query blocks (4 waves x 64 rows)
   const int nb = (L + 32 * nw - 1) / (32 * nw);
   static int pair_mode = -1;      // RV_ATTN_PAIR: 0 = the plain (x, n-1-x) pairing, 1 = pair_blocks (ranked pairs), 2 = one ranked block per workgroup
   if (pair_mode < 0) { const char* e = getenv("RV_ATTN_PAIR"); pair_mode = e ? atoi(e) : 1; }
@@ -1595,6 +1628,22 @@ int rv_attn_fwd(const void* qkv, long ld, int q_col0, int k_col0, int v_col0, vo
   const int nx = nxr | (map_mode << 16) | ((pair_mode ? 1 : 0) << 20) | ((causal && pair_mode == 2 ? 1 : 0) << 21);
   dim3 grid(nxr * H * S), block(64 * nw);
   static bool attr_done = false;
+  if (v3) {
+    static bool attr3_done = false;
+    if (!attr3_done) {
+      hipFuncSetAttribute((const void*)attn_fwd3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 64 * 128 * 2);
+      hipFuncSetAttribute((const void*)attn_fwd3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 64 * 128 * 2);
+      attr3_done = true;
+    }
+    if (causal)
+      hipLaunchKernelGGL((attn_fwd3_kernel<true>), grid, dim3(256), 7 * 64 * 128 * 2, st, (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0,
+                         (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group, row_off, row_len);
+    else
+      hipLaunchKernelGGL((attn_fwd3_kernel<false>), grid, dim3(256), 7 * 64 * 128 * 2, st, (const bf16_t*)qkv, ld, q_col0, k_col0, v_col0,
+                         (bf16_t*)out, ldo, lse, L, H, nx, scale, seg_sh, seg_e1, kv_group, row_off, row_len);
+    RV_CHECK_LAUNCH();
+    return 0;
+  }
   if (!attr_done) {
     hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipFuncSetAttribute((const void*)attn_fwd2_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
