@@ -462,6 +462,59 @@ def test_attn_fwd_online_softmax_rescale(ops):
     torch.testing.assert_close(lse, rl, rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("case", ["causal L1", "causal L257", "causal L640", "causal L1000", "full L577", "gqa4 causal L333", "packed L900",
+                                  "packed L1300", "pad-free rows", "late dominating key", "early dominating key", "causal L2048 H32"])
+def test_attn_fwd3_matches_reference(ops, case):
+    """attn_fwd3_kernel (round 6: one wave per SIMD, two software-pipelined 32-query blocks per wave, O / Q / K fragments in
+    hard-numbered AGPRs, lazy rescale; csrc/attn_fwd3.inc) behind the test knob rv_set_attn_fwd_version(3): same bars as version 2
+    against fp32 torch attention.  It is NOT the default (profiles/r06_attn_fwd3_negative_result.log); the test keeps it correct."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.exp_attn_fwd3 import ref_attn
+    from rlaif_v_amd import hip
+    dev = _dev()
+    cases = {"causal L1": dict(S=2, L=1, H=3, causal=True), "causal L257": dict(S=2, L=257, H=3, causal=True),
+             "causal L640": dict(S=2, L=640, H=3, causal=True), "causal L1000": dict(S=2, L=1000, H=3, causal=True),
+             "full L577": dict(S=1, L=577, H=2, causal=False), "gqa4 causal L333": dict(S=2, L=333, H=8, G=4, causal=True),
+             "packed L900": dict(S=2, L=900, H=2, causal=True, seg=([100, 257], [500, 600])),
+             "packed L1300": dict(S=1, L=1300, H=2, causal=True, seg=([64], [700])),
+             "pad-free rows": dict(S=3, L=700, H=2, causal=True, rows=[700, 130, 513], seg=([40, 10, 300], [400, 60, 400])),
+             "late dominating key": dict(S=1, L=512, H=1, causal=True, spike=(300, 511, 6.0)),
+             "early dominating key": dict(S=1, L=512, H=1, causal=True, spike=(3, 511, 6.0)),
+             "causal L2048 H32": dict(S=1, L=2048, H=32, causal=True)}
+    c = cases[case]
+    S, L, H, G, hd = c["S"], c["L"], c["H"], c.get("G", 1), 128
+    d, dk = H * hd, (H // G) * hd
+    g = torch.Generator().manual_seed(len(case) * 7 + L)
+    rows, ntok = None, S * L
+    if "rows" in c:
+        lens = torch.tensor(c["rows"], dtype=torch.int32)
+        rows = ((torch.cumsum(lens, 0, dtype=torch.int32) - lens).to(dev), lens.to(dev))
+        ntok = int(lens.sum())
+    qkv = (torch.randn(ntok, d + 2 * dk, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    if "spike" in c:
+        kj, qi, amp = c["spike"]
+        qkv[qi, :hd] = qkv[qi, :hd].sign()
+        qkv[kj, d:d + hd] = amp * qkv[qi, :hd].sign()
+    seg = None
+    if "seg" in c:
+        seg = tuple(torch.tensor(x, dtype=torch.int32, device=dev) for x in c["seg"])
+    ro, rl = ref_attn(qkv, S, L, H, hd, c["causal"], G, seg, rows)
+    lib = hip.lib()
+    lib.call("rv_set_attn_fwd_version", 3)
+    try:
+        for rep in range(3 if L >= 1000 else 1):          # the kernel's first build was wrong NON-deterministically at many-tile shapes
+            out, lse = ops.attn_fwd(qkv, S, L, H, hd, c["causal"], 0, d, d + dk, seg=seg, kv_group=G, rows=rows)
+            torch.cuda.synchronize()
+            close(out, ro, rel=2e-2, what=f"attn fwd3 {case}")
+            for s_ in range(S):
+                n = int(rows[1][s_]) if rows is not None else L
+                torch.testing.assert_close(lse[s_, :, :n], rl[s_, :, :n], rtol=1e-3, atol=3e-3)
+    finally:
+        lib.call("rv_set_attn_fwd_version", 0)
+
+
 @pytest.mark.parametrize("causal,L", [(True, 200), (True, 128), (False, 97), (True, 1)])
 def test_attn_bwd(ops, causal, L):
     dev = _dev()

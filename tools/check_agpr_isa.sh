@@ -7,6 +7,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -I$R/rlaif-v_amd/csrc -S --cuda-device-only -o $T/attn.s $R/rlaif-v_amd/csrc/attention.hip 2>/dev/null || exit 2
 rc=0
+awk '$0 ~ "^_ZN12_GLOBAL__N_116attn_fwd3_kernel.*:$"{k=1} k&&/s_endpgm/{k=0} k&&/#ASMSTART/{a=1} k&&/#ASMEND/{a=0} k&&!a&&/v_accvgpr|scratch_/{print; bad++} END{print "compiler-emitted accvgpr/scratch instructions in fwd3:", bad+0; exit bad>0}' $T/attn.s || rc=1
 for K in dkv3 dkv5; do
   awk -v K=$K '$0 ~ "^_ZN12_GLOBAL__N_120attn_bwd_" K "_kernel.*:$"{k=1} k&&/s_endpgm/{k=0} k&&/#ASMSTART/{a=1} k&&/#ASMEND/{a=0} k&&!a&&/v_accvgpr|scratch_/{print; bad++} END{print "compiler-emitted accvgpr/scratch instructions in " K ":", bad+0; exit bad>0}' $T/attn.s || rc=1
 done
