@@ -172,19 +172,22 @@ def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
     """The oracle (a port of the reference's step) at BASELINE config 1's shape: 4 synthetic 336-px
     pairs, text length 512 -> spliced length 1087, fp32, one fwd + bwd + clip + AdamW step at full 7B widths.
     TWO figures, kept apart by ``source``:
-      * ``live_extrapolated`` - timed on THIS box's host cores in THIS run: bounded sample = depths 1 and 2 of the language model
+      * ``live_extrapolated`` - timed on THIS box's host cores in THIS run: bounded sample = depths 2 and 4 of the language model
         (CLIP at full depth), the per-layer slope extrapolated linearly to 32 layers; ``kind`` / ``host_cores`` / ``phases_s`` /
         ``measured_s`` describe this box;
       * ``full_depth_measured`` - the same step MEASURED once at all 32 layers on a GPU box's host (another machine of the same
-        pool; profiles/r03_parity_full_depth.json).  When that committed file is present ``value`` / ``cores`` quote IT and
-        ``source`` says so; when it is missing ``value`` is the live extrapolation, ``source`` says that, and stderr gets a line.  The reference's OWN functions, timed the same way in the build container
+        pool; profiles/r03_parity_full_depth.json).  ``value`` / ``cores`` quote the LIVE figure of this box when it lands within
+        10 % of that measurement (round 6), the committed measurement otherwise; ``source`` says which; when the file is missing
+        ``value`` is the live extrapolation, ``source`` says that, and stderr gets a line.  The reference's OWN functions, timed the same way in the build container
     (tools/cpu_reference_baseline.py -> profiles/r02_cpu_reference_baseline.json), ride along as ``reference_run``."""
     from oracle import dpo_oracle as O
     cores = os.cpu_count() or 1
     threads = min(cores, 128)
     torch.set_num_threads(threads)
     res = {}
-    for depth in (1, 2):
+    D0, D1 = 2, 4               # round 6 (VERDICT r5 next 7): depths 2 and 4 - the 1 -> 2 slope of round 5 carried depth 1's cache-warm
+                                # first layer into the extrapolation and landed 9 - 31 % high of the measured 588 s
+    for depth in (D0, D1):
         cfg = O.LlavaCfg(layers=depth, model_max_length=2048)
         W = O.make_weights(cfg, seed=seed, bf16_round=False)
         batch = O.make_synthetic_batch(cfg, pairs, text_len, 64, seed=seed, ragged=False)
@@ -192,12 +195,12 @@ def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
         O.dpo_train_step(batch, W, cfg, {}, lr=5e-7, step=1, sft_weight=0.0, dpo_weight=1.0, timings=ph)
         res[depth] = ph
         del W
-    per_layer = {k: max(res[2][k] - res[1][k], 0.0) for k in ("fwd_s", "bwd_s", "opt_s")}
-    fixed = {k: max(res[1][k] - per_layer[k], 0.0) for k in per_layer}
+    per_layer = {k: max(res[D1][k] - res[D0][k], 0.0) / (D1 - D0) for k in ("fwd_s", "bwd_s", "opt_s")}
+    fixed = {k: max(res[D0][k] - D0 * per_layer[k], 0.0) for k in per_layer}
     full = {k: fixed[k] + 32 * per_layer[k] for k in per_layer}
     step = sum(full.values())
     out = dict(value=pairs / step, unit="pairs/s", cores=threads, kind="port",
-               sample=f"oracle fp32 step, config 1 ({pairs} pairs, T={text_len}, L={text_len + 575}), depths 1,2 -> 32 layers: {step:.0f} s",
+               sample=f"oracle fp32 step, config 1 ({pairs} pairs, T={text_len}, L={text_len + 575}), depths {D0},{D1} -> 32 layers: {step:.0f} s",
                host_cores=cores, step_s_extrapolated=step,
                phases_s={k[:-2]: round(v, 2) for k, v in full.items()},
                measured_s={str(d): {k[:-2]: round(v, 2) for k, v in res[d].items()} for d in res})
@@ -207,14 +210,22 @@ def cpu_baseline(seed: int = 0, pairs: int = 4, text_len: int = 512):
     try:
         with open(os.path.join(REPO, "profiles", "r03_parity_full_depth.json")) as fh:
             fd = json.load(fh)["cpu_step_measured"]
-        out["live_extrapolated"] = dict(value=out["value"], unit="pairs/s", step_s=step, over_measured=step / fd["step_s"])
+        ratio = step / fd["step_s"]
+        out["live_extrapolated"] = dict(value=out["value"], unit="pairs/s", step_s=step, over_measured=ratio)
         out["full_depth_measured"] = dict(fd, unit="pairs/s", value=fd["pairs_per_s"], source="profiles/r03_parity_full_depth.json")
-        out["value"] = fd["pairs_per_s"]
-        out["cores"] = fd["threads"]
-        out["source"] = "full_depth_measured (committed profiles/r03_parity_full_depth.json: another box of the same pool, NOT this run)"
-        out["sample"] = (f"oracle fp32 step, config 1 ({fd['pairs']} pairs, T=512, L=1087), ALL {fd['layers']} layers MEASURED on a GPU box's "
-                         f"host ({fd['threads']} threads): {fd['step_s']:.0f} s (profiles/r03_parity_full_depth.json); this run's live "
-                         f"bounded sample (depths 1,2 -> 32 layers by extrapolation): {step:.0f} s")
+        if abs(ratio - 1.0) <= 0.10:
+            # north_star asks for the CPU figure of THIS box: the live extrapolation is quoted whenever the committed full-depth
+            # measurement (another box of the same pool) confirms it to 10 %
+            out["source"] = (f"live_extrapolated (this run, this box: depths {D0},{D1} -> 32 layers; {ratio:.2f} x the full-depth step MEASURED "
+                             f"on a GPU box's host, {fd['step_s']:.0f} s, profiles/r03_parity_full_depth.json)")
+        else:
+            out["value"] = fd["pairs_per_s"]
+            out["cores"] = fd["threads"]
+            out["source"] = ("full_depth_measured (committed profiles/r03_parity_full_depth.json: another box of the same pool, NOT this run; "
+                             f"this run's extrapolation is {ratio:.2f} x it and was not trusted)")
+            out["sample"] = (f"oracle fp32 step, config 1 ({fd['pairs']} pairs, T=512, L=1087), ALL {fd['layers']} layers MEASURED on a GPU box's "
+                             f"host ({fd['threads']} threads): {fd['step_s']:.0f} s (profiles/r03_parity_full_depth.json); this run's live "
+                             f"bounded sample (depths {D0},{D1} -> 32 layers by extrapolation): {step:.0f} s")
     except (OSError, KeyError, ValueError) as e:
         out["source"] = "live_extrapolated (this run, this box)"
         print(f"bench.py cpu_baseline: profiles/r03_parity_full_depth.json unusable ({e!r}); value = this run's extrapolation", file=sys.stderr)
@@ -590,10 +601,16 @@ def main():
             # any other workload reports traffic = null instead of a constant that does not describe it
             pmc_config_matches = (not args.lora and not args.omnilmm and not args.ragged and args.layers == 32 and L == 2048 and B == 8
                                   and not args.gradient_checkpointing)        # per GPU: weak scaling keeps it
-            for name in (() if not pmc_config_matches else ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")):   # newest committed PMC passes first
+            traffic_by_class = {}
+            for name in (() if not pmc_config_matches else ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")):   # newest committed PMC passes first
                 try:   # HBM bytes per GEMM launch (profiles/, separate rocprofv3 --pmc runs of this same command)
                     with open(os.path.join(REPO, "profiles", name)) as fh:
-                        traffic = json.load(fh)["gemm_all_launches_hbm_bytes_per_launch"]
+                        pmc = json.load(fh)
+                    traffic = pmc["gemm_all_launches_hbm_bytes_per_launch"]
+                    for cls, kern in (("nn", "gemm_nn_a64_kernel<EpiStore"), ("tn", "gemm_tn_256_kernel<EpiStore"),
+                                      ("nn_swiglu", "gemm_nn_a64_kernel<EpiSwiGLU,"), ("nn_swiglu_bwd", "gemm_nn_a64_kernel<EpiSwiGLUBwd")):
+                        if kern in pmc.get("kernels", {}):
+                            traffic_by_class[cls] = pmc["kernels"][kern]["hbm_bytes_per_launch_corrected"]
                     traffic_file = name
                     break
                 except Exception:
@@ -614,6 +631,10 @@ def main():
                           achieved=d["tflops"], frac=d["tflops"] / PEAK_BF16_TFLOPS,
                           alg_bytes_per_launch=d["alg_bytes"] / max(d["launches"], 1))
                   for k, d in sorted(g["by_kernel"].items(), key=lambda kv: -kv[1]["ms"])}
+            for cls, tb in traffic_by_class.items():      # measured HBM bytes per launch of the class / its algorithmic operand + result bytes
+                if cls in by and by[cls]["alg_bytes_per_launch"] > 0:
+                    by[cls]["traffic"] = tb
+                    by[cls]["traffic_ratio"] = tb / by[cls]["alg_bytes_per_launch"]
             dom = next((k for k in by if not k.startswith("attn_")), None)      # the dominant kernel is a GEMM class (75 % of GPU time)
             weakest = min((k for k in by if by[k]["ms_per_step"] >= 10.0), key=lambda k: by[k]["frac"], default=None)
             line["roofline"] = {"bound": "mfma",
@@ -621,6 +642,7 @@ def main():
                                           "backward, fused LM-head log-prob forward and backward, fused-LoRA forms): 256x256 ping-pong tiles",
                                 "achieved": g["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": g["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+                                "traffic_ratio": (traffic / (g["alg_bytes"] / max(g["launches"], 1))) if traffic is not None else None,
                                 "traffic_note": (("HBM bytes per GEMM launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + "
                                                  f"WRITE_SIZE, separate passes (profiles/{traffic_file}); ") if traffic is not None else
                                                  "null: no PMC pass was collected on this workload (the committed passes are the headline config's); ")

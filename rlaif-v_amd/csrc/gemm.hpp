@@ -1829,7 +1829,12 @@ struct EpiStore {
 // LlamaMLP.forward).  The fused weight stores gate and up INTERLEAVED (row 2j = gate_j, row 2j+1 = up_j), so a lane that holds 8
 // consecutive output columns holds 4 complete (gate, up) pairs: it writes the gate|up tile (kept for backward) AND the
 // activation tile act[m][j] = silu(g) * u - the separate swiglu pass (1.2 GB read + 0.6 GB write per layer) disappears.
-// The activation is computed from the bf16-ROUNDED g, u (what the unfused kernel would read back): bit-identical results.
+// Round 6: the activation is computed from the fp32 ACCUMULATORS of the GEMM, not from the bf16-rounded g, u the
+// unfused kernel would read back - one rounding (of the product) instead of three; the rounding-point study attributed 19 % of the
+// per-token log-prob error to the gate|up term (profiles/r05_rounding_attribution.json).  Free in time; the price is that the
+// fused forward is no longer bit-identical to GEMM -> bf16 -> swiglu kernel (it is CLOSER to the fp32 product: asserted in
+// tests/test_kernels_gpu.py::test_swiglu_fused_gemm_epilogues).  The kept gate|up tile is still the rounded one, and the backward
+// (EpiSwiGLUBwd, swiglu_bwd_kernel) differentiates at it, as does RV_KEEP_RECOMPUTABLE=0's recomputed activation.
 struct EpiSwiGLU {
   bf16_t* C; long ldc;        // gate|up, interleaved columns [M][N]
   bf16_t* ACT; long lda;      // activation [M][N/2]
@@ -1851,13 +1856,10 @@ struct EpiSwiGLU {
           }
           const int n = nw + tn * 32 + rgp * 16 + 8 * half;
           if (n >= N) continue;
-          const uint4 pk = epi_pack8(v);
-          *(uint4*)(C + (long)m * ldc + n) = pk;
-          float r[8];
-          epi_unpack8(pk, r);
+          *(uint4*)(C + (long)m * ldc + n) = epi_pack8(v);
           float o[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = r[2 * j] / (1.f + __expf(-r[2 * j])) * r[2 * j + 1];
+          for (int j = 0; j < 4; ++j) o[j] = v[2 * j] / (1.f + __expf(-v[2 * j])) * v[2 * j + 1];
           uint2 w;
           w.x = pack2bf(o[0], o[1]);
           w.y = pack2bf(o[2], o[3]);

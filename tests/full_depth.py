@@ -32,6 +32,12 @@ from oracle import dpo_oracle as O
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WEIGHT_SEED = 41
 N_SAMPLE = 1024
+GRAD_COS_FLOOR = 0.94             # absolute floor under the emulation-calibrated per-tensor gradient cosine bar (worst committed yardstick: 0.948)
+MAX_TENSORS_BELOW_0_99 = 24       # per case: tensors whose HIP gradient cosine may sit below 0.99 at all
+# the worst per-tensor cosine of the bf16-EMULATED oracle's backward in every committed fixture (tests/test_host_logic.py pins them:
+# regenerating a fixture cannot move its yardstick unnoticed)
+EMU_GRAD_COS_WORST = {'cfg1_cond': 0.99087, 'cfg1_step': 0.99051, 'cfg1m_step': 0.98946, 'cfg2_cond': 0.99149, 'cfg2_step': 0.99129,
+                      'cfg4_cond': 0.94828, 'cfg4_step': 0.94888, 'cfg5_cond': 0.99099, 'cfg5_drop': 0.99148, 'cfg5_step': 0.99097}
 CASES = {
     "cfg1_step": dict(seed=41, pairs=4, text_len=512, prompt_len=64, ragged=True, answer_lens=None, lr=5e-7, step=True),
     "cfg2_fwd": dict(seed=42, pairs=1, text_len=2048 - 575, prompt_len=64, ragged=False, answer_lens=[(1409, 704)],
@@ -865,13 +871,17 @@ def compare(case: str, hip: Dict[str, object], fx: Dict[str, object], W0: Option
             # sits further than 0.99 from the fp32 gradient, the HIP gradient must be no further than the emulation is
             emu_cs = fx["emu_grad_cos"][k]
             worst_emu_cos = min(worst_emu_cos, emu_cs)
-            cs_bar = min(0.99, emu_cs)
+            # ... with an ABSOLUTE floor: the yardstick lives in the same fixtures the same harness regenerates, so a
+            # regression of the emulated oracle's backward must not be able to lower the bar without limit
+            cs_bar = max(min(0.99, emu_cs), GRAD_COS_FLOOR)
             if cs < 0.99:
                 below_99.append((k, cs, emu_cs))
         if check:
             assert rel <= 3e-2 and cs >= cs_bar, (k, rel, cs, cs_bar)
     m.update(grad_tensors=len(per_tensor), grad_worst_norm_rel_err=worst_norm, grad_worst_sample_cosine=worst_cos)
     if "emu_grad_cos" in fx:
+        if check:      # few tensors may sit below 0.99 at all (measured: 0 - 9 of 295 / 514 per case, profiles/r05_parity_full_depth.json)
+            assert len(below_99) <= MAX_TENSORS_BELOW_0_99, (len(below_99), sorted(below_99, key=lambda t: t[1])[:4])
         m.update(emu_bf16_grad_worst_sample_cosine=worst_emu_cos, grad_tensors_below_cosine_0_99=len(below_99),
                  grad_tensors_below_cosine_0_99_examples=sorted(below_99, key=lambda t: t[1])[:8])
     if "_full_grads" in hip and "_full_grads" in fx:

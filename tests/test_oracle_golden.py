@@ -145,3 +145,22 @@ def test_oracle_matches_reference_at_full_width(golden_dir):
         assert abs(got - ref) <= 5e-4 * max(ref, 1e-6) + 1e-7, (k, got, ref)
     for k, ref in g["grad_full"].items():
         torch.testing.assert_close(W[k].grad, ref, rtol=5e-3, atol=1e-6)
+
+
+def test_full_depth_fixtures_carry_their_pinned_yardsticks(golden_dir):
+    """The per-tensor gradient bars of the full-depth GPU tests are calibrated against the bf16-EMULATED oracle's backward, stored
+    in the fixtures themselves (tests/full_depth.py compare()).  ADVICE r5: pin the committed yardsticks, so that regenerating a
+    fixture - with a regressed emulated backward - cannot lower a bar unnoticed; and keep every one above the absolute floor."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import full_depth as FD
+    seen = 0
+    for case, worst in FD.EMU_GRAD_COS_WORST.items():
+        path = os.path.join(golden_dir, f"fulldepth_{case}.pt")
+        fx = torch.load(path, weights_only=False)
+        got = min(fx["emu_grad_cos"].values())
+        assert abs(got - worst) <= 2e-5, (case, got, worst)
+        assert got >= FD.GRAD_COS_FLOOR
+        seen += 1
+    assert seen == 10
