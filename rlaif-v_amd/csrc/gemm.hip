@@ -282,6 +282,19 @@ static bool launch_nn_h128(const GemmShape& g, const Epi& epi, hipStream_t st) {
 }
 #endif
 
+// EXPERIMENT switch (RV_GU_TILE_MAJOR=1, read once): the kept gate|up tensor of the fused SwiGLU epilogues in tile-major layout
+// (EpiSwiGLU::gu_index).  The caller must hand a buffer of ceil(M / 256) * 256 rows (rlaif-v_amd/ops.py does when the variable is
+// set); every consumer of that tensor other than rv_gemm_nn_swiglu_bwd_bf16 would read garbage - not for production use.
+static int gu_tile_major() {
+#ifdef RV_GEMM_EXPERIMENTS          // experiment library only (python rlaif-v_amd/build.py --experiments): measured, no gain - see
+  static int v = -1;               // profiles/r06_swiglu_bwd_tile_major_negative_result.log
+  if (v < 0) { const char* e = getenv("RV_GU_TILE_MAJOR"); v = (e && atoi(e) == 1) ? 1 : 0; }
+  return v;
+#else
+  return 0;
+#endif
+}
+
 // NN GEMM with one of the SwiGLU epilogues: the 64-deep-A kernel when K allows, else the 32-deep one
 template <class Epi>
 static int launch_nn_epi(const GemmShape& g, const Epi& epi, hipStream_t st) {
@@ -464,6 +477,7 @@ int rv_gemm_nn_swiglu_bf16(const void* A, long lda, const void* B, long ldb, voi
   read_group_env();
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
   EpiSwiGLU epi{(bf16_t*)GU, ldgu, (bf16_t*)ACT, ldact};
+  if (gu_tile_major()) { epi.tile_major = 1; epi.tiles_n = (N + 255) / 256; }
   return launch_nn_epi(g, epi, (hipStream_t)stream);
 }
 
@@ -478,6 +492,7 @@ int rv_gemm_nn_swiglu_bwd_bf16(const void* A, long lda, const void* B, long ldb,
   read_group_env();
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
   EpiSwiGLUBwd epi{(const bf16_t*)GU, ldgu, (bf16_t*)DGU, lddgu};
+  if (gu_tile_major()) { epi.tile_major = 1; epi.tiles_n = (2 * N + 255) / 256; }
   return launch_nn_epi(g, epi, (hipStream_t)stream);
 }
 

@@ -1838,6 +1838,13 @@ struct EpiStore {
 struct EpiSwiGLU {
   bf16_t* C; long ldc;        // gate|up, interleaved columns [M][N]
   bf16_t* ACT; long lda;      // activation [M][N/2]
+  // EXPERIMENT (round 6; RV_GU_TILE_MAJOR=1): the kept gate|up tensor TILE-MAJOR - 256 x 256 tiles, each 128 KB
+  // contiguous, tile (tm, tn) at ((tm * tiles_n + tn) << 16) - so that the backward epilogue reads two contiguous 128 KB regions
+  // per output tile instead of 256 row segments 44 KB apart.  Requires a buffer of ceil(M / 256) * 256 rows.
+  int tile_major = 0, tiles_n = 0;
+  __device__ __forceinline__ long gu_index(int m, int n) const {
+    return tile_major ? ((((long)(m >> 8) * tiles_n + (n >> 8)) << 16) + ((m & 255) << 8) + (n & 255)) : ((long)m * ldc + n);
+  }
   __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
     const int half = lane >> 5;
 #pragma unroll
@@ -1856,7 +1863,7 @@ struct EpiSwiGLU {
           }
           const int n = nw + tn * 32 + rgp * 16 + 8 * half;
           if (n >= N) continue;
-          *(uint4*)(C + (long)m * ldc + n) = epi_pack8(v);
+          *(uint4*)(C + gu_index(m, n)) = epi_pack8(v);
           float o[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = v[2 * j] / (1.f + __expf(-v[2 * j])) * v[2 * j + 1];
@@ -1876,6 +1883,7 @@ struct EpiSwiGLU {
 struct EpiSwiGLUBwd {
   const bf16_t* GU; long ldgu;
   bf16_t* DGU; long lddgu;
+  int tile_major = 0, tiles_n = 0;      // layout of GU (see EpiSwiGLU); tiles_n counts 256-column tiles of the 2f-wide tensor
   // All 16 gate|up loads of the wave's 64 x 64 block are issued BEFORE the first one is used (addresses clamped into the
   // tensor; out-of-range rows / columns are loaded from valid memory and never stored): one exposed memory latency per block
   // instead of eight.  The edge tests used to be `continue`s in front of the loads - control flow hipcc does not move loads
@@ -1890,7 +1898,9 @@ struct EpiSwiGLUBwd {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int nc = min(nw + (i >> 1) * 32 + (i & 1) * 16 + 8 * half, N - 8);
-        const bf16_t* gp = GU + mc * ldgu + 2 * nc;
+        const int c2 = 2 * nc;
+        const bf16_t* gp = tile_major ? GU + ((((long)(mc >> 8) * tiles_n + (c2 >> 8)) << 16) + ((mc & 255) << 8) + (c2 & 255))
+                                      : GU + mc * ldgu + c2;
         ga[tm][i] = *(const uint4*)gp;
         gb[tm][i] = *(const uint4*)(gp + 8);
       }

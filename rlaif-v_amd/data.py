@@ -1,5 +1,11 @@
-"""Batch construction for the DPO step: the reference's collator surface, kept so the trainer is a
-drop-in (same class/function names, argument meaning and batch-dict keys).
+"""Batch construction for the DPO step: the reference's collator surface (same class / function names, argument meaning and
+batch-dict keys).
+
+STATUS: OFFLINE / BENCH STAND-IN.  At the integration point the reference's OWN collator
+(muffin/train/train_muffin.py:37-112) is the documented default feed of the trainer: this module restates
+it only because tests, bench.py and the GPU box cannot import /root/reference.  It is pinned against a fixture produced by the
+reference collator (tests/test_host_logic.py::test_collator_matches_reference_golden); do not grow it - new host-side behaviour
+belongs in the reference's collator, not in a twin.
 
 Mirrors (paths relative to /root/reference):
   SFT_collator_fn            muffin/train/train_utils.py:55-96

@@ -454,7 +454,8 @@ def linear_swiglu(x: torch.Tensor, wguT: torch.Tensor):
     N = wguT.shape[1]
     if wguT.shape[0] != K:
         raise ValueError(f"linear_swiglu: inner dimensions differ: {K} vs {wguT.shape[0]}")
-    gu = torch.empty(M, N, dtype=BF16, device=x.device)
+    rows = M if os.environ.get("RV_GU_TILE_MAJOR", "0") != "1" else (M + 255) // 256 * 256     # (experiment: tile-major gate|up, gemm.hip)
+    gu = torch.empty(rows, N, dtype=BF16, device=x.device)[:M]
     act = torch.empty(M, N // 2, dtype=BF16, device=x.device)
     hip.call("rv_gemm_nn_swiglu_bf16", x, x.stride(0), wguT, wguT.stride(0), gu, gu.stride(0), act, act.stride(0), M, N, K)
     return gu, act
