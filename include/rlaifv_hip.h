@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 6
+#define RV_ABI_VERSION 7
 
 const char* rv_last_error(void);
 int rv_abi_version(void);
@@ -59,6 +59,14 @@ int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
  * 512-byte row segments.  Large problems only (256x256 tiles); K % 32 == 0, N % 8 == 0. */
 int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* residual, long ldr, float alpha, void* stream);
+
+/* q|k|v projection with RoPE in the epilogue (ABI 7; HF apply_rotary_pos_emb on the outputs of q_proj / k_proj, reached through
+ * llava/model/language_model/llava_llama.py:91-102): C = A B with B the W^T copy [K][N] of the fused q|k|v weight; the first
+ * rope_cols columns (the q and k heads, head dim hd = 128) leave rotated - y1 = x1 cos - x2 sin, y2 = x2 cos + x1 sin for the
+ * half-split pairs (i, i + 64), tables [position][64] fp32 as rv_rope_inplace takes them, position = pos[token] or token % L - from
+ * the fp32 accumulators (one rounding; replaces rv_gemm_nn_bf16 + rv_rope_inplace).  N, rope_cols multiples of 256, K % 64 == 0. */
+int rv_gemm_nn_rope_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                         const float* cos_tab, const float* sin_tab, const int* pos, int L, int rope_cols, int hd, void* stream);
 
 /* gate|up projection with SwiGLU in the epilogue (HF LlamaMLP.forward: down_proj(act_fn(gate_proj(x)) * up_proj(x)),
  * reached through llava_llama.py:91-102).  B = the W^T copy [K][N] of the fused weight whose rows are INTERLEAVED

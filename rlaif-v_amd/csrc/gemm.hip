@@ -466,6 +466,37 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   return 0;
 }
 
+int rv_gemm_nn_rope_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                         const float* cos_tab, const float* sin_tab, const int* pos, int L, int rope_cols, int hd, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  RV_REQUIRE(hd == 128, "rv_gemm_nn_rope_bf16: head dim 128 only");
+  RV_REQUIRE(K >= 512 && K % 64 == 0, "rv_gemm_nn_rope_bf16: K must be a multiple of 64 and >= 512 (64-deep-A kernel)");
+  RV_REQUIRE(N % 256 == 0 && rope_cols % 256 == 0 && rope_cols >= 0 && rope_cols <= N,
+             "rv_gemm_nn_rope_bf16: N and rope_cols must be multiples of 256 (a 256-column tile holds q / k heads or v heads)");
+  RV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "rv_gemm_nn_rope_bf16: leading dimensions must be multiples of 8");
+  RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)cos_tab | (uintptr_t)sin_tab) & 15) == 0,
+             "rv_gemm_nn_rope_bf16: operands and tables must be 16-byte aligned");
+  RV_REQUIRE(cos_tab && sin_tab && L > 0, "rv_gemm_nn_rope_bf16: tables / L");
+  read_group_env();
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
+  EpiStoreRope epi{(bf16_t*)C, ldc, cos_tab, sin_tab, pos, L, rope_cols};
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStoreRope>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiStoreRope, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
+  if (nn_mi16())
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStoreRope, false, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  else
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiStoreRope>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
 int rv_gemm_nn_swiglu_bf16(const void* A, long lda, const void* B, long ldb, void* GU, long ldgu, void* ACT, long ldact,
                            int M, int N, int K, void* stream) {
   if (M == 0 || N == 0) return 0;

@@ -752,6 +752,10 @@ __device__ __forceinline__ void tn_tile_origin(int bid, int I, int J, int group,
 }
 
 struct EpiStoreF32;
+// An epilogue that wants a wave's 64 output columns as TWO 32-column blocks 64 columns apart (the half-split RoPE pairs (i, i + 64) of
+// a 128-wide head in the same lane and register: EpiStoreRope) declares `static constexpr bool kRopeCols = true`.
+template <class E, class = void> struct EpiRopeCols : std::false_type {};
+template <class E> struct EpiRopeCols<E, std::void_t<decltype(E::kRopeCols)>> : std::bool_constant<E::kRopeCols> {};
 
 template <class Epi, int DIST = 3, bool MI16 = false>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm_tn_256_kernel(const bf16_t* __restrict__ P, long ldp,
@@ -1238,9 +1242,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   const int a_sw = (fr >> 1) & 7;                               // (row >> 1) & 7 with row = wm*128 + t*32 + fr
   const int g4 = lane >> 4, s16 = lane & 15;
   const uint32_t lane_part = (uint32_t)((8 * (g4 >> 1) + (s16 >> 2)) * 512 + 32 * (g4 & 1) + 8 * (s16 & 3));
+  // the wave's two 32-column blocks of the 256-column tile: 2 wn, 2 wn + 1 - or, for the RoPE epilogue, blocks b and b + 2 of head
+  // wn >> 1 (columns c .. c + 31 and c + 64 .. c + 95: rotation partners meet in one lane; only the LDS column offset of the B
+  // fragments and the epilogue's column arithmetic change, the tile in HBM keeps its layout)
+  constexpr bool RC = EpiRopeCols<Epi>::value;
+  const int wblk = RC ? ((wn >> 1) * 4 + (wn & 1)) : wn * 2;
+  constexpr int wstep = RC ? 2 : 1;
   uint32_t q_blk[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) q_blk[t] = lane_part + (uint32_t)((((wn * 2 + t) ^ (s16 >> 2))) << 6);
+  for (int t = 0; t < 2; ++t) q_blk[t] = lane_part + (uint32_t)((((wblk + t * wstep) ^ (s16 >> 2))) << 6);
 
   // MI16 fragments: A tile t_m (16 rows): row wm*128 + 16 t_m + s16, 16-byte chunk 4h + g4 of the 64-deep row;
   // B tile t_n (16 columns): k rows 8 g4 + (s16 >> 2) (+4 for the second read of the pair), 64-byte block wn*2 + (t_n >> 1),
@@ -1249,7 +1259,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
   uint32_t q16[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-    q16[t] = (uint32_t)((8 * g4 + (s16 >> 2)) * 512) + (uint32_t)(((wn * 2 + (t >> 1)) ^ (s16 >> 2)) << 6) +
+    q16[t] = (uint32_t)((8 * g4 + (s16 >> 2)) * 512) + (uint32_t)(((wblk + (t >> 1) * wstep) ^ (s16 >> 2)) << 6) +
              (uint32_t)((((t & 1) ^ (g4 & 1)) << 5) + 8 * (s16 & 3));
 
   f32x16_t acc[MI16 ? 1 : 4][2];
@@ -1478,11 +1488,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm_nn_a64_kernel(GemmShape g,
     for (int hm = 0; hm < 2; ++hm) {
       f32x16_t blk[2][2];
       acc16_block_to_acc32(*reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[MI16 ? 4 * hm : 0]), blk, lane);
-      epi.apply(blk, m0 + wm * 128 + hm * 64, n0 + wn * 64, lane, g.M, g.N);
+      epi.apply(blk, m0 + wm * 128 + hm * 64, n0 + wblk * 32, lane, g.M, g.N);
     }
   } else {
-    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wn * 64, lane, g.M, g.N);
-    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[MI16 ? 0 : 2]), m0 + wm * 128 + 64, n0 + wn * 64, lane, g.M, g.N);
+    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), m0 + wm * 128, n0 + wblk * 32, lane, g.M, g.N);
+    epi.apply(*reinterpret_cast<f32x16_t(*)[2][2]>(&acc[MI16 ? 0 : 2]), m0 + wm * 128 + 64, n0 + wblk * 32, lane, g.M, g.N);
   }
 }
 
@@ -1820,6 +1830,68 @@ struct EpiStore {
           o.y = pack2bf(v[2], v[3]);
           *(uint2*)(C + (long)m * ldc + n) = o;
         }
+      }
+    }
+  }
+};
+
+// RoPE fused into the q|k|v projection (round 6; HF apply_rotary_pos_emb / rotate_half behind
+// llava_llama.py:91-102): the epilogue rotates the q and k heads from the fp32 ACCUMULATORS - one rounding instead of the two of
+// GEMM -> bf16 -> rope_kernel (7 % of the per-token error sat in that second rounding: profiles/r05_rounding_attribution.json) and
+// one pass over [tokens, 2 d] less per layer.  kRopeCols: the kernel hands this wave columns nw .. nw + 31 (tn = 0) and
+// nw + 64 .. nw + 95 (tn = 1) of one 128-wide head, so x1 = acc[tm][0][r] and x2 = acc[tm][1][r] are a rotation pair:
+//     y1 = x1 cos - x2 sin,   y2 = x2 cos + x1 sin        (tables [position][64] fp32, position = pos[m] or m % L)
+// Columns >= rope_cols (the v heads) are stored as they are.  Head dim 128 only; N, rope_cols multiples of 256.
+struct EpiStoreRope {
+  static constexpr bool kRopeCols = true;
+  bf16_t* C; long ldc;
+  const float* cos_tab; const float* sin_tab;
+  const int* pos; int L;
+  int rope_cols;
+  __device__ __forceinline__ void apply(f32x16_t (&acc)[2][2], int mw, int nw, int lane, int M, int N) const {
+    const int half = lane >> 5;
+    const bool rot = nw < rope_cols;                 // wave-uniform (a 256-column tile holds q / k heads or v heads, never both)
+    const int i0 = (nw & 127) + 8 * half;            // head-local index of the lane's first column of block tn = 0 (< 64)
+    f32x4_t cs[2][2][2], sn[2][2][2];                // [tm][rgp][first / second four columns]
+    if (rot) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int mc = min(mw + tm * 32 + (lane & 31), M - 1);
+        const long p = pos ? pos[mc] : (mc % L);
+#pragma unroll
+        for (int rgp = 0; rgp < 2; ++rgp) {
+          const float* c = cos_tab + p * 64 + i0 + rgp * 16;
+          const float* s_ = sin_tab + p * 64 + i0 + rgp * 16;
+          cs[tm][rgp][0] = *(const f32x4_t*)c;
+          cs[tm][rgp][1] = *(const f32x4_t*)(c + 4);
+          sn[tm][rgp][0] = *(const f32x4_t*)s_;
+          sn[tm][rgp][1] = *(const f32x4_t*)(s_ + 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int m = mw + tm * 32 + (lane & 31);
+      if (m >= M) continue;                       // lanes l and l+32 share m: partners skip together
+#pragma unroll
+      for (int rgp = 0; rgp < 2; ++rgp) {
+        float x1[8], x2[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          epi_xhalf(acc[tm][0][(2 * rgp) * 4 + j], acc[tm][0][(2 * rgp + 1) * 4 + j], half, x1[j], x1[4 + j]);
+          epi_xhalf(acc[tm][1][(2 * rgp) * 4 + j], acc[tm][1][(2 * rgp + 1) * 4 + j], half, x2[j], x2[4 + j]);
+        }
+        const int n1 = nw + rgp * 16 + 8 * half;
+        if (n1 >= N) continue;
+        float y1[8], y2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float c = rot ? cs[tm][rgp][j >> 2][j & 3] : 1.f, s_ = rot ? sn[tm][rgp][j >> 2][j & 3] : 0.f;
+          y1[j] = x1[j] * c - x2[j] * s_;
+          y2[j] = x2[j] * c + x1[j] * s_;
+        }
+        *(uint4*)(C + (long)m * ldc + n1) = epi_pack8(y1);
+        if (n1 + 64 < N) *(uint4*)(C + (long)m * ldc + n1 + 64) = epi_pack8(y2);
       }
     }
   }

@@ -54,7 +54,7 @@ class HipLib:
             fn = getattr(self.lib, name)          # AttributeError = header/library drift, fail loudly
             fn.restype = ctypes.c_char_p if ret.startswith("const char") else (ctypes.c_long if ret == "long" else ctypes.c_int)
             fn.argtypes = [_to_ctype(t) for t, _ in args]
-        if self.lib.rv_abi_version() != 6:
+        if self.lib.rv_abi_version() != 7:
             raise RuntimeError("librlaifv_hip.so ABI version mismatch")
 
     def last_error(self) -> str:

@@ -363,16 +363,22 @@ class LlavaDPOModel:
         # packed rows are concatenated without inter-row padding (splice.build_packed_plan pad_free; RV_PAD_FREE=0: every packed
         # row right-padded to the longest, the round-1..4 layout).  Log-probs are bit-identical either way (SURVEY 8a property (i))
         self.pad_free = os.environ.get("RV_PAD_FREE", "1") != "0"
-        # OPT-IN: the DECODER's residual stream in fp32 (RV_RESID_FP32=1).  o_proj / down_proj write their branch in bf16 without the
-        # residual operand; rv_rmsnorm_fwd_f32 adds it to the fp32 stream and normalises in one pass.  -25 % per-token RMS error for
-        # ~ +1.3 % step time: below the adoption line VERDICT r4 drew (sigma < 1.5e-3 for <= 1 %), so it stays off
-        self.resid_fp32 = os.environ.get("RV_RESID_FP32", "0") != "0"
+        # The DECODER's residual stream in fp32 - DEFAULT for the full fine-tune since round 6 (RV_RESID_FP32=0 restores the bf16
+        # stream; LoRA runs keep bf16: their fixtures were validated that way and the producer-side dropout kernels write bf16).
+        # o_proj / down_proj write their branch in bf16 without the residual operand; rv_rmsnorm_fwd_f32 adds it to the fp32 stream
+        # and normalises in one pass.  Decided on round 6's evidence (profiles/r06_cfg1_step_numerics.json): with
+        # SwiGLU and RoPE taken from fp32 accumulators the stream is what is left - per-token RMS error 0.035 -> 0.027 at 32 layers
+        # (the HF-style bf16 emulation: 0.053), and BASELINE config 1's literal batch - whose 1e-3 loss bar is a fraction of a sigma
+        # of ANY bf16 forward - lands at 4.2e-4 with it and at 2.6e-3 ... 3.9e-3 without.  Price: +1.1 % step time, +14 GB.
+        env = os.environ.get("RV_RESID_FP32")
+        self.resid_fp32 = (env != "0") if env not in (None, "") else (lora is None)
         # OPT-IN: peft's dropout semantics to the letter (RV_LORA_PEFT_MASKS=1): peft wraps every nn.Linear in its own lora.Linear with
         # its OWN nn.Dropout, so q / k / v (and gate / up) draw INDEPENDENT masks of the same input.  The default fuses them: one
         # dropped input per fused projection (same marginals, one pass over the activation instead of three).  See _module_seeds.
         self.lora_peft_masks = os.environ.get("RV_LORA_PEFT_MASKS", "0") != "0"
         self.clip_fp32_resid = os.environ.get("RV_CLIP_FP32_RESID", "1") != "0"      # default ON since round 5, see clip_features
         self.fuse_rope_bwd = os.environ.get("RV_FUSE_ROPE_BWD", "1") != "0"
+        self.fuse_rope_fwd = os.environ.get("RV_FUSE_ROPE_FWD", "1") != "0"      # RoPE in the q|k|v GEMM epilogue (ops.linear_rope)
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -743,8 +749,15 @@ class LlavaDPOModel:
             xn, rstd1, xnd = ops.rmsnorm_fwd_dropout(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps, p_drop, self._dropout_seed(i, 0))
         else:
             xn, rstd1 = ops.rmsnorm_fwd(x, st.p(f"layers.{i}.ln1"), cfg.rms_eps)
-        qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0, xd=xnd)
-        ops.rope_inplace(qkv, cos, sin, L, H + cfg.n_kv_heads, hd, pos=plan.pos)      # q heads then k heads
+        rope_cols = (H + cfg.n_kv_heads) * hd
+        if (self.lora is None and self.fuse_rope_fwd
+                and ops.linear_rope_ok(xn.shape[0], rope_cols + cfg.kv_dim, xn.shape[1], rope_cols, hd)):
+            # RoPE in the epilogue of the q|k|v projection, from the fp32 accumulators (round 6): no rope pass, one rounding less on Q / K
+            qkv = ops.linear_rope(xn, st.pT(f"layers.{i}.wqkv")[:, :rope_cols + cfg.kv_dim], cos, sin, plan.pos, L, rope_cols, hd)
+            t_qkv = xd_qkv = None
+        else:
+            qkv, t_qkv, xd_qkv = self._proj_fwd(xn, i, "qkv", drop_slot=0, xd=xnd)
+            ops.rope_inplace(qkv, cos, sin, L, H + cfg.n_kv_heads, hd, pos=plan.pos)      # q heads then k heads
         attn, lse = ops.attn_fwd(qkv, S, L, H, hd, True, 0, d, d + cfg.kv_dim, seg=plan.seg, kv_group=cfg.kv_group, rows=plan.rows)
         if self.resid_fp32:
             if drop:

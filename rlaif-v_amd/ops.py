@@ -75,6 +75,26 @@ def linear(x: torch.Tensor, w: torch.Tensor, wT: Optional[torch.Tensor], residua
     return gemm_nt(x, w, out=out, residual=residual)
 
 
+def linear_rope_ok(M: int, N: int, K: int, rope_cols: int, hd: int) -> bool:
+    """Whether ``linear_rope`` serves this q|k|v projection (else: ``linear`` + ``rope_inplace``)."""
+    return (hd == 128 and N % 256 == 0 and rope_cols % 256 == 0 and K % 64 == 0 and K >= 512
+            and ((M + 255) // 256) * (N // 256) >= 192)
+
+
+def linear_rope(x: torch.Tensor, wT: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: Optional[torch.Tensor], L: int,
+                rope_cols: int, hd: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv = x @ W_qkv^T with the q and k heads (the first ``rope_cols`` columns) leaving ROTATED: HF apply_rotary_pos_emb in the
+    epilogue of the projection (rv_gemm_nn_rope_bf16), from the fp32 accumulators - one rounding instead of two and no separate
+    pass over [tokens, 2 d].  wT = the [in, out] copy of the fused weight; cos / sin = rope_tables; pos = position per token or None."""
+    _chk2d(x, "x"), _chk2d(wT, "wT")
+    M, K = x.shape
+    N = wT.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=x.device)
+    hip.call("rv_gemm_nn_rope_bf16", x, x.stride(0), wT, wT.stride(0), out, out.stride(0), M, N, K, cos, sin, pos, L, rope_cols, hd)
+    return out
+
+
 def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
             alpha: float = 1.0) -> torch.Tensor:
     """out[i][j] = alpha * sum_r p[r][i] q[r][j] + residual[i][j]  (weight gradient dW = dY^T X)."""

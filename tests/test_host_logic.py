@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert len(lib.decls) >= 37
     for name in lib.decls:
         assert hasattr(lib.lib, name), name
-    assert lib.lib.rv_abi_version() == 6
+    assert lib.lib.rv_abi_version() == 7
     # argument errors are reported through the ABI (no launch happens for an invalid shape)
     assert lib.lib.rv_set_gemm_variant(7) == 1 and "rv_set_gemm_variant" in lib.last_error()
     assert lib.lib.rv_set_gemm_variant(1) == 0

@@ -957,6 +957,39 @@ def test_swiglu_fused_gemm_epilogues(ops, M, d, f):
     assert torch.equal(torch.cat([dgu_ref[:, 0::2], dgu_ref[:, 1::2]], 1), dblocks)
 
 
+@pytest.mark.parametrize("M,d,kvd,use_pos", [(27000, 1024, 1024, True), (13000, 2048, 512, False), (300, 1024, 1024, True)])
+def test_rope_fused_qkv_gemm_epilogue(ops, M, d, kvd, use_pos):
+    """RoPE in the epilogue of the q|k|v projection (rv_gemm_nn_rope_bf16, round 6): the q and k heads leave rotated from the fp32
+    accumulators.  Against the exact fp64 product + rotation it must be CLOSER than the unfused composition GEMM -> bf16 ->
+    rv_rope_inplace (two roundings) is, and agree with that composition to bf16 rounding; the v columns are the plain GEMM's, bit
+    for bit (grouped-query width kvd < d included); positions from a table (packed pairs) or token % L."""
+    dev = _dev()
+    hd, L = 128, 977
+    H, Hkv = d // hd, kvd // hd
+    N, rope_cols = d + 2 * kvd, d + kvd
+    x = rnd(M, d, seed=81, dev=dev, scale=1.0)
+    wT = rnd(d, N, seed=82, dev=dev, scale=0.06)
+    cos, sin = ops.rope_tables(2048, hd, 10000.0, dev)
+    pos = (torch.arange(M, device=dev, dtype=torch.int32) * 7 % 1500).contiguous() if use_pos else None
+    assert ops.linear_rope_ok(M, N, d, rope_cols, hd) == (M > 1000)
+    fused = ops.linear_rope(x, wT, cos, sin, pos, L, rope_cols, hd)
+    plain = ops.gemm_nn(x, wT)
+    assert torch.equal(fused[:, rope_cols:], plain[:, rope_cols:])
+    unfused = ops.rope_inplace(plain.clone(), cos, sin, L, H + Hkv, hd, pos=pos)
+    close(fused, unfused, rel=1.6e-2, what="fused rope vs gemm + rope_inplace")
+    # exact reference
+    y = (x.double() @ wT.double())
+    p = pos.long() if pos is not None else torch.arange(M, device=dev) % L
+    c, s_ = cos[p].double(), sin[p].double()                       # [M, 64]
+    yr = y[:, :rope_cols].reshape(M, H + Hkv, 2, 64)
+    x1, x2 = yr[:, :, 0], yr[:, :, 1]
+    ex = torch.stack([x1 * c[:, None] - x2 * s_[:, None], x2 * c[:, None] + x1 * s_[:, None]], 2).reshape(M, rope_cols)
+    e_f = (fused[:, :rope_cols].double() - ex).abs().mean().item()
+    e_u = (unfused[:, :rope_cols].double() - ex).abs().mean().item()
+    assert e_f < 0.85 * e_u, (e_f, e_u)
+    close(fused[:, :rope_cols], ex.float(), rel=8e-3, what="fused rope vs exact")
+
+
 @pytest.mark.parametrize("R,I,J", [(4096, 4096, 4608), (4352, 8192, 4352), (6000, 4104, 4600)])
 def test_gemm_tn_tail_split(ops, R, I, J, monkeypatch):
     """Weight-gradient GEMM whose last round of 256 tiles is partly filled: the tail tiles are split over the token axis into
