@@ -115,19 +115,29 @@ def _lora_fwd_bwd_case(monkeypatch, cfg, r, share_prefix):
 
 
 def test_lora_zero_b_is_bit_identical_to_base(monkeypatch):
-    """peft's initial adapter (lora_B = 0) must not change a single bit of the log-probs."""
+    """peft's initial adapter (lora_B = 0) must not change a single bit of the log-probs: the adapter model with B = 0 against the
+    same model with A = 0 as well (then t = x A^T is zero too) - the adapter segment of the fused GEMM adds exactly nothing.
+    Against the BASE (full fine-tune) model the log-probs agree to bf16 rounding only: since round 6 that model takes SwiGLU and RoPE
+    from fp32 accumulators in its GEMM epilogues and carries an fp32 residual stream, arithmetic the adapter path (separate
+    swiglu / rope kernels on bf16 tensors, bf16 stream) does not share."""
     _need_gpu()
     from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
     cfg = O.tiny_cfg()
     model, W = _build(cfg, 64, b_std=None)
+    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=5)
+    args = (batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"])
+    a = model.eval().forward_logps(*args, save_for_backward=False)
+    W0 = {k: (torch.zeros_like(v) if ".lora_A." in k else v) for k, v in W.items()}
+    assert any(".lora_A." in k and float(W[k].abs().sum()) > 0 for k in W)
+    zero, _ = _build(cfg, 64, b_std=None)
+    zero.load_state_dict(W0)
+    z = zero.eval().forward_logps(*args, save_for_backward=False)
+    assert torch.equal(a.per_token_logp, z.per_token_logp)
     base = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)))
     base.load_state_dict({k: v for k, v in W.items() if ".lora_" not in k})
-    batch = O.make_synthetic_batch(cfg, 2, 40, 12, seed=5)
-    a = model.eval().forward_logps(batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"],
-                                   save_for_backward=False)
-    b = base.eval().forward_logps(batch["concatenated_input_ids"], batch["concatenated_labels"], batch["images"],
-                                  save_for_backward=False)
-    assert torch.equal(a.per_token_logp, b.per_token_logp)
+    b = base.eval().forward_logps(*args, save_for_backward=False)
+    assert torch.allclose(a.per_token_logp, b.per_token_logp, rtol=0, atol=2e-2)
+    assert float((a.per_token_logp - b.per_token_logp).abs().mean()) <= 4e-3
 
 
 def test_lora_merge_and_adapter_roundtrip(tmp_path):
