@@ -75,6 +75,9 @@ class GemmTimer:
                                                                    + a.shape[0] * b.shape[1])),
         "gemm_nt_dropout": ("nt_dropout", lambda a, b, *r, **k: 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
                             lambda a, b, *r, **k: 2.0 * (a.numel() + b.numel() + 2 * a.shape[0] * b.shape[0])),
+        # q|k|v projection with RoPE in the epilogue (round 6): the plain NN kernel's work + two table reads per (row, 8 columns)
+        "linear_rope": ("nn_rope", lambda x, wT, *r, **k: 2.0 * x.shape[0] * wT.shape[1] * x.shape[1],
+                        lambda x, wT, *r, **k: 2.0 * (x.numel() + wT.numel() + x.shape[0] * wT.shape[1])),
         # gate|up projection with SwiGLU in the epilogue: writes gu [M, 2f] and act [M, f]
         "linear_swiglu": ("nn_swiglu", lambda x, wT, *r, **k: 2.0 * x.shape[0] * wT.shape[1] * x.shape[1],
                           lambda x, wT, *r, **k: 2.0 * (x.numel() + wT.numel() + 1.5 * x.shape[0] * wT.shape[1])),
@@ -608,7 +611,8 @@ def main():
                         pmc = json.load(fh)
                     traffic = pmc["gemm_all_launches_hbm_bytes_per_launch"]
                     for cls, kern in (("nn", "gemm_nn_a64_kernel<EpiStore"), ("tn", "gemm_tn_256_kernel<EpiStore"),
-                                      ("nn_swiglu", "gemm_nn_a64_kernel<EpiSwiGLU,"), ("nn_swiglu_bwd", "gemm_nn_a64_kernel<EpiSwiGLUBwd")):
+                                      ("nn_swiglu", "gemm_nn_a64_kernel<EpiSwiGLU,"), ("nn_swiglu_bwd", "gemm_nn_a64_kernel<EpiSwiGLUBwd"),
+                                      ("nn_rope", "gemm_nn_a64_kernel<EpiStoreRope")):
                         if kern in pmc.get("kernels", {}):
                             traffic_by_class[cls] = pmc["kernels"][kern]["hbm_bytes_per_launch_corrected"]
                     traffic_file = name
@@ -617,13 +621,14 @@ def main():
                     pass
             KNAME = {"nn": "gemm_nn_a64_kernel<EpiStore> (rv_gemm_nn_bf16)", "tn": "gemm_tn_256_kernel (rv_gemm_tn_bf16)",
                      "nt": "gemm_nt_256_kernel / gemm_nt_kernel (rv_gemm_nt_bf16)",
+                     "nn_rope": "gemm_nn_a64_kernel<EpiStoreRope> (rv_gemm_nn_rope_bf16: q|k|v projection with RoPE in the epilogue)",
                      "nn_swiglu": "gemm_nn_a64_kernel<EpiSwiGLU> (rv_gemm_nn_swiglu_bf16)",
                      "nn_swiglu_bwd": "gemm_nn_a64_kernel<EpiSwiGLUBwd> (rv_gemm_nn_swiglu_bwd_bf16)",
                      "nn_lora": "gemm_nn_a64_kernel<EpiStore, EXT> (rv_gemm_nn_lora_bf16)",
                      "nn_lora_pre": "gemm_nn_a64_kernel<EpiStore, PRE> (rv_gemm_nn_lora_pre_bf16)",
                      "lmhead_fwd": "gemm_nt_256_kernel<EpiLogpFwd> (rv_lmhead_logp_fwd)",
                      "lmhead_bwd": "gemm_nt_256_kernel<EpiLogpBwd> (rv_lmhead_logp_bwd)",
-                     "attn_fwd": "attn_fwd2_kernel (rv_attn_fwd: decoder packed-causal rows + the CLIP tower's full rows); algorithmic 4 hd "
+                     "attn_fwd": "attn_fwd2_kernel (rv_attn_fwd; version 3 = attn_fwd3_kernel is not the default: decoder packed-causal rows + the CLIP tower's full rows); algorithmic 4 hd "
                                  "flop per visible (query, key) pair and head",
                      "attn_bwd": "attn_bwd_dq2_kernel + attn_bwd_dkv5_kernel (rv_attn_bwd, two launches timed together); algorithmic 10 hd "
                                  "flop per visible pair and head (the pair of launches executes 14 hd: S and dP are recomputed in both)"}

@@ -22,7 +22,7 @@ def summarize(path, substr=None):
 
 
 GROUPS = ["gemm_nn_a64_kernel<EpiStore", "gemm_nn_256_kernel<EpiStore", "gemm_nt_256_kernel<EpiStore", "gemm_tn_256_kernel<EpiStore",
-          "gemm_nn_a64_kernel<EpiSwiGLU,", "gemm_nn_a64_kernel<EpiSwiGLUBwd", "gemm_nt_256_kernel<EpiLogpFwd", "gemm_nt_256_kernel<EpiLogpBwd",
+          "gemm_nn_a64_kernel<EpiSwiGLU,", "gemm_nn_a64_kernel<EpiSwiGLUBwd", "gemm_nn_a64_kernel<EpiStoreRope", "gemm_nt_256_kernel<EpiLogpFwd", "gemm_nt_256_kernel<EpiLogpBwd",
           "attn_fwd2_kernel<128", "attn_fwd3_kernel", "attn_bwd_dq2", "attn_bwd_dkv5", "adamw_kernel", "swiglu_fwd", "rmsnorm_fwd"]
 
 
