@@ -16,6 +16,8 @@
 #   omnilmm       bench.py --omnilmm (config 4 from pixels)
 #   prof          rocprofv3 --kernel-trace --stats of the headline bench (3 steps)
 #   pmc           HBM traffic per GEMM launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+#   pmcattn       PMC passes of the attention kernels at the bench shape (matrix-pipe busy, wait / issue-stall / active fractions)
+#   fwd3          forward attention version 3 against version 2: correctness on 19 shapes, 30-launch stress, timing A/B
 #   smoke         __graft_entry__.smoke()
 R=${RV_ROUND:-r06}
 export RV_ROUND=$R
@@ -39,6 +41,8 @@ for st in "$@"; do
     omnilmm)   timeout 900 python bench.py --omnilmm --no-dp-probe > $OUT/bench_line_omnilmm_pixels.json 2> $OUT/bench_omnilmm_err.log; head -c 600 $OUT/bench_line_omnilmm_pixels.json; echo ;;
     prof)      bash tools/profile_bench.sh $R/bench_kernel python $PWD/bench.py --steps 3 --no-cpu-baseline --no-dp-probe --no-gemm-timer; head -25 gpurun_out/$R/bench_kernel_stats.csv ;;
     pmc)       bash tools/collect_pmc_traffic.sh > $OUT/pmc_collect.log 2>&1; cp gpurun_out/pmc_hbm_traffic.json $OUT/pmc_hbm_traffic.json; tail -c 400 $OUT/pmc_hbm_traffic.json; echo ;;
+    pmcattn)   bash tools/pmc_attn_r04.sh $R 2>&1 | tail -4; cp gpurun_out/pmc_attn_$R.txt $OUT/pmc_attn.txt ;;
+    fwd3)      timeout 600 python tools/exp_attn_fwd3.py 2>&1 | tee $OUT/attn_fwd3.log | tail -16; timeout 300 python tools/exp_attn_fwd3.py --stress 2>&1 | tail -1 ;;
     smoke)     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log ;;
     *)         echo "unknown stage $st" ;;
   esac
