@@ -84,6 +84,14 @@ class GemmTimer:
         # down projection's input gradient with SwiGLU backward in the epilogue: reads gu [M, 2f], writes dgu [M, 2f]
         "linear_swiglu_bwd": ("nn_swiglu_bwd", lambda dy, w, gu, *r, **k: 2.0 * dy.shape[0] * w.shape[1] * dy.shape[1],
                               lambda dy, w, gu, *r, **k: 2.0 * (dy.numel() + w.numel() + 2 * gu.numel())),
+        # the same two for ADAPTER models (RV_LORA_FUSE_SWIGLU=1): the adapter segment rides in the K loop; the forward also writes the
+        # dropped activation when p > 0 (+0.5 x gu bytes)
+        "linear_lora_swiglu": ("nn_lora_swiglu", lambda x, wT, t, bexp, *r, **k: 2.0 * x.shape[0] * wT.shape[1] * (x.shape[1] + bexp.shape[0]),
+                               lambda x, wT, t, bexp, *r, **k: 2.0 * (x.numel() + wT.numel() + t.numel() + bexp.numel()
+                                                                       + 2.0 * x.shape[0] * wT.shape[1])),
+        "linear_lora_swiglu_bwd": ("nn_lora_swiglu_bwd",
+                                   lambda dy, w, dt, a, gu, *r, **k: 2.0 * dy.shape[0] * w.shape[1] * (dy.shape[1] + a.shape[0]),
+                                   lambda dy, w, dt, a, gu, *r, **k: 2.0 * (dy.numel() + w.numel() + dt.numel() + a.numel() + 2 * gu.numel())),
         # fused LM head: logits tile -> online log-softmax statistics (forward), recomputed tile -> dlogits (backward)
         "lmhead_logp_fwd": ("lmhead_fwd", lambda h, w, tgt, n, *r, **k: 2.0 * n * w.shape[0] * w.shape[1],
                             lambda h, w, tgt, n, *r, **k: 2.0 * (n * w.shape[1] + w.numel())),
@@ -626,6 +634,8 @@ def main():
                      "nn_swiglu_bwd": "gemm_nn_a64_kernel<EpiSwiGLUBwd> (rv_gemm_nn_swiglu_bwd_bf16)",
                      "nn_lora": "gemm_nn_a64_kernel<EpiStore, EXT> (rv_gemm_nn_lora_bf16)",
                      "nn_lora_pre": "gemm_nn_a64_kernel<EpiStore, PRE> (rv_gemm_nn_lora_pre_bf16)",
+                     "nn_lora_swiglu": "gemm_nn_a64_kernel<EpiSwiGLU, EXT> (rv_gemm_nn_lora_swiglu_bf16)",
+                     "nn_lora_swiglu_bwd": "gemm_nn_a64_kernel<EpiSwiGLUBwd, PRE> (rv_gemm_nn_lora_swiglu_bwd_bf16)",
                      "lmhead_fwd": "gemm_nt_256_kernel<EpiLogpFwd> (rv_lmhead_logp_fwd)",
                      "lmhead_bwd": "gemm_nt_256_kernel<EpiLogpBwd> (rv_lmhead_logp_bwd)",
                      "attn_fwd": "attn_fwd2_kernel (rv_attn_fwd; version 3 = attn_fwd3_kernel is not the default: decoder packed-causal rows + the CLIP tower's full rows); algorithmic 4 hd "

@@ -68,6 +68,20 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
 int rv_gemm_nn_rope_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                          const float* cos_tab, const float* sin_tab, const int* pos, int L, int rope_cols, int hd, void* stream);
 
+/* The two fused SwiGLU GEMMs for ADAPTER models (ABI 7; peft lora.Linear.forward of gate_proj / up_proj + LlamaMLP's act_fn(gate) * up,
+ * muffin/train/train_llava15_lora.py:304-318).  Forward: GU = [A | A2] [B | B2]^T with interleaved gate / up columns, ACT = silu(g) u,
+ * optionally ACTD = rv_dropout(ACT; p, seed) (the dropped adapter input of the down projection).  B2 = the expanded adapter matrix
+ * [K2 = 2 r][N]: rows 0..r-1 = lora_B(gate)^T on the even columns (zeros on the odd ones), rows r..2r-1 = lora_B(up)^T on the odd
+ * columns; A2 = t = (alpha / r) dropout(x) [lora_A(gate); lora_A(up)]^T [M][2 r].
+ * Backward: d(gate|up) = SwiGLU'(GU) o (A B + mask_{p,seed}(A2 B2) / (1 - p)) - the down projection's input gradient with the
+ * adapter term (A = dy, B = W_down [d][f], A2 = dt [M][r], B2 = lora_A(down) [r][f]; p = 0: no mask). */
+int rv_gemm_nn_lora_swiglu_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                                long ldb2, int K2, void* GU, long ldgu, void* ACT, long ldact, void* ACTD, float p, int seed,
+                                int M, int N, int K, void* stream);
+int rv_gemm_nn_lora_swiglu_bwd_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                                    long ldb2, int K2, float p, int seed, const void* GU, long ldgu, void* DGU, long lddgu,
+                                    int M, int N, int K, void* stream);
+
 /* gate|up projection with SwiGLU in the epilogue (HF LlamaMLP.forward: down_proj(act_fn(gate_proj(x)) * up_proj(x)),
  * reached through llava_llama.py:91-102).  B = the W^T copy [K][N] of the fused weight whose rows are INTERLEAVED
  * (row 2j = gate_j, row 2j+1 = up_j), N = 2 x ffn.  Writes GU [M][N] (kept for backward) and ACT [M][N/2] = silu(g) * u. */

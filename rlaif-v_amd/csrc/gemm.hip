@@ -568,6 +568,88 @@ int rv_gemm_nn_lora_bf16(const void* A, long lda, const void* B, long ldb, const
   return 0;
 }
 
+// gate|up projection of an ADAPTER model with SwiGLU in the epilogue (round 6): the fused-LoRA K loop
+// y = [x | t] [W | B2]^T of rv_gemm_nn_lora_bf16 with the epilogue of rv_gemm_nn_swiglu_bf16.  Interleaved gate / up columns; B2 is the
+// EXPANDED adapter matrix [K2 = 2 r][N]: row k < r carries lora_B(gate) on the even columns and zeros on the odd ones, row r + k
+// lora_B(up) on the odd columns - peft's adapters are per module, the zeros keep t_gate out of the up columns and vice versa.
+int rv_gemm_nn_lora_swiglu_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                                long ldb2, int K2, void* GU, long ldgu, void* ACT, long ldact, void* ACTD, float p, int seed,
+                                int M, int N, int K, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  RV_REQUIRE(K >= 512 && K % 64 == 0 && K2 > 0 && K2 % 64 == 0, "rv_gemm_nn_lora_swiglu_bf16: K % 64, K >= 512, K2 % 64");
+  RV_REQUIRE(N % 16 == 0, "rv_gemm_nn_lora_swiglu_bf16: N (= 2 x ffn, interleaved gate/up columns) must be a multiple of 16");
+  RV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ldgu % 8 == 0 && ldact % 4 == 0,
+             "rv_gemm_nn_lora_swiglu_bf16: bad leading dimension");
+  RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2 | (uintptr_t)GU) & 15) == 0 && ((uintptr_t)ACT & 7) == 0 &&
+             ((uintptr_t)ACTD & 7) == 0, "rv_gemm_nn_lora_swiglu_bf16: operands must be 16-byte aligned (activations: 8)");
+  RV_REQUIRE(p >= 0.f && p < 1.f && (ACTD == nullptr || ldact == N / 2), "rv_gemm_nn_lora_swiglu_bf16: 0 <= p < 1; ACTD needs a contiguous ACT");
+  read_group_env();
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group, (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, 0, 0};
+  EpiSwiGLU epi{(bf16_t*)GU, ldgu, (bf16_t*)ACT, ldact};
+  if (ACTD != nullptr && p > 0.f) {
+    epi.ACTD = (bf16_t*)ACTD;
+    epi.drop_thresh16 = (uint32_t)((double)p * 65536.0 + 0.5);
+    epi.drop_key = (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu;
+    epi.drop_inv_keep = 1.f / (1.f - p);
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiSwiGLU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiSwiGLU, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
+  if (nn_mi16())
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiSwiGLU, true, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  else
+    hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiSwiGLU, true>), dim3(tiles_m * tiles_n), dim3(G2_THREADS), G4_LDS_BYTES,
+                       (hipStream_t)stream, g, epi);
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
+// Input gradient of an ADAPTER model's down projection with the SwiGLU backward in the epilogue: acc = d act = dy W + [mask](dt A) / (1 - p)
+// (p > 0: the adapter-first form of rv_gemm_nn_lora_pre_bf16, mask of rv_dropout for the [M][N] activation; p = 0: the in-ring form
+// of rv_gemm_nn_lora_bf16), then d(gate|up) from the kept interleaved gate|up tile as rv_gemm_nn_swiglu_bwd_bf16 does.
+int rv_gemm_nn_lora_swiglu_bwd_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
+                                    long ldb2, int K2, float p, int seed, const void* GU, long ldgu, void* DGU, long lddgu,
+                                    int M, int N, int K, void* stream) {
+  if (M == 0 || N == 0) return 0;
+  RV_REQUIRE(K >= 512 && K % 64 == 0 && K2 > 0 && K2 % 64 == 0, "rv_gemm_nn_lora_swiglu_bwd_bf16: K % 64, K >= 512, K2 % 64");
+  RV_REQUIRE(N % 8 == 0, "rv_gemm_nn_lora_swiglu_bwd_bf16: N (= ffn) must be a multiple of 8");
+  RV_REQUIRE(p >= 0.f && p < 1.f, "rv_gemm_nn_lora_swiglu_bwd_bf16: 0 <= p < 1");
+  RV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ldgu % 8 == 0 && lddgu % 8 == 0,
+             "rv_gemm_nn_lora_swiglu_bwd_bf16: bad leading dimension");
+  RV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2 | (uintptr_t)GU | (uintptr_t)DGU) & 15) == 0,
+             "rv_gemm_nn_lora_swiglu_bwd_bf16: operands must be 16-byte aligned");
+  read_group_env();
+  GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group, (const bf16_t*)A2, (const bf16_t*)B2, lda2, ldb2, K2, 0, 0};
+  EpiSwiGLUBwd epi{(const bf16_t*)GU, ldgu, (bf16_t*)DGU, lddgu};
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiSwiGLUBwd, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiSwiGLUBwd, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiSwiGLUBwd, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nn_a64_kernel<EpiSwiGLUBwd, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+    attr_done = true;
+  }
+  const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
+  const dim3 grid(tiles_m * tiles_n), block(G2_THREADS);
+  if (p > 0.f) {
+    g.pre_thresh16 = (uint32_t)((double)p * 65536.0 + 0.5);
+    g.pre_key = (uint32_t)seed * 0x9e3779b9u + 0x85ebca6bu;
+    g.pre_inv_keep = 1.f / (1.f - p);
+    if (nn_mi16()) hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiSwiGLUBwd, false, true, true>), grid, block, G4_LDS_BYTES, (hipStream_t)stream, g, epi);
+    else hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiSwiGLUBwd, false, false, true>), grid, block, G4_LDS_BYTES, (hipStream_t)stream, g, epi);
+  } else {
+    if (nn_mi16()) hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiSwiGLUBwd, true, true>), grid, block, G4_LDS_BYTES, (hipStream_t)stream, g, epi);
+    else hipLaunchKernelGGL((gemm_nn_a64_kernel<EpiSwiGLUBwd, true>), grid, block, G4_LDS_BYTES, (hipStream_t)stream, g, epi);
+  }
+  RV_CHECK_LAUNCH();
+  return 0;
+}
+
 int rv_gemm_nn_lora_pre_bf16(const void* A, long lda, const void* B, long ldb, const void* A2, long lda2, const void* B2,
                              long ldb2, int K2, int group_cols, int group0, float p, int seed, void* C, long ldc, int M, int N,
                              int K, const void* residual, long ldr, void* stream) {

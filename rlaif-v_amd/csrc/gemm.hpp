@@ -1914,6 +1914,12 @@ struct EpiSwiGLU {
   // contiguous, tile (tm, tn) at ((tm * tiles_n + tn) << 16) - so that the backward epilogue reads two contiguous 128 KB regions
   // per output tile instead of 256 row segments 44 KB apart.  Requires a buffer of ceil(M / 256) * 256 rows.
   int tile_major = 0, tiles_n = 0;
+  // optional (round 6, fused-LoRA form rv_gemm_nn_lora_swiglu_bf16): ACTD = rv_dropout(ACT) for the contiguous [M][N/2] activation
+  // with the same (p, seed) - the dropped adapter input of the down projection, written by its producer (what
+  // swiglu_fwd_kernel<0, true> writes); drop_thresh16 = 0 / ACTD = NULL disables it
+  bf16_t* ACTD = nullptr;
+  uint32_t drop_thresh16 = 0, drop_key = 0;
+  float drop_inv_keep = 1.f;
   __device__ __forceinline__ long gu_index(int m, int n) const {
     return tile_major ? ((((long)(m >> 8) * tiles_n + (n >> 8)) << 16) + ((m & 255) << 8) + (n & 255)) : ((long)m * ldc + n);
   }
@@ -1943,6 +1949,17 @@ struct EpiSwiGLU {
           w.x = pack2bf(o[0], o[1]);
           w.y = pack2bf(o[2], o[3]);
           *(uint2*)(ACT + (long)m * lda + (n >> 1)) = w;
+          if (ACTD) {                   // rv_dropout's arithmetic on the ROUNDED activation (mask index = element index in [M][N/2])
+            const long e = (long)m * (N >> 1) + (n >> 1);
+            const uint32_t base = (uint32_t)(e >> 33) * 0x9e3779b9u + drop_key;
+            const uint32_t h0 = gemm_mix32((uint32_t)(e >> 1) ^ base), h1 = gemm_mix32(((uint32_t)(e >> 1) + 1u) ^ base);
+            const float a0 = bf2f((bf16_t)(w.x & 0xffff)), a1 = bf2f((bf16_t)(w.x >> 16));
+            const float a2 = bf2f((bf16_t)(w.y & 0xffff)), a3 = bf2f((bf16_t)(w.y >> 16));
+            uint2 wd;
+            wd.x = pack2bf(((h0 & 0xffffu) >= drop_thresh16) ? a0 * drop_inv_keep : 0.f, ((h0 >> 16) >= drop_thresh16) ? a1 * drop_inv_keep : 0.f);
+            wd.y = pack2bf(((h1 & 0xffffu) >= drop_thresh16) ? a2 * drop_inv_keep : 0.f, ((h1 >> 16) >= drop_thresh16) ? a3 * drop_inv_keep : 0.f);
+            *(uint2*)(ACTD + (long)m * (N >> 1) + (n >> 1)) = wd;
+          }
         }
       }
     }

@@ -164,7 +164,14 @@ class ParamStore:
         # Full fine-tune: the fused gate|up weight stores its rows INTERLEAVED (row 2j = gate_j, 2j+1 = up_j) so that the GEMM
         # epilogues can apply SwiGLU and its backward in registers (ops.linear_swiglu / linear_swiglu_bwd).  LoRA keeps
         # [gate | up] blocks (its adapter column groups address them).  RV_FUSE_SWIGLU=0: block layout + separate kernels.
-        self.interleave_gu = lora is None and os.environ.get("RV_FUSE_SWIGLU", "1") != "0"
+        fuse = os.environ.get("RV_FUSE_SWIGLU", "1") != "0"
+        # Round 6: adapter models can take the fused SwiGLU epilogues too (RV_LORA_FUSE_SWIGLU=1): the frozen gate|up weight AND the
+        # rows of the gate|up adapter lora_B are stored interleaved, and the fused GEMM's adapter segment runs over BOTH modules'
+        # t = x A^T columns against an EXPANDED lora_B^T whose zeros keep t_gate out of the up columns (``gu_bexp``).
+        self.lora_il = lora is not None and fuse and os.environ.get("RV_LORA_FUSE_SWIGLU", "0") == "1" \
+            and os.environ.get("RV_LORA_PEFT_MASKS", "0") == "0"      # (independent gate / up masks need two adapter inputs)
+        self.interleave_gu = fuse and (lora is None or self.lora_il)
+        self.gu_bexp: Dict[int, torch.Tensor] = {}      # layer -> [2 r_pad, 2 ffn] expanded transposed gate|up adapter (lora_il only)
         proj_w, proj_b = cfg.vision_param_entries()
         self.vision_keys = [k for k, _, _ in proj_w + proj_b]
         base_w: List[Entry] = [("lm_head.weight", (V, d), True)]
@@ -267,6 +274,24 @@ class ParamStore:
         for k in self.t_offsets:
             if not trainable_only or k in self.trainable:
                 ops.transpose(self.p(k), out=self.pT(k))
+        if self.lora_il:
+            self.refresh_gu_bexp()
+
+    def refresh_gu_bexp(self):
+        """lora_il: the expanded transposed gate|up adapter of every layer from its (row-interleaved) lora_B: rows 0..rp-1 =
+        lora_B(gate)^T on the even columns, rows rp..2rp-1 = lora_B(up)^T on the odd columns, zeros elsewhere (plumbing: 64
+        strided device copies of 2.8 MB per optimizer step)."""
+        rp = self.lora.r_pad
+        for key in self.t_offsets:
+            if not key.endswith("lora_gu.B"):
+                continue
+            i = int(key.split(".")[1])
+            BT = self.pT(key)                                   # [rp, 2f]: column 2j = lora_B(gate)[j], 2j + 1 = lora_B(up)[j]
+            e = self.gu_bexp.get(i)
+            if e is None:
+                e = self.gu_bexp[i] = torch.zeros(2 * rp, BT.shape[1], dtype=BT.dtype, device=BT.device)
+            e[:rp, 0::2].copy_(BT[:, 0::2])
+            e[rp:, 1::2].copy_(BT[:, 1::2])
 
     def sync_master_from_params(self):
         if self.flat_master is not None:
@@ -302,9 +327,15 @@ class ParamStore:
         return view[r0:r0 + n * step:step]
 
 
-    def lora_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int, int]]:
-        """peft adapter name (without the 'base_model.model.' prefix) -> (store key, first row, n rows, n cols)."""
-        m: Dict[str, Tuple[str, int, int, int]] = {}
+    @staticmethod
+    def lora_view(t: torch.Tensor, r0: int, n: int, ncol: int, step: int = 1) -> torch.Tensor:
+        """The peft tensor inside a store view: rows r0, r0 + step, ... (n of them), first ncol columns."""
+        return t[r0:r0 + n * step:step, :ncol]
+
+    def lora_slices(self, cfg: LlavaConfig) -> Dict[str, Tuple[str, int, int, int, int]]:
+        """peft adapter name (without the 'base_model.model.' prefix) -> (store key, first row, n rows, n cols, row step); the
+        tensor is ``lora_view(view(key), r0, n, ncol, step)`` (step 2 = the interleaved gate / up rows of lora_il's lora_gu.B)."""
+        m: Dict[str, Tuple[str, int, int, int, int]] = {}
         if self.lora is None:
             return m
         r, rp, d, f = self.lora.r, self.lora.r_pad, cfg.hidden, cfg.ffn
@@ -313,8 +344,11 @@ class ParamStore:
             for grp, mods in LORA_GROUPS.items():
                 for gi, (mod, (r0, rows)) in enumerate(zip(mods, lora_group_rows(cfg, grp))):
                     p = f"model.layers.{i}.{mod}."
-                    m[p + "lora_A.weight"] = (f"layers.{i}.lora_{grp}.A", gi * rp, r, in_cols[grp])
-                    m[p + "lora_B.weight"] = (f"layers.{i}.lora_{grp}.B", r0, rows, r)
+                    m[p + "lora_A.weight"] = (f"layers.{i}.lora_{grp}.A", gi * rp, r, in_cols[grp], 1)
+                    if grp == "gu" and self.lora_il:
+                        m[p + "lora_B.weight"] = (f"layers.{i}.lora_{grp}.B", gi, rows, r, 2)
+                    else:
+                        m[p + "lora_B.weight"] = (f"layers.{i}.lora_{grp}.B", r0, rows, r, 1)
         return m
 
 
@@ -476,8 +510,8 @@ class LlavaDPOModel:
         """peft LoraLayer.reset_lora_parameters: lora_A ~ kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)),
         lora_B = 0 (b_std: draw B ~ N(0, b_std) instead - tests and benchmarks that want a non-trivial adapter)."""
         st, g = self.store, torch.Generator(device=self.device).manual_seed(seed)
-        for name, (key, r0, n, ncol) in st.lora_slices(self.cfg).items():
-            view = st.p(key)[r0:r0 + n, :ncol]
+        for name, (key, r0, n, ncol, step) in st.lora_slices(self.cfg).items():
+            view = st.lora_view(st.p(key), r0, n, ncol, step)
             if name.endswith("lora_A.weight"):
                 bound = 1.0 / math.sqrt(ncol)
                 view.copy_(((torch.rand(n, ncol, device=self.device, generator=g) * 2 - 1) * bound).to(BF16))
@@ -491,9 +525,9 @@ class LlavaDPOModel:
         st = self.store
         norm = {k.replace("base_model.model.", "").replace(".default.", "."): v for k, v in sd.items() if ".lora_" in k}
         found = 0
-        for name, (key, r0, n, ncol) in st.lora_slices(self.cfg).items():
+        for name, (key, r0, n, ncol, step) in st.lora_slices(self.cfg).items():
             if name in norm:
-                st.p(key)[r0:r0 + n, :ncol].copy_(norm[name].to(BF16))
+                st.lora_view(st.p(key), r0, n, ncol, step).copy_(norm[name].to(BF16))
                 found += 1
             elif strict:
                 raise KeyError(f"adapter tensor {name} missing")
@@ -506,9 +540,9 @@ class LlavaDPOModel:
     def lora_state_dict(self, grads: bool = False) -> Dict[str, torch.Tensor]:
         """What get_peft_state_maybe_zero_3(named_parameters(), 'none') collects: 'base_model.model.<module>.lora_X.weight'."""
         st, out = self.store, {}
-        for name, (key, r0, n, ncol) in st.lora_slices(self.cfg).items():
+        for name, (key, r0, n, ncol, step) in st.lora_slices(self.cfg).items():
             src = st.g(key) if grads else st.p(key)
-            t = src[r0:r0 + n, :ncol].detach()
+            t = st.lora_view(src, r0, n, ncol, step).detach()
             out["base_model.model." + name] = t.float().cpu() if grads else t.cpu().clone()
         return out
 
@@ -526,6 +560,14 @@ class LlavaDPOModel:
         for i in range(cfg.layers):
             for grp in LORA_GROUPS:
                 W, B, AT = st.p(f"layers.{i}.w{grp}"), st.p(f"layers.{i}.lora_{grp}.B"), st.pT(f"layers.{i}.lora_{grp}.A")
+                if grp == "gu" and st.lora_il:
+                    # interleaved rows: W[2j + gi] += sc B[2j + gi] A_gi - one GEMM per module on contiguous copies (a one-off)
+                    for gi in range(2):
+                        Wg = W[gi::2].contiguous()
+                        ops.gemm_nt(B[gi::2].contiguous(), AT[:, gi * rp:(gi + 1) * rp].contiguous(), out=Wg, residual=Wg, alpha=sc)
+                        W[gi::2].copy_(Wg)
+                    B.zero_()
+                    continue
                 for gi, (r0, rows) in enumerate(lora_group_rows(cfg, grp)):
                     Wg = W[r0:r0 + rows]
                     ops.gemm_nt(B[r0:r0 + rows], AT[:, gi * rp:(gi + 1) * rp], out=Wg, residual=Wg, alpha=sc)
@@ -697,9 +739,16 @@ class LlavaDPOModel:
         groups = lora_group_rows(self.cfg, grp)                       # (first output column, width) per peft module
         G = len(groups)
         BT = st.pT(bkey)                                              # [rp, total output width]
-        dt = torch.empty(dy.shape[0], G * rp, dtype=BF16, device=self.device)
-        for g, (c0, og) in enumerate(groups):                         # dt_g = (alpha/r) dy_g B_g
-            ops.gemm_nt(dy[:, c0:c0 + og], BT[:, c0:c0 + og], out=dt[:, g * rp:(g + 1) * rp], alpha=sc)
+        il = grp == "gu" and st.lora_il                               # interleaved gate / up columns: the modules are column PARITIES
+        if il:
+            if self.training and self.lora.lora_dropout > 0.0 and self.lora_peft_masks:
+                raise NotImplementedError("RV_LORA_FUSE_SWIGLU with RV_LORA_PEFT_MASKS")
+            # dt = (alpha/r) dy bexp^T: the expanded adapter's zeros keep the gate columns of dy out of dt_up and vice versa
+            dt = ops.gemm_nt(dy, st.gu_bexp[i], alpha=sc)
+        else:
+            dt = torch.empty(dy.shape[0], G * rp, dtype=BF16, device=self.device)
+            for g, (c0, og) in enumerate(groups):                     # dt_g = (alpha/r) dy_g B_g
+                ops.gemm_nt(dy[:, c0:c0 + og], BT[:, c0:c0 + og], out=dt[:, g * rp:(g + 1) * rp], alpha=sc)
         if self.training and self.lora.lora_dropout > 0.0 and self.lora_peft_masks:
             # per-module masks: dx = dy W + sum_g mask_g * (dt_g A_g) / (1 - p); dA_g = dt_g^T dropout_g(x)
             p_, A, AT, gA = self.lora.lora_dropout, st.p(akey), st.pT(akey), st.g(akey)
@@ -724,9 +773,63 @@ class LlavaDPOModel:
             dx = ops.linear_lora(dy, st.pT(wkey), st.p(wkey), dt, st.pT(akey), st.p(akey), group_cols=0)
         ops.gemm_tn_skinny(dt, xin, out=st.g(akey))
         gB = st.g(bkey)
+        if il:
+            # dB of both modules from ONE product dy^T [t_gate | t_up] -> [2f, 2 rp]; row 2j keeps its first rp columns (gate),
+            # row 2j + 1 its last rp (up): the other halves are the cross terms the expanded adapter's zeros stand for
+            full = ops.gemm_tn_skinny(dy, t)
+            gB[0::2].copy_(full[0::2, :rp])
+            gB[1::2].copy_(full[1::2, rp:])
+            return dx
         for g, (c0, og) in enumerate(groups):
             ops.gemm_tn_skinny(dy[:, c0:c0 + og], t[:, g * rp:(g + 1) * rp], out=gB[c0:c0 + og])
         return dx
+
+    # ---- adapter models with interleaved gate|up layout (ParamStore.lora_il; RV_LORA_FUSE_SWIGLU=1, round 6) -----------------------
+    def _lora_gu_fwd(self, xn2: torch.Tensor, i: int, xn2d: Optional[torch.Tensor], p_drop: float):
+        """(gu, act, actd, t, xd) of the gate|up projection + SwiGLU of an adapter model: the fused-LoRA GEMM with the SwiGLU
+        epilogue (and the dropped activation for the down projection's adapter written by the same epilogue) at chip-filling
+        shapes, the unfused composition on the same layout otherwise."""
+        st, cfg = self.store, self.cfg
+        if self._lora_drop() and self.lora_peft_masks:
+            raise NotImplementedError("RV_LORA_FUSE_SWIGLU with RV_LORA_PEFT_MASKS")
+        xd = xn2d
+        if xd is None and self._lora_drop():
+            xd = ops.dropout(xn2, self.lora.lora_dropout, self._dropout_seed(i, 2))
+        t = ops.gemm_nt(xn2 if xd is None else xd, st.p(f"layers.{i}.lora_gu.A"), alpha=self.lora.scaling)
+        keep_xd = xd if self.keep_dropped_inputs else None
+        p3, seed3 = (self.lora.lora_dropout, self._dropout_seed(i, 3)) if self._lora_drop() else (0.0, 0)
+        bexp = st.gu_bexp[i]
+        if ops.linear_lora_swiglu_ok(xn2.shape[0], cfg.ffn, cfg.hidden, self.lora.r_pad):
+            # the producer-side dropped copy only when the fused-dropout path wants it (p_drop > 0), as swiglu_fwd_dropout does
+            gu, act, actd = ops.linear_lora_swiglu(xn2, st.pT(f"layers.{i}.wgu"), t, bexp, p3 if p_drop > 0.0 else 0.0, seed3)
+            return gu, act, actd, t, keep_xd
+        gu = ops.linear(xn2, st.p(f"layers.{i}.wgu"), st.pT(f"layers.{i}.wgu"))
+        ops.gemm_nn(t, bexp, out=gu, residual=gu)
+        act = ops.swiglu_fwd(gu, interleaved=True)
+        actd = ops.dropout(act, p3, seed3) if p_drop > 0.0 else None
+        return gu, act, actd, t, keep_xd
+
+    def _lora_down_bwd_swiglu(self, dy: torch.Tensor, act: torch.Tensor, t: torch.Tensor, i: int, xd: Optional[torch.Tensor],
+                              gu: torch.Tensor) -> torch.Tensor:
+        """d(gate|up) of an adapter model: the down projection's backward (_proj_bwd "down": dA, dB, input gradient) with the SwiGLU
+        backward in the epilogue of its input-gradient GEMM."""
+        st, cfg = self.store, self.cfg
+        rp, sc = self.lora.r_pad, self.lora.scaling
+        wkey, akey, bkey = f"layers.{i}.wdown", f"layers.{i}.lora_down.A", f"layers.{i}.lora_down.B"
+        if (self.training and self.lora.lora_dropout > 0.0 and self.lora_peft_masks) or \
+                not ops.linear_lora_swiglu_ok(dy.shape[0], cfg.ffn, cfg.hidden, rp):
+            dact = self._proj_bwd(dy, act, t, i, "down", drop_slot=3, xd=xd)
+            return ops.swiglu_bwd(dact, gu, interleaved=True)
+        dt = ops.gemm_nt(dy, st.pT(bkey), alpha=sc)                   # dt = (alpha/r) dy B_down: [M, rp]
+        drop = self.training and self.lora.lora_dropout > 0.0
+        p_, seed = (self.lora.lora_dropout, self._dropout_seed(i, 3)) if drop else (0.0, 0)
+        dgu = ops.linear_lora_swiglu_bwd(dy, st.p(wkey), dt, st.p(akey), gu, p_, seed)
+        xin = act
+        if drop:
+            xin = xd if xd is not None else ops.dropout(act, p_, seed)
+        ops.gemm_tn_skinny(dt, xin, out=st.g(akey))
+        ops.gemm_tn_skinny(dy, t, out=st.g(bkey))
+        return dgu
 
     def _layer_fwd(self, i: int, x: torch.Tensor, plan: SplicePlan, cos, sin, save: bool):
         """One decoder layer (HF LlamaDecoderLayer: RMSNorm, QKV, RoPE, causal attention, O + residual, RMSNorm, SwiGLU
@@ -771,9 +874,11 @@ class LlavaDPOModel:
                 xn2, rstd2, xn2d = ops.rmsnorm_fwd_dropout(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps, p_drop, self._dropout_seed(i, 2))
             else:
                 xn2, rstd2 = ops.rmsnorm_fwd(x_mid, st.p(f"layers.{i}.ln2"), cfg.rms_eps)
-        if st.interleave_gu:          # full fine-tune: SwiGLU in the epilogue of the gate|up GEMM (interleaved weight rows)
+        if st.interleave_gu and self.lora is None:   # full fine-tune: SwiGLU in the epilogue of the gate|up GEMM (interleaved weight rows)
             gu, act = ops.linear_swiglu(xn2, st.pT(f"layers.{i}.wgu"))
             t_gu = xd_gu = None
+        elif st.lora_il:              # adapter model, interleaved layout (RV_LORA_FUSE_SWIGLU=1): the same epilogue on the fused-LoRA GEMM
+            gu, act, actd, t_gu, xd_gu = self._lora_gu_fwd(xn2, i, xn2d, p_drop)
         else:
             gu, t_gu, xd_gu = self._proj_fwd(xn2, i, "gu", drop_slot=2, xd=xn2d)
             if drop:
@@ -915,10 +1020,13 @@ class LlavaDPOModel:
                 _, c = self._layer_fwd(i, c["x"], plan, cos, sin, True)
             act = c["act"] if c["act"] is not None else ops.swiglu_fwd(c["gu"], interleaved=st.interleave_gu)
             c["act"] = None
-            if st.interleave_gu:
+            if st.interleave_gu and self.lora is None:
                 # d(gate|up) straight out of the down projection's input-gradient GEMM (SwiGLU backward in its epilogue)
                 dgu = ops.linear_swiglu_bwd(dx, st.p(f"layers.{i}.wdown"), c["gu"])
                 ops.gemm_tn(dx, act, out=st.g(f"layers.{i}.wdown"))
+                del act
+            elif st.lora_il:
+                dgu = self._lora_down_bwd_swiglu(dx, act, c["t_down"], i, c["xd_down"], c["gu"])
                 del act
             else:
                 dact = self._proj_bwd(dx, act, c["t_down"], i, "down", drop_slot=3, xd=c["xd_down"])

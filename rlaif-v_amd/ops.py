@@ -481,6 +481,45 @@ def linear_swiglu(x: torch.Tensor, wguT: torch.Tensor):
     return gu, act
 
 
+def linear_lora_swiglu(x: torch.Tensor, wguT: torch.Tensor, t: torch.Tensor, bexp: torch.Tensor, p: float = 0.0, seed: int = 0):
+    """(gu, act, actd): the gate|up projection of an ADAPTER model with SwiGLU in the epilogue (rv_gemm_nn_lora_swiglu_bf16):
+    gu = x W_gu^T + t bexp (interleaved gate / up columns; t = (alpha / r) dropout(x) [A_gate; A_up]^T [M, 2 r_pad], bexp = the
+    expanded transposed adapter [2 r_pad, 2 f], ParamStore.gu_bexp), act = silu(gate) * up, actd = dropout(act; p, seed) when
+    p > 0 (the dropped adapter input of the down projection; None otherwise)."""
+    _chk2d(x, "x"), _chk2d(wguT, "wguT"), _chk2d(t, "t"), _chk2d(bexp, "bexp")
+    M, K = x.shape
+    N, K2 = wguT.shape[1], bexp.shape[0]
+    if wguT.shape[0] != K or t.shape != (M, K2) or bexp.shape[1] != N:
+        raise ValueError(f"linear_lora_swiglu: shapes x{tuple(x.shape)} wguT{tuple(wguT.shape)} t{tuple(t.shape)} bexp{tuple(bexp.shape)}")
+    gu = torch.empty(M, N, dtype=BF16, device=x.device)
+    act = torch.empty(M, N // 2, dtype=BF16, device=x.device)
+    actd = torch.empty_like(act) if p > 0.0 else None
+    hip.call("rv_gemm_nn_lora_swiglu_bf16", x, x.stride(0), wguT, wguT.stride(0), t, t.stride(0), bexp, bexp.stride(0), K2,
+             gu, gu.stride(0), act, act.stride(0), actd, float(p), int(seed) & 0x7FFFFFFF, M, N, K)
+    return gu, act, actd
+
+
+def linear_lora_swiglu_ok(M: int, f: int, d: int, r_pad: int) -> bool:
+    """Whether the fused adapter SwiGLU GEMMs serve this shape (chip-filling, 64-deep-A kernel)."""
+    return d % 64 == 0 and d >= 512 and r_pad % 64 == 0 and f % 8 == 0 and ((M + 255) // 256) * ((2 * f + 255) // 256) >= 192
+
+
+def linear_lora_swiglu_bwd(dy: torch.Tensor, w_down: torch.Tensor, dt: torch.Tensor, a_down: torch.Tensor, gu: torch.Tensor,
+                           p: float = 0.0, seed: int = 0):
+    """d(gate|up) [M, 2f] (interleaved like gu) of an ADAPTER model: SwiGLU'(gu) applied to d act = dy @ W_down +
+    mask_{p,seed}(dt @ A_down) / (1 - p) in the epilogue of that GEMM (rv_gemm_nn_lora_swiglu_bwd_bf16); d act never reaches HBM.
+    w_down [d, f] frozen base weight, a_down = lora_A of the down projection [r_pad, f], dt [M, r_pad]."""
+    _chk2d(dy, "dy"), _chk2d(w_down, "w_down"), _chk2d(dt, "dt"), _chk2d(a_down, "a_down"), _chk2d(gu, "gu")
+    M, K = dy.shape
+    f, K2 = w_down.shape[1], a_down.shape[0]
+    if w_down.shape[0] != K or gu.shape != (M, 2 * f) or dt.shape != (M, K2) or a_down.shape[1] != f:
+        raise ValueError("linear_lora_swiglu_bwd: shapes")
+    dgu = torch.empty_like(gu)
+    hip.call("rv_gemm_nn_lora_swiglu_bwd_bf16", dy, dy.stride(0), w_down, w_down.stride(0), dt, dt.stride(0), a_down, a_down.stride(0),
+             K2, float(p), int(seed) & 0x7FFFFFFF, gu, gu.stride(0), dgu, dgu.stride(0), M, f, K)
+    return dgu
+
+
 def linear_swiglu_bwd(dy: torch.Tensor, w_down: torch.Tensor, gu: torch.Tensor):
     """d(gate|up) [M, 2f] (interleaved like gu) = SwiGLU'(gu) applied to d act = dy @ W_down - the input gradient of the down
     projection with the SwiGLU backward in its epilogue (rv_gemm_nn_swiglu_bwd_bf16); d act never reaches HBM."""

@@ -538,10 +538,10 @@ def _trainable_views(model, flat: torch.Tensor):
         off, shp = st.offsets[key]
         off -= st.t0
         yield name, st.rows(flat[off:off + math.prod(shp)].view(*shp), r0, n, step)
-    for name, (key, r0, n, ncol) in st.lora_slices(cfg).items():           # peft adapter tensors (LoRA runs; empty otherwise)
+    for name, (key, r0, n, ncol, step) in st.lora_slices(cfg).items():     # peft adapter tensors (LoRA runs; empty otherwise)
         off, shp = st.offsets[key]
         off -= st.t0
-        yield name, flat[off:off + math.prod(shp)].view(*shp)[r0:r0 + n, :ncol]
+        yield name, st.lora_view(flat[off:off + math.prod(shp)].view(*shp), r0, n, ncol, step)
 
 
 def _take(view: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

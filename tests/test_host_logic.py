@@ -252,8 +252,8 @@ def test_param_store_lora_layout():
     W = O.make_lora_weights(O.tiny_cfg(), 16)
     sl = st.lora_slices(cfg)
     assert set(sl) == set(W)
-    for name, (key, r0, n, ncol) in sl.items():
-        assert tuple(st.p(key)[r0:r0 + n, :ncol].shape) == tuple(W[name].shape), name
+    for name, (key, r0, n, ncol, step) in sl.items():
+        assert tuple(st.lora_view(st.p(key), r0, n, ncol, step).shape) == tuple(W[name].shape), name
         assert key in st.trainable and key in st.t_offsets
     # trainable set == what the reference's LoRA run trains (adapters + mm_projector)
     full = dict(O.make_weights(O.tiny_cfg(), seed=0))

@@ -140,8 +140,10 @@ def test_lora_zero_b_is_bit_identical_to_base(monkeypatch):
     assert float((a.per_token_logp - b.per_token_logp).abs().mean()) <= 4e-3
 
 
-def test_lora_merge_and_adapter_roundtrip(tmp_path):
+@pytest.mark.parametrize("fuse_swiglu", [0, 1])
+def test_lora_merge_and_adapter_roundtrip(tmp_path, monkeypatch, fuse_swiglu):
     _need_gpu()
+    monkeypatch.setenv("RV_LORA_FUSE_SWIGLU", str(fuse_swiglu))      # 1: interleaved gate|up adapter rows in the store, peft layout on disk
     from rlaif_v_amd.checkpoint import load_lora_adapter, lora_config_from_dir, save_lora_adapter
     from rlaif_v_amd.model import LlavaConfig, LlavaDPOModel
     cfg = O.tiny_cfg()
@@ -159,6 +161,9 @@ def test_lora_merge_and_adapter_roundtrip(tmp_path):
     k = "base_model.model.model.layers.1.self_attn.v_proj.lora_B.weight"
     assert tuple(sd[k].shape) == (cfg.hidden, 16)
     assert torch.equal(sd[k], W["model.layers.1.self_attn.v_proj.lora_B.weight"].to(torch.bfloat16))
+    for mod in ("gate_proj", "up_proj"):
+        k2 = f"model.layers.1.mlp.{mod}.lora_B.weight"
+        assert torch.equal(sd["base_model.model." + k2], W[k2].to(torch.bfloat16))
     # fresh base + adapter directory -> same outputs; merged -> same within bf16 rounding of W + sBA
     m2 = LlavaDPOModel(LlavaConfig(**O.asdict(cfg)), lora=lora_config_from_dir(d), with_optimizer=False)
     m2.load_state_dict({k: v for k, v in W.items() if ".lora_" not in k})
@@ -171,9 +176,11 @@ def test_lora_merge_and_adapter_roundtrip(tmp_path):
     assert m2.store.p("layers.0.lora_qkv.B").abs().sum() == 0
 
 
-def test_lora_training_steps_match_oracle():
+@pytest.mark.parametrize("fuse_swiglu", [0, 1])
+def test_lora_training_steps_match_oracle(monkeypatch, fuse_swiglu):
     """Two optimizer steps (clip + AdamW on adapters + projector only); the frozen base must not move."""
     _need_gpu()
+    monkeypatch.setenv("RV_LORA_FUSE_SWIGLU", str(fuse_swiglu))
     cfg = O.tiny_cfg()
     model, W = _build(cfg, 64)
     model.lora.lora_dropout = 0.0
@@ -199,6 +206,11 @@ def test_lora_training_steps_match_oracle():
     # W^T copies of the adapters follow the update
     st = model.store
     assert torch.equal(st.pT("layers.0.lora_o.A"), st.p("layers.0.lora_o.A").t().contiguous())
+    if fuse_swiglu:     # and so does the expanded gate|up adapter the fused SwiGLU GEMM reads
+        B, rp = st.p("layers.1.lora_gu.B"), model.lora.r_pad
+        bexp = st.gu_bexp[1]
+        assert torch.equal(bexp[:rp, 0::2], B[0::2].t()) and torch.equal(bexp[rp:, 1::2], B[1::2].t())
+        assert bexp[:rp, 1::2].abs().sum() == 0 and bexp[rp:, 0::2].abs().sum() == 0
 
 
 def test_dropout_kernel_statistics():
@@ -340,10 +352,14 @@ def test_gemm_nn_lora_adapter_first_vs_adapter_last(M, N, K, gc, g0):
     assert (first != last).float().mean() < 0.02            # same products, another summation order: rare 1-ulp differences
 
 
-def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch):
-    """lora_dropout > 0: replay the device masks (regenerated from the model's seeds) inside the oracle."""
+@pytest.mark.parametrize("fuse_swiglu", [0, 1])
+def test_lora_dropout_training_matches_oracle_with_replayed_masks(monkeypatch, fuse_swiglu):
+    """lora_dropout > 0: replay the device masks (regenerated from the model's seeds) inside the oracle.  fuse_swiglu = 1: the
+    interleaved gate|up adapter layout (RV_LORA_FUSE_SWIGLU) on a model too small for the fused kernels - the unfused composition on
+    the interleaved layout, and the parity-split adapter gradients."""
     _need_gpu()
     from rlaif_v_amd import ops
+    monkeypatch.setenv("RV_LORA_FUSE_SWIGLU", str(fuse_swiglu))
     monkeypatch.setenv("SFT_weight", "0.0")
     monkeypatch.setenv("DPO_weight", "1.0")
     cfg = O.tiny_cfg()
@@ -420,8 +436,11 @@ def test_lora_peft_exact_per_module_dropout_masks(monkeypatch):
     assert (ref_shared["log_prob"].detach() - ref["log_prob"]).abs().max() > 1e-3
 
 
-def test_lora_full_width_dropout_one_pass_paths_vs_oracle(monkeypatch):
-    """Config 5's training step AS IT RUNS IN THE BENCH - adapter dropout on, production widths, enough rows that the projections take
+@pytest.mark.parametrize("fuse_swiglu", [0, 1])
+def test_lora_full_width_dropout_one_pass_paths_vs_oracle(monkeypatch, fuse_swiglu):
+    """(fuse_swiglu = 1: RV_LORA_FUSE_SWIGLU - interleaved gate|up layout, SwiGLU and the dropped activation in the epilogue of the
+    fused-LoRA gate|up GEMM, SwiGLU backward in the epilogue of the down projection's adapter-first input-gradient GEMM; round 6.)
+    Config 5's training step AS IT RUNS IN THE BENCH - adapter dropout on, production widths, enough rows that the projections take
     the chip-filling kernels: the adapter-first input-gradient GEMM with the mask on its accumulators (rv_gemm_nn_lora_pre_bf16), the
     dropped projection inputs written by the RMSNorm / SwiGLU kernels, the streaming NT kernel for t and dt - against the fp32 oracle
     with the device's masks replayed (2 full-width layers, r = 64, p = 0.05, 2 pairs of L = 1064: 4,256 rows)."""
@@ -431,6 +450,7 @@ def test_lora_full_width_dropout_one_pass_paths_vs_oracle(monkeypatch):
     from rlaif_v_amd import hip, ops
     monkeypatch.setenv("SFT_weight", "0.0")
     monkeypatch.setenv("DPO_weight", "1.0")
+    monkeypatch.setenv("RV_LORA_FUSE_SWIGLU", str(fuse_swiglu))
     cfg = O.LlavaCfg(layers=2, clip_layers=3, image_size=112, model_max_length=2048)      # 64 patches, 3-layer CLIP-L width
     p = 0.05
     model, W = _build(cfg, 64, seed=17, dropout=p, share_prefix=False)     # reference row layout: masks index [S L, in]
@@ -466,7 +486,13 @@ def test_lora_full_width_dropout_one_pass_paths_vs_oracle(monkeypatch):
     coef_ref = torch.cat([-beta * sig / Bq, beta * sig / Bq])
     model.backward(out, coef_ref.to(model.last_coef.device, model.last_coef.dtype))
     monkeypatch.setattr(hip, "call", orig_call)
-    assert {"rv_gemm_nn_lora_pre_bf16", "rv_rmsnorm_fwd_dropout", "rv_swiglu_fwd_dropout"} <= called, sorted(called)
+    assert model.store.lora_il == bool(fuse_swiglu)
+    if fuse_swiglu:
+        assert {"rv_gemm_nn_lora_pre_bf16", "rv_rmsnorm_fwd_dropout", "rv_gemm_nn_lora_swiglu_bf16",
+                "rv_gemm_nn_lora_swiglu_bwd_bf16"} <= called, sorted(called)
+        assert not {"rv_swiglu_fwd_dropout", "rv_swiglu_fwd", "rv_swiglu_bwd"} & called, sorted(called)
+    else:
+        assert {"rv_gemm_nn_lora_pre_bf16", "rv_rmsnorm_fwd_dropout", "rv_swiglu_fwd_dropout"} <= called, sorted(called)
     assert "rv_gemm_nt_dropout_bf16" not in called
     print(f"  loss coefficients x B / beta: HIP forward {(coef_hip[Bq:] * Bq / beta).tolist()}, oracle {sig.tolist()}")
     rel = ((out.seq_logp.cpu() - lp_ref).abs() / lp_ref.abs()).max().item()
@@ -500,7 +526,8 @@ def test_lora_full_width_dropout_one_pass_paths_vs_oracle(monkeypatch):
     assert (ref0["log_prob"].detach() - lp_ref).abs().max() > 1e-2
 
 
-def test_lora_full_width_shallow_vs_oracle(monkeypatch):
+@pytest.mark.parametrize("fuse_swiglu", [0, 1])
+def test_lora_full_width_shallow_vs_oracle(monkeypatch, fuse_swiglu):
     """BASELINE config 5's adapter shapes at production widths: r = 64 on all seven projections of 2 full-width layers
     (d 4096, f 11008): the fused NN-form LoRA GEMM (256-wide column groups), the split-K adapter gradients and the frozen
     base, against the fp32 oracle.  (The oracle's adapter arithmetic is pinned to peft only when the wheel is present:
@@ -510,6 +537,7 @@ def test_lora_full_width_shallow_vs_oracle(monkeypatch):
         pytest.skip("needs the 288 GB part")
     monkeypatch.setenv("SFT_weight", "0.0")
     monkeypatch.setenv("DPO_weight", "1.0")
+    monkeypatch.setenv("RV_LORA_FUSE_SWIGLU", str(fuse_swiglu))
     cfg = O.LlavaCfg(layers=2, clip_layers=3, image_size=112, model_max_length=2048)      # 64 patches, 3-layer CLIP-L width
     model, W = _build(cfg, 64, seed=13)
     model.train()
