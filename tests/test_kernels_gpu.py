@@ -957,6 +957,54 @@ def test_swiglu_fused_gemm_epilogues(ops, M, d, f):
     assert torch.equal(torch.cat([dgu_ref[:, 0::2], dgu_ref[:, 1::2]], 1), dblocks)
 
 
+@pytest.mark.parametrize("M,d,f,p", [(6200, 1024, 2048, 0.0), (5003, 512, 3072, 0.05), (12345, 1088, 1536, 0.3)])
+def test_lora_swiglu_fused_gemm_epilogues(ops, M, d, f, p):
+    """The same two epilogues on the fused-LoRA GEMMs (rv_gemm_nn_lora_swiglu_bf16 / rv_gemm_nn_lora_swiglu_bwd_bf16, round 6;
+    RV_LORA_FUSE_SWIGLU): gate|up = x W^T + [t_gate | t_up] bexp with the expanded adapter's zeros keeping the modules apart, the
+    activation from the fp32 accumulators, dropout(act) = rv_dropout of the ROUNDED activation written by the same epilogue;
+    backward d(gate|up) = SwiGLU'(gu) o (dy W_down + mask o (dt A_down) / (1 - p)).  Ragged row counts, three widths."""
+    dev = _dev()
+    rp, seed = 64, 12345
+    assert ops.linear_lora_swiglu_ok(M, f, d, rp)
+    x = rnd(M, d, seed=91, dev=dev, scale=1.0)
+    wguT = rnd(d, 2 * f, seed=92, dev=dev, scale=0.06)
+    t = rnd(M, 2 * rp, seed=93, dev=dev, scale=0.5)
+    bexp = torch.zeros(2 * rp, 2 * f, dtype=torch.bfloat16, device=dev)
+    bexp[:rp, 0::2] = rnd(rp, f, seed=94, dev=dev, scale=0.1)
+    bexp[rp:, 1::2] = rnd(rp, f, seed=95, dev=dev, scale=0.1)
+    gu, act, actd = ops.linear_lora_swiglu(x, wguT, t, bexp, p, seed)
+    exact_gu = x.double() @ wguT.double() + t.double() @ bexp.double()
+    close(gu, exact_gu.float(), rel=6e-3, what="lora swiglu gate|up")
+    exact = torch.nn.functional.silu(exact_gu[:, 0::2]) * exact_gu[:, 1::2]
+    close(act, exact.float(), rel=6e-3, what="lora swiglu act")
+    unfused = ops.swiglu_fwd(gu, interleaved=True)
+    e_f, e_u = (act.double() - exact).abs().mean().item(), (unfused.double() - exact).abs().mean().item()
+    assert e_f < 0.75 * e_u, (e_f, e_u)
+    if p > 0:
+        assert torch.equal(actd, ops.dropout(act, p, seed))
+        keep = float((actd != 0).float().mean()) / max(float((act != 0).float().mean()), 1e-9)
+        assert abs(keep - (1 - p)) < 5e-3
+    else:
+        assert actd is None
+    # backward
+    dy = rnd(M, d, seed=96, dev=dev, scale=0.5)
+    w_down = rnd(d, f, seed=97, dev=dev, scale=0.06)
+    dt = rnd(M, rp, seed=98, dev=dev, scale=0.5)
+    a_down = rnd(rp, f, seed=99, dev=dev, scale=0.1)
+    dgu = ops.linear_lora_swiglu_bwd(dy, w_down, dt, a_down, gu, p, seed)
+    ad = dt.double() @ a_down.double()
+    if p > 0:
+        mask = (ops.dropout(torch.ones(M, f, dtype=torch.bfloat16, device=dev), p, seed) != 0).double() / (1 - p)
+        ad = ad * mask
+    dact = (dy.double() @ w_down.double() + ad).float().bfloat16()          # the unfused path rounds d act once; so does the epilogue
+    ref = ops.swiglu_bwd(dact, gu, interleaved=True)
+    close(dgu, ref.float(), rel=1.6e-2, what="lora swiglu d(gate|up)")
+    g32, u32, da = gu.float()[:, 0::2], gu.float()[:, 1::2], dact.float()
+    sg = torch.sigmoid(g32)
+    close(dgu[:, 0::2], da * u32 * sg * (1 + g32 * (1 - sg)), rel=1.6e-2, what="lora swiglu d gate")
+    close(dgu[:, 1::2], da * g32 * sg, rel=1.6e-2, what="lora swiglu d up")
+
+
 @pytest.mark.parametrize("M,d,kvd,use_pos", [(27000, 1024, 1024, True), (13000, 2048, 512, False), (300, 1024, 1024, True)])
 def test_rope_fused_qkv_gemm_epilogue(ops, M, d, kvd, use_pos):
     """RoPE in the epilogue of the q|k|v projection (rv_gemm_nn_rope_bf16, round 6): the q and k heads leave rotated from the fp32
