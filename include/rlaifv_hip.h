@@ -59,6 +59,11 @@ int rv_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
  * 512-byte row segments.  Large problems only (256x256 tiles); K % 32 == 0, N % 8 == 0. */
 int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* residual, long ldr, float alpha, void* stream);
+/* The same with the bias / activation epilogue of rv_gemm_nt_bf16: C = act(alpha * A B + bias[n]) + residual (ABI 7).  For frozen,
+ * forward-only towers whose nn.Linear weights (with bias; fc1 + GELU) are kept ONLY in the [in][out] orientation: the EVA02 blocks
+ * behind omnilmm/model/omnilmm.py:31-43 (timm Attention.qkv / proj, Mlp.fc1 / fc2). */
+int rv_gemm_nn_bias_act_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                             const void* bias, const void* residual, long ldr, int act, float alpha, void* stream);
 
 /* q|k|v projection with RoPE in the epilogue (ABI 7; HF apply_rotary_pos_emb on the outputs of q_proj / k_proj, reached through
  * llava/model/language_model/llava_llama.py:91-102): C = A B with B the W^T copy [K][N] of the fused q|k|v weight; the first

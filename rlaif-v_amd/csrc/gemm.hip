@@ -427,8 +427,23 @@ int rv_gemm_nt_lora_bf16(const void* A, long lda, const void* B, long ldb, const
   return dispatch_ext(g, epi, stream);
 }
 
+static int nn_bias_act(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, const void* bias,
+                       const void* residual, long ldr, int act, float alpha, void* stream);
+
 int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                     const void* residual, long ldr, float alpha, void* stream) {
+  return nn_bias_act(A, lda, B, ldb, C, ldc, M, N, K, nullptr, residual, ldr, RV_ACT_NONE, alpha, stream);
+}
+
+int rv_gemm_nn_bias_act_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                             const void* bias, const void* residual, long ldr, int act, float alpha, void* stream) {
+  RV_REQUIRE(act == RV_ACT_NONE || act == RV_ACT_QUICK_GELU || act == RV_ACT_GELU, "rv_gemm_nn_bias_act_bf16: unknown activation");
+  RV_REQUIRE(bias == nullptr || ((uintptr_t)bias & 15) == 0, "rv_gemm_nn_bias_act_bf16: bias must be 16-byte aligned");
+  return nn_bias_act(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, act, alpha, stream);
+}
+
+static int nn_bias_act(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, const void* bias,
+                       const void* residual, long ldr, int act, float alpha, void* stream) {
   if (M == 0 || N == 0) return 0;
   RV_REQUIRE(K > 0 && K % G2_BK == 0, "rv_gemm_nn_bf16: K must be a positive multiple of 32");
   RV_REQUIRE(N % 8 == 0 && N >= 8, "rv_gemm_nn_bf16: N must be a multiple of 8");
@@ -437,7 +452,7 @@ int rv_gemm_nn_bf16(const void* A, long lda, const void* B, long ldb, void* C, l
   RV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "rv_gemm_nn_bf16: A/B must be 16-byte aligned");
   read_group_env();
   GemmShape g{(const bf16_t*)A, (const bf16_t*)B, M, N, K, lda, ldb, g_group};
-  EpiStore epi{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, RV_ACT_NONE, alpha};
+  EpiStore epi{(bf16_t*)C, ldc, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, alpha};
   epi.narrow = epi_narrow();
   static bool attr_done = false;
   static int use_a64 = 1;          // RV_GEMM_NN_A64=0: 32-deep A tiles (gemm_nn_256_kernel) also when K % 64 == 0

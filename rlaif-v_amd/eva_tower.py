@@ -14,6 +14,10 @@ architecture from the timm 0.9.10 ``models/eva.py`` definition as the author kno
 tests/test_omnilmm_gpu.py checks the kernels against oracle/omnilmm_oracle.py::eva_forward_features - a restatement by the
 same author, i.e. self-consistency, not parity with timm.  Use ``OmniLMMDPOModel.set_vision_tower(EvaTower(...))``.
 
+Weight orientation (round 6): the tower is frozen and forward-only, so each block's four nn.Linear weights are kept ONLY as
+W^T [in][out] and go through the NN GEMM with the bias / GELU epilogue (rv_gemm_nn_bias_act_bf16: the weight tile arrives in full
+512-byte row segments; RV_EVA_NN=0 keeps [out][in] and the NT kernels).
+
 Head dim 112 on the 128-wide attention kernels: every head is stored zero-padded to 128 (zero q / k columns add nothing to
 the scores, zero v columns produce zero outputs that meet zero rows of the output projection) and the q rows carry the
 factor sqrt(128 / 112) so that the kernels' 1 / sqrt(128) becomes 1 / sqrt(112).
@@ -71,6 +75,7 @@ class EvaTower:
         self.cfg, self.device = cfg, torch.device(device)
         self.w: Dict[str, torch.Tensor] = {}
         self._pos: Dict[int, torch.Tensor] = {}
+        self.nn_form = False             # the block weights are stored transposed ([in][out]) for the NN GEMM
 
     # ---- weights (timm names under ``prefix``)
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = ""):
@@ -110,6 +115,7 @@ class EvaTower:
             w[f"{i}.fc2.w"], w[f"{i}.fc2.b"] = dev16(t(p + "mlp.fc2.weight")), dev16(t(p + "mlp.fc2.bias"))
         w["norm.w"], w["norm.b"] = dev16(t("norm.weight")), dev16(t("norm.bias"))
         self._pos = {}
+        self._finalize_layout()
 
     def init_random(self, seed: int = 0, std: float = 0.02):
         """Random weights of the full architecture drawn directly on the device (benchmarks: no checkpoint exists offline;
@@ -145,7 +151,24 @@ class EvaTower:
             w[f"{i}.fc2.w"], w[f"{i}.fc2.b"] = rn(d, c.mlp), rn(d)
         w["norm.w"], w["norm.b"] = ln()
         self._pos = {}
+        self._finalize_layout()
         return self
+
+    def _finalize_layout(self):
+        """Block weights to [in][out] (one tensor at a time: no second copy of the 8.8 GB tower is ever alive)."""
+        c = self.cfg
+        self.nn_form = (os.environ.get("RV_EVA_NN", "1") != "0"
+                        and all(k % 32 == 0 for k in (c.width, c.heads * 128, c.mlp)))      # K % 32 of the NN kernels
+        if not self.nn_form:
+            return
+        for i in range(c.blocks_used):
+            for key in (f"{i}.wqkv", f"{i}.wo", f"{i}.fc1.w", f"{i}.fc2.w"):
+                self.w[key] = self.w[key].t().contiguous()
+
+    def _linear(self, x: torch.Tensor, key: str, bias: torch.Tensor, act: int = ops.ACT_NONE) -> torch.Tensor:
+        if self.nn_form:
+            return ops.gemm_nn(x, self.w[key], bias=bias, act=act)
+        return ops.gemm_nt(x, self.w[key], bias=bias, act=act)
 
     def n_params(self) -> int:
         """Parameters of the un-padded architecture (accounting)."""
@@ -185,25 +208,25 @@ class EvaTower:
             # x become roundings of the (small) post-norm branch outputs; the GEMM operands are bf16 casts of the stream.
             x32 = ops.cast_bf16_to_f32(x)
             for i in range(c.blocks_used):
-                qkv = ops.gemm_nt(x, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"])
+                qkv = self._linear(x, f"{i}.wqkv", w[f"{i}.bqkv"])
                 a, _ = ops.attn_fwd(qkv, B, T, H, 128, False, 0, H * 128, 2 * H * 128)
-                o = ops.gemm_nt(a, w[f"{i}.wo"], bias=w[f"{i}.bo"])
+                o = self._linear(a, f"{i}.wo", w[f"{i}.bo"])
                 x32 = ops.add_f32_bf16(x32, ops.layernorm_fwd(o, w[f"{i}.norm1.w"], w[f"{i}.norm1.b"], c.eps))
                 x = ops.cast_f32_to_bf16(x32)
-                h = ops.gemm_nt(x, w[f"{i}.fc1.w"], bias=w[f"{i}.fc1.b"], act=ops.ACT_GELU)
-                m = ops.gemm_nt(h, w[f"{i}.fc2.w"], bias=w[f"{i}.fc2.b"])
+                h = self._linear(x, f"{i}.fc1.w", w[f"{i}.fc1.b"], ops.ACT_GELU)
+                m = self._linear(h, f"{i}.fc2.w", w[f"{i}.fc2.b"])
                 x32 = ops.add_f32_bf16(x32, ops.layernorm_fwd(m, w[f"{i}.norm2.w"], w[f"{i}.norm2.b"], c.eps))
                 x = ops.cast_f32_to_bf16(x32)
             x = ops.layernorm_fwd_f32in(x32, w["norm.w"], w["norm.b"], c.eps)
             idx = (torch.arange(B, device=self.device)[:, None] * T + 1 + torch.arange(P, device=self.device)[None]).reshape(-1)
             return ops.gather_rows(x, idx.to(torch.int32)).view(B, P, d)
         for i in range(c.blocks_used):
-            qkv = ops.gemm_nt(x, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"])
+            qkv = self._linear(x, f"{i}.wqkv", w[f"{i}.bqkv"])
             a, _ = ops.attn_fwd(qkv, B, T, H, 128, False, 0, H * 128, 2 * H * 128)
-            o = ops.gemm_nt(a, w[f"{i}.wo"], bias=w[f"{i}.bo"])
+            o = self._linear(a, f"{i}.wo", w[f"{i}.bo"])
             x = ops.add_rows(x, ops.layernorm_fwd(o, w[f"{i}.norm1.w"], w[f"{i}.norm1.b"], c.eps))
-            h = ops.gemm_nt(x, w[f"{i}.fc1.w"], bias=w[f"{i}.fc1.b"], act=ops.ACT_GELU)
-            m = ops.gemm_nt(h, w[f"{i}.fc2.w"], bias=w[f"{i}.fc2.b"])
+            h = self._linear(x, f"{i}.fc1.w", w[f"{i}.fc1.b"], ops.ACT_GELU)
+            m = self._linear(h, f"{i}.fc2.w", w[f"{i}.fc2.b"])
             x = ops.add_rows(x, ops.layernorm_fwd(m, w[f"{i}.norm2.w"], w[f"{i}.norm2.b"], c.eps))
         x = ops.layernorm_fwd(x, w["norm.w"], w["norm.b"], c.eps)
         idx = (torch.arange(B, device=self.device)[:, None] * T + 1 + torch.arange(P, device=self.device)[None]).reshape(-1)

@@ -49,8 +49,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 
 
 def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
-            residual: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
-    """out[m][n] = alpha * sum_k a[m][k] b[k][n] + residual[m][n]   (b row-major [K, N]: rv_gemm_nn_bf16)."""
+            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, bias: Optional[torch.Tensor] = None,
+            act: int = ACT_NONE) -> torch.Tensor:
+    """out[m][n] = act(alpha * sum_k a[m][k] b[k][n] + bias[n]) + residual[m][n]   (b row-major [K, N]: rv_gemm_nn_bf16;
+    with bias / activation: rv_gemm_nn_bias_act_bf16)."""
     _chk2d(a, "a"), _chk2d(b, "b")
     M, K = a.shape
     Kb, N = b.shape
@@ -59,6 +61,10 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
     _chk2d(out, "out")
+    if bias is not None or act != ACT_NONE:
+        hip.call("rv_gemm_nn_bias_act_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, K, bias, residual,
+                 residual.stride(0) if residual is not None else 0, int(act), float(alpha))
+        return out
     hip.call("rv_gemm_nn_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, K, residual,
              residual.stride(0) if residual is not None else 0, float(alpha))
     return out

@@ -957,6 +957,32 @@ def test_swiglu_fused_gemm_epilogues(ops, M, d, f):
     assert torch.equal(torch.cat([dgu_ref[:, 0::2], dgu_ref[:, 1::2]], 1), dblocks)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(8200, 1792, 2048, 0), (8200, 6144, 1792, 0), (8200, 15360, 1792, 2), (300, 264, 96, 1),
+                                        (4100, 1024, 544, 2)])
+def test_gemm_nn_bias_act(ops, M, N, K, act):
+    """rv_gemm_nn_bias_act_bf16 (round 6): the NN kernels with the bias / activation epilogue of the NT ones - what the frozen EVA
+    tower's linears run on with their weights kept only as W^T.  Against torch fp32 and against rv_gemm_nt_bf16 on the other
+    orientation of the same weight (same products, another summation order)."""
+    dev = _dev()
+    x = rnd(M, K, seed=61, dev=dev, scale=1.0)
+    w = rnd(N, K, seed=62, dev=dev, scale=0.05)
+    bias = rnd(N, seed=63, dev=dev, scale=0.5)
+    res = rnd(M, N, seed=64, dev=dev, scale=1.0)
+    wT = w.t().contiguous()
+    got = ops.gemm_nn(x, wT, bias=bias, act=act, residual=res)
+    y = x.float() @ w.float().t() + bias.float()
+    if act == 1:
+        y = y * torch.sigmoid(1.702 * y)
+    elif act == 2:
+        y = torch.nn.functional.gelu(y)
+    close(got, y + res.float(), what="gemm_nn bias/act")
+    if K % 64 == 0:              # (the NT kernels step K by 64; K = 96 / 544 run the 32-deep NN kernel)
+        nt = ops.gemm_nt(x, w, bias=bias, act=act, residual=res)
+        assert (got.float() - nt.float()).abs().max().item() <= 2e-2 * y.abs().max().item()
+        assert (got != nt).float().mean().item() < 0.2          # mostly the same bf16 values: only the summation order differs
+    assert torch.equal(ops.gemm_nn(x, wT), ops.gemm_nn(x, wT, bias=None, act=0))
+
+
 @pytest.mark.parametrize("M,d,f,p", [(6200, 1024, 2048, 0.0), (5003, 512, 3072, 0.05), (12345, 1088, 1536, 0.3)])
 def test_lora_swiglu_fused_gemm_epilogues(ops, M, d, f, p):
     """The same two epilogues on the fused-LoRA GEMMs (rv_gemm_nn_lora_swiglu_bf16 / rv_gemm_nn_lora_swiglu_bwd_bf16, round 6;
